@@ -1,0 +1,122 @@
+"""CPU oracle for the UCFP hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  The product (ucfp_amd/) must never import it: a product path that routes
+through the oracle voids every parity claim.
+
+PARITY STATUS: see the header of each ucfp_oracle_*.c.  The image / audio / text
+arithmetic of the reference lives in un-vendored crates (imgfprint 0.4.1, audiofp 0.3.0,
+txtfp 0.2.0) -> "parity unpinned" beyond the sizes/layouts the reference's tests hold;
+cosine kNN is restated from in-tree code and is pinned by the reference's own tests.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libucfp_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (no-op when the .so is newer than the sources)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    srcs.append(os.path.join(_HERE, "..", "include", "ucfp_dct32.h"))
+    if not force and os.path.exists(_SO):
+        so_m = os.path.getmtime(_SO)
+        if all(os.path.getmtime(s) <= so_m for s in srcs if os.path.exists(s)):
+            return _SO
+    subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(l):
+    l.ucfp_oracle_image_hash_batch.restype = C.c_int
+    l.ucfp_oracle_image_hash_batch.argtypes = [
+        C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t,
+        C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.ucfp_oracle_image_normalize.restype = None
+    l.ucfp_oracle_image_normalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
+                                              C.c_int, C.c_void_p]
+    l.ucfp_oracle_image_hashes17.restype = None
+    l.ucfp_oracle_image_hashes17.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    l.ucfp_oracle_image_region_gray32.restype = None
+    l.ucfp_oracle_image_region_gray32.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    l.ucfp_oracle_image_phash_coefs.restype = None
+    l.ucfp_oracle_image_phash_coefs.argtypes = [C.c_void_p, C.c_void_p]
+    l.ucfp_oracle_image_synth.restype = None
+    l.ucfp_oracle_image_synth.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t]
+
+
+ALGO = {"ahash": 1, "phash": 2, "dhash": 4, "multi": 7}
+_BPP = {0: 1, 1: 3, 2: 4}
+
+
+def image_hash_batch(frames: np.ndarray, algo: int, pixfmt: int = 0, exact=None,
+                     min_dim: int = 32, max_dim: int = 8192):
+    """frames: uint8 [n, h, w] (GRAY8) or [n, h, w, 3|4]. Returns (records [n, rec] u8, status [n] i32)."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, h, w = frames.shape[:3]
+    bpp = _BPP[pixfmt]
+    assert frames.size == n * h * w * bpp
+    rec = 536 if algo == 7 else 168
+    out = np.zeros((n, rec), np.uint8)
+    status = np.zeros(n, np.int32)
+    ex = None
+    if exact is not None:
+        ex = np.ascontiguousarray(exact, dtype=np.uint8)
+        assert ex.shape == (n, 32)
+    lib().ucfp_oracle_image_hash_batch(
+        algo, frames.ctypes.data, n, w, h, w * bpp, h * w * bpp, pixfmt, min_dim, max_dim,
+        ex.ctypes.data if ex is not None else None, out.ctypes.data, status.ctypes.data)
+    return out, status
+
+
+def image_normalize(frame: np.ndarray, pixfmt: int = 0) -> np.ndarray:
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w = frame.shape[:2]
+    norm = np.zeros((256, 256), np.uint8)
+    lib().ucfp_oracle_image_normalize(frame.ctypes.data, w, h, w * _BPP[pixfmt], pixfmt,
+                                      norm.ctypes.data)
+    return norm
+
+
+def image_hashes17(norm: np.ndarray, which: int) -> np.ndarray:
+    norm = np.ascontiguousarray(norm, dtype=np.uint8)
+    hs = np.zeros(17, np.uint64)
+    lib().ucfp_oracle_image_hashes17(norm.ctypes.data, which, hs.ctypes.data)
+    return hs
+
+
+def image_region_gray32(norm: np.ndarray, r: int) -> np.ndarray:
+    norm = np.ascontiguousarray(norm, dtype=np.uint8)
+    g = np.zeros((32, 32), np.uint8)
+    lib().ucfp_oracle_image_region_gray32(norm.ctypes.data, r, g.ctypes.data)
+    return g
+
+
+def image_phash_coefs(g32: np.ndarray) -> np.ndarray:
+    g32 = np.ascontiguousarray(g32, dtype=np.uint8)
+    co = np.zeros(64, np.float32)
+    lib().ucfp_oracle_image_phash_coefs(g32.ctypes.data, co.ctypes.data)
+    return co.reshape(8, 8)
+
+
+def image_synth(n: int, w: int, h: int, first: int = 0) -> np.ndarray:
+    out = np.zeros((n, h, w), np.uint8)
+    lib().ucfp_oracle_image_synth(out.ctypes.data, n, w, h, first)
+    return out

@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly the
+symbols include/ucfp_hip.h declares; host-only entry points work; device entry points fail
+loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ucfp_amd import _lib, errors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "ucfp_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ucfp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    syms = _header_symbols()
+    assert len(syms) >= 8
+    lib = _lib.load()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in ucfp_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in ucfp_amd/_lib.py"
+    for s in _lib.SIGNATURES:
+        assert s in syms, f"{s} bound in _lib.py but not declared in ucfp_hip.h"
+
+
+def test_abi_version_and_record_sizes():
+    lib = _lib.load()
+    assert lib.ucfp_abi_version() == 1
+    # pinned by the reference: 536-B bundle (src/server/tests.rs:1206), 168-B single
+    # (web/src/lib/components/charts/algorithmView.ts:11-17)
+    assert lib.ucfp_image_record_bytes(7) == 536
+    for a in (1, 2, 4):
+        assert lib.ucfp_image_record_bytes(a) == 168
+    assert lib.ucfp_image_record_bytes(3) == 0
+
+
+def test_blake3_known_answers():
+    from ucfp_amd.blake3 import blake3_digest
+    # official BLAKE3 test vectors (input byte i = i % 251)
+    assert blake3_digest(b"").hex() == \
+        "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+    assert blake3_digest(b"abc").hex() == \
+        "6437b3ac38465133ffb63b75273a8db548c558465d79db03fd359c6cd5bd9d85"
+    assert blake3_digest(bytes(i % 251 for i in range(1025))).hex() == \
+        "d00278ae47eb27b34faecf67b4fe263f82d5412916c1ffd97c8cb7fb814b8444"
+    assert blake3_digest(bytes(i % 251 for i in range(31744))).hex().startswith(
+        "62b6960e1a44bcc1eb1a611a8d6235b6")
+
+
+def test_error_mapping_matches_reference_http_codes():
+    # src/server/error.rs:24-34
+    assert errors.ModalityError.http_status == 400
+    assert errors.UnsupportedError.http_status == 501
+    assert errors.IndexError_.http_status == 500
+    assert errors.RecordNotFound.http_status == 404
+    assert isinstance(errors.from_status(-1, "x"), errors.ModalityError)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present; the loud-failure path is exercised on CPU-only hosts")
+    with pytest.raises(errors.UcfpError):
+        _lib.Context(0)
+    msg = _lib.load().ucfp_last_error().decode()
+    assert "no CPU path" in msg or "HIP" in msg
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure; nothing under ucfp_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "ucfp_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), (dp, fn)
+                assert not re.search(r'#include\s*"[^"]*oracle', txt), (dp, fn)
+                assert "libucfp_oracle" not in txt, (dp, fn)

@@ -1,0 +1,101 @@
+"""ctypes binding of libucfp_hip.so -- the C ABI declared in include/ucfp_hip.h.
+
+There is no fallback: if the shared library is missing or no gfx950 device is present the
+import of a compute entry point fails loudly (the product path never routes through CPU code).
+"""
+import ctypes as C
+import os
+import threading
+
+from . import errors
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libucfp_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+
+class ImagePreprocess(C.Structure):
+    """ucfp_image_preprocess (imgfprint::PreprocessConfig guards)."""
+    _fields_ = [("max_dimension", C.c_uint32), ("min_dimension", C.c_uint32)]
+
+
+# name -> (restype, argtypes); every symbol of include/ucfp_hip.h appears here and
+# tests/test_abi.py checks the two lists against each other.
+SIGNATURES = {
+    "ucfp_abi_version": (C.c_int, []),
+    "ucfp_last_error": (C.c_char_p, []),
+    "ucfp_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ucfp_ctx_destroy": (None, [C.c_void_p]),
+    "ucfp_image_record_bytes": (C.c_size_t, [C.c_uint32]),
+    "ucfp_image_hash_batch_dev": (C.c_int, [
+        C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
+        C.c_size_t, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p]),
+    "ucfp_image_hash_batch": (C.c_int, [
+        C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
+        C.c_size_t, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                       C.c_uint32, C.c_size_t, C.c_void_p]),
+}
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and declare every signature. Raises if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(SO_PATH):
+                raise ImportError(
+                    f"{SO_PATH} is missing: run `python -m ucfp_amd.build` (or "
+                    "__graft_entry__.build()). ucfp_amd has no CPU fallback.")
+            lib = C.CDLL(SO_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().ucfp_last_error().decode("utf-8", "replace")
+        raise errors.from_status(rc, msg)
+
+
+class Context:
+    """Owns one ucfp_ctx (one per process per GPU). `device` is the HIP ordinal (LOCAL_RANK)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        check(self._lib.ucfp_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    with _lock:
+        ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            _default_ctx[device] = ctx
+    return ctx

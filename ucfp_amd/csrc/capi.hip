@@ -1,0 +1,207 @@
+// capi.hip -- extern "C" boundary (include/ucfp_hip.h) over the HIP launchers.
+// No torch, no C++ types in signatures. No CPU fallback: every entry point needs a HIP device.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "../../include/ucfp_hip.h"
+#include "common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(UCFP_E_INDEX, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+constexpr size_t kNormWsFrames = 256;  // generic-geometry normalised planes held at once (16 MiB)
+
+}  // namespace
+
+struct ucfp_ctx {
+    int device = 0;
+    uint8_t* norm_ws = nullptr;  // kNormWsFrames x 65536
+    // host-variant staging (grown on demand), guarded by `mu`
+    std::mutex mu;
+    uint8_t* stage_in = nullptr;
+    size_t stage_in_cap = 0;
+    uint8_t* stage_out = nullptr;
+    size_t stage_out_cap = 0;
+    hipStream_t host_stream = nullptr;
+};
+
+namespace {
+
+int grow(uint8_t** p, size_t* cap, size_t need) {
+    if (*cap >= need) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 4;
+    HIP_TRY(hipMalloc((void**)p, want));
+    *cap = want;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ucfp_abi_version(void) { return UCFP_ABI_VERSION; }
+
+const char* ucfp_last_error(void) { return g_err; }
+
+int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
+    if (!out) return fail(UCFP_E_INVALID, "ucfp_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(UCFP_E_INDEX, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count)
+        return fail(UCFP_E_INVALID, "device %d out of range [0,%d)", device_id, count);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(UCFP_E_UNSUPPORTED, "device %d is %s; kernels are built for gfx950 only",
+                    device_id, prop.gcnArchName);
+    ucfp_ctx* c = new (std::nothrow) ucfp_ctx();
+    if (!c) return fail(UCFP_E_INDEX, "out of host memory");
+    c->device = device_id;
+    hipError_t e2 = hipMalloc((void**)&c->norm_ws, kNormWsFrames * 65536);
+    if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking);
+    if (e2 != hipSuccess) {
+        ucfp_ctx_destroy(c);
+        return fail(UCFP_E_INDEX, "context allocation failed: %s", hipGetErrorString(e2));
+    }
+    *out = c;
+    return UCFP_OK;
+}
+
+void ucfp_ctx_destroy(ucfp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->norm_ws) (void)hipFree(c->norm_ws);
+    if (c->stage_in) (void)hipFree(c->stage_in);
+    if (c->stage_out) (void)hipFree(c->stage_out);
+    if (c->host_stream) (void)hipStreamDestroy(c->host_stream);
+    delete c;
+}
+
+size_t ucfp_image_record_bytes(uint32_t algo) {
+    if (algo == UCFP_IMG_MULTI) return UCFP_IMAGE_MULTI_BYTES;
+    if (algo == UCFP_IMG_AHASH || algo == UCFP_IMG_PHASH || algo == UCFP_IMG_DHASH)
+        return UCFP_IMAGE_FP_BYTES;
+    return 0;
+}
+
+static int image_check(ucfp_ctx* ctx, uint32_t algo, const void* frames, size_t n, uint32_t w,
+                       uint32_t h, size_t row_stride, size_t frame_stride, int pixfmt,
+                       const void* out) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (ucfp_image_record_bytes(algo) == 0)
+        return fail(UCFP_E_UNSUPPORTED, "image algo mask %u is not one of ahash|phash|dhash|multi", algo);
+    if (pixfmt < UCFP_PIX_GRAY8 || pixfmt > UCFP_PIX_RGBA8)
+        return fail(UCFP_E_INVALID, "unknown pixfmt %d", pixfmt);
+    if (n && (!frames || !out)) return fail(UCFP_E_INVALID, "frames/out is NULL");
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    if (w == 0 || h == 0) return fail(UCFP_E_MODALITY, "empty image %ux%u", w, h);
+    if (row_stride < (size_t)w * bpp) return fail(UCFP_E_INVALID, "row_stride %zu < width*bpp", row_stride);
+    if (n > 1 && frame_stride < row_stride * (size_t)(h - 1) + (size_t)w * bpp)
+        return fail(UCFP_E_INVALID, "frame_stride %zu overlaps frames", frame_stride);
+    if (n > 0x7fffffffu) return fail(UCFP_E_INVALID, "batch of %zu frames exceeds one launch", n);
+    return UCFP_OK;
+}
+
+int ucfp_image_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t n,
+                              uint32_t width, uint32_t height, size_t row_stride,
+                              size_t frame_stride, int pixfmt, const ucfp_image_preprocess* pre,
+                              const uint8_t* exact, uint8_t* out, int32_t* status, void* stream) {
+    int rc = image_check(ctx, algo, frames, n, width, height, row_stride, frame_stride, pixfmt, out);
+    if (rc) return rc;
+    const uint32_t min_dim = pre ? pre->min_dimension : 32u;
+    const uint32_t max_dim = pre ? pre->max_dimension : 8192u;
+    ucfp::launch_image_hash(algo, frames, n, width, height, row_stride, frame_stride, pixfmt,
+                            min_dim, max_dim, exact, out, status, ctx->norm_ws, kNormWsFrames,
+                            (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UCFP_OK;
+}
+
+int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t n,
+                          uint32_t width, uint32_t height, size_t row_stride, size_t frame_stride,
+                          int pixfmt, const ucfp_image_preprocess* pre, const uint8_t* exact,
+                          uint8_t* out, int32_t* status) {
+    int rc = image_check(ctx, algo, frames, n, width, height, row_stride, frame_stride, pixfmt, out);
+    if (rc) return rc;
+    if (n == 0) return UCFP_OK;
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    const size_t rec = ucfp_image_record_bytes(algo);
+    // Stage densely packed and 16-byte aligned so the fused path is taken whenever geometry allows.
+    const size_t d_row = (((size_t)width * bpp) + 15) & ~(size_t)15;
+    const size_t d_frame = d_row * height;
+    const size_t in_bytes = d_frame * n;
+    const size_t out_bytes = n * rec + n * 32 + n * sizeof(int32_t);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = grow(&ctx->stage_in, &ctx->stage_in_cap, in_bytes);
+    if (rc) return rc;
+    rc = grow(&ctx->stage_out, &ctx->stage_out_cap, out_bytes);
+    if (rc) return rc;
+    hipStream_t st = ctx->host_stream;
+    if (frame_stride == row_stride * height || n == 1) {
+        // frames are one tall image: a single strided copy
+        HIP_TRY(hipMemcpy2DAsync(ctx->stage_in, d_row, frames, row_stride, (size_t)width * bpp,
+                                 (size_t)height * n, hipMemcpyHostToDevice, st));
+    } else {
+        for (size_t i = 0; i < n; i++)
+            HIP_TRY(hipMemcpy2DAsync(ctx->stage_in + i * d_frame, d_row, frames + i * frame_stride,
+                                     row_stride, (size_t)width * bpp, height, hipMemcpyHostToDevice, st));
+    }
+    uint8_t* d_out = ctx->stage_out;
+    uint8_t* d_exact = ctx->stage_out + n * rec;
+    int32_t* d_status = reinterpret_cast<int32_t*>(ctx->stage_out + n * rec + n * 32);
+    if (exact) HIP_TRY(hipMemcpyAsync(d_exact, exact, n * 32, hipMemcpyHostToDevice, st));
+    const uint32_t min_dim = pre ? pre->min_dimension : 32u;
+    const uint32_t max_dim = pre ? pre->max_dimension : 8192u;
+    ucfp::launch_image_hash(algo, ctx->stage_in, n, width, height, d_row, d_frame, pixfmt, min_dim,
+                            max_dim, exact ? d_exact : nullptr, d_out, d_status, ctx->norm_ws,
+                            kNormWsFrames, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, n * rec, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return UCFP_OK;
+}
+
+int ucfp_image_synth_dev(ucfp_ctx* ctx, uint8_t* frames, size_t n, uint32_t width, uint32_t height,
+                         size_t first_index, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (n && !frames) return fail(UCFP_E_INVALID, "frames is NULL");
+    if (((size_t)width * height) % 4 != 0 || ((uintptr_t)frames & 3))
+        return fail(UCFP_E_INVALID, "synth needs width*height %% 4 == 0 and a 4-byte aligned base");
+    ucfp::launch_image_synth(frames, n, width, height, first_index, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UCFP_OK;
+}
+
+}  // extern "C"

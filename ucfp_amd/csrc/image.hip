@@ -1,0 +1,514 @@
+// image.hip -- batched aHash / pHash / dHash for gfx950 (MI355X).
+//
+// Replaces the arithmetic behind src/modality/image.rs:62-88 (multi bundle) and :112-194
+// (single algorithm) of the reference -- i.e. imgfprint's hashing AFTER decode.  The spec
+// every step follows is DESIGN.md "Image spec" (I1..I8); oracle/ucfp_oracle_image.c is the
+// independent CPU statement of the same spec.
+//
+// One 256-thread workgroup hashes one frame:
+//   phase A  stream the frame once from HBM (16 B/lane, every 128-B line fully used); each
+//            thread owns tiles of 8x8 NORMALISED pixels and reduces them in registers to
+//            exact integer partial sums, which is all phase B needs:
+//              s2[128][128] u8   2x2 means of the normalised plane = the sixteen 32x32 block images
+//              g32[32][32]  u8   8x8 means = global 32x32 image (its 8x8 sub-grids are the
+//                                block aHash images)
+//              gsum[32][32] u16  raw 8x8 sums (global 8x8 aHash image = 4x4 sums of these)
+//              v8[32][256]  u16  vertical 8-row sums at full x resolution (all 9x8 dHash images)
+//            The 256x256 normalised plane itself is never materialised.
+//   phase B  17 regions x {aHash, dHash, pHash}.  A wave is exactly 64 lanes = the 64 bits
+//            of a hash, so every hash is one __ballot.  The pHash 2-D DCT is two MFMA GEMMs
+//            (v_mfma_f32_16x16x4_f32, an exact k-ordered fmaf chain, so bit-identical to
+//            the oracle): P = X * C8^T, then Y = C8 * P.
+//
+// HBM-bound by construction: 262 144 B read + 536 B written per 512x512 luma frame.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ucfp_dct32.h"
+#include "common.h"
+
+namespace ucfp {
+
+__constant__ float c_dct_lo[8][32] = UCFP_DCT32_LO_INIT;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ImageLds {
+    uint8_t s2[128 * 128];   // 16 KiB
+    uint16_t v8[32 * 256];   // 16 KiB
+    uint16_t gsum[32 * 32];  // 2 KiB
+    uint8_t g32[32 * 32];    // 1 KiB
+    float pbuf[4][32 * 8];   // per-wave P = X*C8^T
+    float coef[4][64];       // per-wave DCT low block
+    uint64_t hashes[3][17];  // [ahash, phash, dhash][region]
+};
+
+// ---- phase A helpers -----------------------------------------------------------------
+
+// Box sum of S*S source bytes -> one normalised pixel, round half up.
+template <int S>
+__device__ __forceinline__ uint32_t norm_round(uint32_t sum) {
+    return (2u * sum + (uint32_t)(S * S)) / (2u * (uint32_t)(S * S));
+}
+
+// S = 2: one normalised row (8 px) from two source rows of 16 bytes. v_dot4_u32_u8 sums a
+// masked pair of bytes per operand; the +2 makes the >>2 round half up.
+__device__ __forceinline__ void norm_row_s2(const uint4& ra, const uint4& rb, uint32_t (&n)[8]) {
+    const uint32_t a[4] = {ra.x, ra.y, ra.z, ra.w};
+    const uint32_t b[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t s0 = __builtin_amdgcn_udot4(a[d], 0x00000101u, 2u, false);
+        s0 = __builtin_amdgcn_udot4(b[d], 0x00000101u, s0, false);
+        uint32_t s1 = __builtin_amdgcn_udot4(a[d], 0x01010000u, 2u, false);
+        s1 = __builtin_amdgcn_udot4(b[d], 0x01010000u, s1, false);
+        n[2 * d] = s0 >> 2;
+        n[2 * d + 1] = s1 >> 2;
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void norm_row_general(const uint8_t* rp, size_t row_stride,
+                                                 uint32_t (&n)[8]) {
+    uint32_t sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int yy = 0; yy < S; yy++) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(rp + (size_t)yy * row_stride);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            // S bytes per pixel, S % 4 == 0: whole dwords, summed by v_dot4_u32_u8
+#pragma unroll
+            for (int xx = 0; xx < S / 4; xx++)
+                sums[i] = __builtin_amdgcn_udot4(w[(S / 4) * i + xx], 0x01010101u, sums[i], false);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) n[i] = norm_round<S>(sums[i]);
+}
+
+// Incremental reduction of one tile (8x8 normalised pixels) into the LDS planes: rows arrive
+// two at a time so only 16 normalised pixels are ever live in registers.
+struct TileAcc {
+    uint32_t col[8];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 8; i++) col[i] = 0;
+    }
+    // nA / nB = normalised rows 2*j2 and 2*j2+1 of the tile
+    __device__ __forceinline__ void push_rowpair(ImageLds& L, int ty, int tx, int j2,
+                                                 const uint32_t (&nA)[8], const uint32_t (&nB)[8]) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; i2++) {
+            const uint32_t s = nA[2 * i2] + nA[2 * i2 + 1] + nB[2 * i2] + nB[2 * i2 + 1];
+            packed |= ((s + 2u) >> 2) << (8 * i2);
+        }
+        *reinterpret_cast<uint32_t*>(&L.s2[(4 * ty + j2) * 128 + 4 * tx]) = packed;
+#pragma unroll
+        for (int i = 0; i < 8; i++) col[i] += nA[i] + nB[i];
+    }
+    __device__ __forceinline__ void finish(ImageLds& L, int ty, int tx) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) tot += col[i];
+        uint4 v;
+        v.x = col[0] | (col[1] << 16);
+        v.y = col[2] | (col[3] << 16);
+        v.z = col[4] | (col[5] << 16);
+        v.w = col[6] | (col[7] << 16);
+        *reinterpret_cast<uint4*>(&L.v8[ty * 256 + 8 * tx]) = v;
+        L.gsum[ty * 32 + tx] = (uint16_t)tot;
+        L.g32[ty * 32 + tx] = (uint8_t)((tot + 32u) >> 6);
+    }
+};
+
+// ---- phase B -------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// aHash of region r (0 = global, 1..16 = blocks). lane = bit index.
+__device__ __forceinline__ uint64_t ahash_region(const ImageLds& L, int r, int lane) {
+    const int a = lane >> 3, b = lane & 7;
+    uint32_t px;
+    if (r == 0) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) s += L.gsum[(4 * a + j) * 32 + 4 * b + i];
+        px = (s + 512u) >> 10;
+    } else {
+        const int by = (r - 1) >> 2, bx = (r - 1) & 3;
+        px = L.g32[(8 * by + a) * 32 + 8 * bx + b];
+    }
+    const uint32_t mean = wave_sum_u32(px) >> 6;
+    return __ballot(px > mean);
+}
+
+// One 9x8 dHash pixel. Global: SRC = 256 columns, 4 v8 rows per output row, /8192.
+// Block: SRC = 64 columns starting at x0, 1 v8 row, /512.
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t dhash_px(const ImageLds& L, int vrow, int x0, int c) {
+    constexpr int SRC = GLOBAL ? 256 : 64;
+    const int d0 = SRC * c, d1 = d0 + SRC;          // dest cell on the 9*SRC lattice
+    const int xs = d0 / 9, xe = (d1 + 8) / 9;       // source cells touching it
+    uint32_t acc = 0;
+#pragma unroll 2
+    for (int x = xs; x < xe; x++) {
+        const int s0 = 9 * x, s1 = s0 + 9;
+        const int lo = s0 > d0 ? s0 : d0, hi = s1 < d1 ? s1 : d1;
+        const uint32_t w = (uint32_t)(hi - lo);
+        uint32_t cs;
+        if (GLOBAL) {
+            cs = (uint32_t)L.v8[(vrow + 0) * 256 + x] + L.v8[(vrow + 1) * 256 + x] +
+                 L.v8[(vrow + 2) * 256 + x] + L.v8[(vrow + 3) * 256 + x];
+        } else {
+            cs = L.v8[vrow * 256 + x0 + x];
+        }
+        acc += w * cs;
+    }
+    return GLOBAL ? (acc + 4096u) >> 13 : (acc + 256u) >> 9;
+}
+
+__device__ __forceinline__ uint64_t dhash_region(const ImageLds& L, int r, int lane) {
+    const int a = lane >> 3, c = lane & 7;
+    uint32_t left, right;
+    if (r == 0) {
+        left = dhash_px<true>(L, 4 * a, 0, c);
+        right = dhash_px<true>(L, 4 * a, 0, c + 1);
+    } else {
+        const int by = (r - 1) >> 2, bx = (r - 1) & 3;
+        left = dhash_px<false>(L, 8 * by + a, 64 * bx, c);
+        right = dhash_px<false>(L, 8 * by + a, 64 * bx, c + 1);
+    }
+    return __ballot(left > right);
+}
+
+// pHash of region r. creg[s] = C[lane&15][4s + (lane>>4)] (0 for lane&15 >= 8).
+__device__ __forceinline__ uint64_t phash_region(ImageLds& L, int r, int lane, int wave,
+                                                 const float (&creg)[8]) {
+    const int m = lane & 15, q = lane >> 4;
+    const uint8_t* img;
+    int stride;
+    if (r == 0) {
+        img = L.g32;
+        stride = 32;
+    } else {
+        const int by = (r - 1) >> 2, bx = (r - 1) & 3;
+        img = L.s2 + (32 * by) * 128 + 32 * bx;
+        stride = 128;
+    }
+    float* P = L.pbuf[wave];
+    float* CO = L.coef[wave];
+
+    // ---- GEMM 1: P[y][u] = sum_x X[y][x] * C[u][x]; A = X (M = y), B = C^T (N = u) ----
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint4* rowp = reinterpret_cast<const uint4*>(img + (16 * t + m) * stride);
+        const uint4 lo = rowp[0], hi = rowp[1];
+        const uint32_t dw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const float a = (float)((dw[s] >> (8 * q)) & 0xffu);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, creg[s], acc, 0, 0, 0);
+        }
+        // D: col = lane&15 = u, row = 4q + reg = y - 16t
+        if (m < 8) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) P[(16 * t + 4 * q + g) * 8 + m] = acc[g];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // ---- GEMM 2: Y[v][u] = sum_y C[v][y] * P[y][u]; A = C (M = v), B = P (N = u) ----
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const float b = (m < 8) ? P[(4 * s + q) * 8 + m] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(creg[s], b, acc, 0, 0, 0);
+        }
+        // D: col = u = lane&15, row = v = 4q + reg  (valid for u < 8, q < 2)
+        if (m < 8 && q < 2) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) CO[(4 * q + g) * 8 + m] = acc[g];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // ---- median of the 63 AC coefficients by rank counting; lane = coefficient index ----
+    const float mine = CO[lane];
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 1; j < 64; j++) {
+        const float o = CO[j];
+        rank += (o < mine || (o == mine && j < lane)) ? 1 : 0;
+    }
+    const uint64_t is_med = __ballot(lane >= 1 && rank == 31);
+    const int med_lane = __ffsll((unsigned long long)is_med) - 1;
+    const float med = __shfl(mine, med_lane, 64);
+    const uint64_t h = __ballot(mine > med);
+    __builtin_amdgcn_wave_barrier();
+    return h;
+}
+
+__device__ __forceinline__ void hash_phase_and_store(ImageLds& L, uint32_t algo,
+                                                     const uint8_t* __restrict__ exact,
+                                                     uint8_t* __restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float creg[8];
+    {
+        const int m = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 8; s++) creg[s] = (m < 8) ? c_dct_lo[m][4 * s + q] : 0.f;
+    }
+#pragma unroll 1
+    for (int r = wave; r < 17; r += 4) {
+        if (algo & 1u) {
+            const uint64_t h = ahash_region(L, r, lane);
+            if (lane == 0) L.hashes[0][r] = h;
+        }
+        if (algo & 4u) {
+            const uint64_t h = dhash_region(L, r, lane);
+            if (lane == 0) L.hashes[2][r] = h;
+        }
+        if (algo & 2u) {
+            const uint64_t h = phash_region(L, r, lane, wave, creg);
+            if (lane == 0) L.hashes[1][r] = h;
+        }
+    }
+    __syncthreads();
+
+    // ---- emit the record: 168 B (single) or 536 B (multi: exact | ahash | phash | dhash) ----
+    // dword index -> content; 32-byte exact prefix repeated in front of every ImageFingerprint.
+    const bool multi = (algo == 7u);
+    const int ndw = multi ? 134 : 42;
+    if (tid < ndw) {
+        int d = tid;
+        uint32_t val;
+        int slot = 0;  // which algorithm plane (0 a, 1 p, 2 d)
+        if (multi) {
+            if (d < 8) {
+                val = exact ? reinterpret_cast<const uint32_t*>(exact)[d] : 0u;
+                reinterpret_cast<uint32_t*>(out)[tid] = val;
+                return;
+            }
+            d -= 8;
+            slot = d / 42;
+            d -= slot * 42;
+        } else {
+            slot = (algo == 1u) ? 0 : (algo == 2u) ? 1 : 2;
+        }
+        if (d < 8) {
+            val = exact ? reinterpret_cast<const uint32_t*>(exact)[d] : 0u;
+        } else {
+            const int k = d - 8;  // dword k of the 17 u64 hashes
+            const uint64_t h = L.hashes[slot][k >> 1];
+            val = (uint32_t)(h >> (32 * (k & 1)));
+        }
+        reinterpret_cast<uint32_t*>(out)[tid] = val;
+    }
+}
+
+// ---- fused kernel: GRAY8 frames with width = height = 256*S ---------------------------------
+// tile = 8x8 normalised px = (8S)x(8S) source px; thread t handles tiles t + 256k, k = 0..3.
+template <int S>
+__global__ __launch_bounds__(256) void image_hash_gray_kernel(
+    const uint8_t* __restrict__ frames, size_t n, size_t row_stride, size_t frame_stride,
+    uint32_t algo, const uint8_t* __restrict__ exact, uint8_t* __restrict__ out,
+    int32_t* __restrict__ status) {
+    __shared__ ImageLds L;
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const uint8_t* __restrict__ f = frames + img * frame_stride;
+    const int tid = threadIdx.x;
+    const int tx = tid & 31;
+
+    for (int k = 0; k < 4; k++) {
+        const int ty = (tid >> 5) + 8 * k;
+        const uint8_t* base = f + (size_t)(8 * S * ty) * row_stride + (size_t)(8 * S * tx);
+        TileAcc acc;
+        acc.init();
+        if constexpr (S == 2) {
+            uint4 rows[16];
+#pragma unroll
+            for (int y = 0; y < 16; y++)
+                rows[y] = *reinterpret_cast<const uint4*>(base + (size_t)y * row_stride);
+#pragma unroll
+            for (int j2 = 0; j2 < 4; j2++) {
+                uint32_t nA[8], nB[8];
+                norm_row_s2(rows[4 * j2], rows[4 * j2 + 1], nA);
+                norm_row_s2(rows[4 * j2 + 2], rows[4 * j2 + 3], nB);
+                acc.push_rowpair(L, ty, tx, j2, nA, nB);
+            }
+        } else if constexpr (S == 1) {
+            uint2 rows[8];
+#pragma unroll
+            for (int y = 0; y < 8; y++)
+                rows[y] = *reinterpret_cast<const uint2*>(base + (size_t)y * row_stride);
+#pragma unroll
+            for (int j2 = 0; j2 < 4; j2++) {
+                uint32_t nA[8], nB[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    nA[i] = (rows[2 * j2].x >> (8 * i)) & 0xffu;
+                    nA[4 + i] = (rows[2 * j2].y >> (8 * i)) & 0xffu;
+                    nB[i] = (rows[2 * j2 + 1].x >> (8 * i)) & 0xffu;
+                    nB[4 + i] = (rows[2 * j2 + 1].y >> (8 * i)) & 0xffu;
+                }
+                acc.push_rowpair(L, ty, tx, j2, nA, nB);
+            }
+        } else {
+            // general integral scale: S rows x S bytes per normalised pixel
+#pragma unroll 1
+            for (int j2 = 0; j2 < 4; j2++) {
+                uint32_t nA[8], nB[8];
+                norm_row_general<S>(base + (size_t)(S * (2 * j2)) * row_stride, row_stride, nA);
+                norm_row_general<S>(base + (size_t)(S * (2 * j2 + 1)) * row_stride, row_stride, nB);
+                acc.push_rowpair(L, ty, tx, j2, nA, nB);
+            }
+        }
+        acc.finish(L, ty, tx);
+    }
+    __syncthreads();
+    if (status && tid == 0) status[img] = 0;
+    hash_phase_and_store(L, algo, exact ? exact + 32 * img : nullptr,
+                         out + img * (algo == 7u ? 536 : 168));
+}
+
+// ---- generic path, step 1: any geometry / pixel format -> 256x256 normalised plane ----------
+// grid (256, n): block = one normalised row, thread = one normalised pixel (spec I1 + I3).
+__global__ __launch_bounds__(256) void image_normalize_kernel(
+    const uint8_t* __restrict__ frames, uint32_t w, uint32_t h, size_t row_stride,
+    size_t frame_stride, int pixfmt, uint8_t* __restrict__ norm) {
+    const uint32_t i = threadIdx.x, j = blockIdx.x;
+    const size_t img = blockIdx.y;
+    const uint8_t* f = frames + img * frame_stride;
+    const uint32_t bpp = pixfmt == 0 ? 1 : pixfmt == 1 ? 3 : 4;
+    const uint32_t y0 = (uint32_t)(((uint64_t)h * j) / 256), y1 = (uint32_t)(((uint64_t)h * (j + 1) + 255) / 256);
+    const uint32_t x0 = (uint32_t)(((uint64_t)w * i) / 256), x1 = (uint32_t)(((uint64_t)w * (i + 1) + 255) / 256);
+    const uint64_t dj0 = (uint64_t)h * j, dj1 = dj0 + h, di0 = (uint64_t)w * i, di1 = di0 + w;
+    uint64_t acc = 0;
+    for (uint32_t y = y0; y < y1 && y < h; y++) {
+        const uint64_t s0 = 256ull * y, s1 = s0 + 256;
+        const uint64_t lo = s0 > dj0 ? s0 : dj0, hi = s1 < dj1 ? s1 : dj1;
+        if (hi <= lo) continue;
+        const uint64_t wy = hi - lo;
+        const uint8_t* row = f + (size_t)y * row_stride;
+        uint64_t racc = 0;
+        for (uint32_t x = x0; x < x1 && x < w; x++) {
+            const uint64_t t0 = 256ull * x, t1 = t0 + 256;
+            const uint64_t l2 = t0 > di0 ? t0 : di0, h2 = t1 < di1 ? t1 : di1;
+            if (h2 <= l2) continue;
+            uint32_t px;
+            if (bpp == 1) px = row[x];
+            else {
+                const uint8_t* p = row + (size_t)x * bpp;
+                px = (77u * p[0] + 150u * p[1] + 29u * p[2] + 128u) >> 8;
+            }
+            racc += (h2 - l2) * px;
+        }
+        acc += wy * racc;
+    }
+    const uint64_t D = (uint64_t)w * h;
+    norm[img * 65536 + (size_t)j * 256 + i] = (uint8_t)((2 * acc + D) / (2 * D));
+}
+
+// ---- invalid geometry: zero records, status = UCFP_E_MODALITY ----------------------------
+__global__ void image_reject_kernel(uint8_t* out, size_t total_bytes, int32_t* status, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total_bytes) out[i] = 0;
+    if (status && i < n) status[i] = -1;
+}
+
+// ---- synthetic frames (bench / tests): see ucfp_image_synth_dev ------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void image_synth_kernel(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first) {
+    const size_t per = (size_t)w * h;
+    const size_t total = n * per;
+    for (size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; p < total;
+         p += (size_t)gridDim.x * blockDim.x * 4) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const size_t pp = p + b;
+            const size_t k = pp / per, rem = pp % per;
+            const uint32_t y = (uint32_t)(rem / w), x = (uint32_t)(rem % w);
+            const uint64_t idx = first + k;
+            const uint64_t pix = (idx * h + y) * w + x;
+            const uint8_t v = (uint8_t)((x + y + 17 * idx) & 255) ^ (uint8_t)(mix64(pix) >> 60);
+            packed |= (uint32_t)v << (8 * b);
+        }
+        *reinterpret_cast<uint32_t*>(frames + p) = packed;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------
+
+static inline bool aligned16(const void* p, size_t a, size_t b) {
+    return (((uintptr_t)p | a | b) & 15u) == 0;
+}
+
+int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w, uint32_t h,
+                      size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim,
+                      uint32_t max_dim, const uint8_t* exact, uint8_t* out, int32_t* status,
+                      uint8_t* norm_ws, size_t norm_ws_frames, hipStream_t stream) {
+    if (n == 0) return 0;
+    const size_t rec = (algo == 7u) ? 536 : 168;
+    if (w < min_dim || h < min_dim || w > max_dim || h > max_dim) {
+        const size_t total = n * rec;
+        const size_t work = total > n ? total : n;
+        hipLaunchKernelGGL(image_reject_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0,
+                           stream, out, total, status, n);
+        return 0;
+    }
+    const bool square = (w == h) && (w % 256 == 0);
+    const uint32_t S = square ? w / 256 : 0;
+    if (pixfmt == 0 && aligned16(frames, row_stride, frame_stride) && (S == 1 || S == 2 || S == 4)) {
+        dim3 grid((unsigned)n), block(256);
+        if (S == 2)
+            hipLaunchKernelGGL(image_hash_gray_kernel<2>, grid, block, 0, stream, frames, n,
+                               row_stride, frame_stride, algo, exact, out, status);
+        else if (S == 1)
+            hipLaunchKernelGGL(image_hash_gray_kernel<1>, grid, block, 0, stream, frames, n,
+                               row_stride, frame_stride, algo, exact, out, status);
+        else
+            hipLaunchKernelGGL(image_hash_gray_kernel<4>, grid, block, 0, stream, frames, n,
+                               row_stride, frame_stride, algo, exact, out, status);
+        return 0;
+    }
+    // generic: normalise into the workspace in chunks, then hash the 256x256 planes (S = 1).
+    for (size_t done = 0; done < n;) {
+        const size_t chunk = (n - done) < norm_ws_frames ? (n - done) : norm_ws_frames;
+        hipLaunchKernelGGL(image_normalize_kernel, dim3(256, (unsigned)chunk), dim3(256), 0, stream,
+                           frames + done * frame_stride, w, h, row_stride, frame_stride, pixfmt,
+                           norm_ws);
+        hipLaunchKernelGGL(image_hash_gray_kernel<1>, dim3((unsigned)chunk), dim3(256), 0, stream,
+                           norm_ws, chunk, (size_t)256, (size_t)65536, algo,
+                           exact ? exact + 32 * done : nullptr, out + done * rec,
+                           status ? status + done : nullptr);
+        done += chunk;
+    }
+    return 0;
+}
+
+int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,
+                       hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(image_synth_kernel, dim3(4096), dim3(256), 0, stream, frames, n, w, h, first);
+    return 0;
+}
+
+}  // namespace ucfp

@@ -1,0 +1,176 @@
+"""Image fingerprinting -- host-side mirror of src/modality/image.rs.
+
+Same names, argument meaning and error behaviour as the reference adapters:
+
+    fingerprint(bytes, tenant_id, record_id)                      image.rs:56-58
+    fingerprint_with(bytes, tenant_id, record_id, preprocess)     image.rs:62-88   (536-B bundle)
+    fingerprint_phash / _dhash / _ahash(bytes, preprocess, t, r)  image.rs:112-162 (168 B each)
+
+plus the batched form the GPU wants (`fingerprint_frames`), which the reference lacks
+ and its per-request adapters are the n = 1 case of.  All hashing runs in the HIP
+library through the C ABI; this module only decodes (Pillow -- decode is out of the hot path,
+SURVEY 8f N4), enforces PreprocessConfig and wraps bytes into `Record`s.
+"""
+import ctypes as C
+import io
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .core import Modality, Record
+from .errors import ModalityError
+
+# algorithm tags: src/modality/image.rs:38-48
+ALGORITHM = "imgfprint-multihash-v1"
+ALGORITHM_MULTIHASH = "imgfprint-multihash-v1"
+ALGORITHM_PHASH = "imgfprint-phash-v1"
+ALGORITHM_DHASH = "imgfprint-dhash-v1"
+ALGORITHM_AHASH = "imgfprint-ahash-v1"
+
+FORMAT_VERSION = 1  # imgfprint::FORMAT_VERSION as stored by image.rs:76
+
+AHASH, PHASH, DHASH, MULTI = 1, 2, 4, 7
+PIX_GRAY8, PIX_RGB8, PIX_RGBA8 = 0, 1, 2
+_TAG = {AHASH: ALGORITHM_AHASH, PHASH: ALGORITHM_PHASH, DHASH: ALGORITHM_DHASH,
+        MULTI: ALGORITHM_MULTIHASH}
+_BPP = {PIX_GRAY8: 1, PIX_RGB8: 3, PIX_RGBA8: 4}
+
+
+@dataclass
+class PreprocessConfig:
+    """imgfprint::PreprocessConfig; defaults per src/server/algorithms_manifest.rs:446-469,
+    query mapping src/server/handlers.rs:307-319."""
+    max_input_bytes: int = 50 * 1024 * 1024
+    max_dimension: int = 8192
+    min_dimension: int = 32
+
+    def _c(self) -> _lib.ImagePreprocess:
+        return _lib.ImagePreprocess(self.max_dimension, self.min_dimension)
+
+
+def record_bytes(algo: int) -> int:
+    return int(_lib.load().ucfp_image_record_bytes(algo))
+
+
+# ------------------------------------------------------------------------------------------
+# batched, decoded frames (device or host resident)
+# ------------------------------------------------------------------------------------------
+
+def fingerprint_frames_dev(frames_ptr: int, n: int, width: int, height: int, *, algo: int = MULTI,
+                           pixfmt: int = PIX_GRAY8, row_stride: Optional[int] = None,
+                           frame_stride: Optional[int] = None, exact_ptr: int = 0, out_ptr: int,
+                           status_ptr: int = 0, stream: int = 0,
+                           preprocess: Optional[PreprocessConfig] = None, ctx=None) -> None:
+    """Enqueue hashing of `n` device-resident frames; raw device addresses, no sync.
+    `stream` is a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream)."""
+    ctx = ctx or _lib.default_context()
+    bpp = _BPP[pixfmt]
+    rs = row_stride if row_stride is not None else width * bpp
+    fs = frame_stride if frame_stride is not None else rs * height
+    pre = (preprocess or PreprocessConfig())._c()
+    _lib.check(_lib.load().ucfp_image_hash_batch_dev(
+        ctx.handle, algo, frames_ptr, n, width, height, rs, fs, pixfmt, C.byref(pre),
+        exact_ptr or None, out_ptr, status_ptr or None, stream or None))
+
+
+def fingerprint_frames(frames: np.ndarray, *, algo: int = MULTI, pixfmt: int = PIX_GRAY8,
+                       exact: Optional[np.ndarray] = None,
+                       preprocess: Optional[PreprocessConfig] = None, ctx=None):
+    """Hash host-resident decoded frames [n, h, w(, c)] uint8 through the host-pointer ABI.
+    Returns (records uint8 [n, record_bytes], status int32 [n])."""
+    ctx = ctx or _lib.default_context()
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    if frames.ndim < 3:
+        raise ModalityError("frames must be [n, h, w] or [n, h, w, c]")
+    n, h, w = frames.shape[:3]
+    bpp = _BPP[pixfmt]
+    if frames.size != n * h * w * bpp:
+        raise ModalityError(f"frames shape {frames.shape} does not match pixfmt {pixfmt}")
+    rec = record_bytes(algo)
+    out = np.zeros((n, max(rec, 1)), np.uint8)
+    status = np.zeros(n, np.int32)
+    ex = None
+    if exact is not None:
+        ex = np.ascontiguousarray(exact, dtype=np.uint8)
+        if ex.shape != (n, 32):
+            raise ModalityError("exact must be [n, 32] bytes")
+    pre = (preprocess or PreprocessConfig())._c()
+    _lib.check(_lib.load().ucfp_image_hash_batch(
+        ctx.handle, algo, frames.ctypes.data, n, w, h, w * bpp, h * w * bpp, pixfmt,
+        C.byref(pre), ex.ctypes.data if ex is not None else None, out.ctypes.data,
+        status.ctypes.data))
+    return out[:, :rec], status
+
+
+# ------------------------------------------------------------------------------------------
+# per-request adapters (encoded bytes in, Record out) -- the reference's call shape
+# ------------------------------------------------------------------------------------------
+
+def _decode(data: bytes, pre: PreprocessConfig):
+    """Encoded image -> (array, pixfmt). Errors map to Error::Modality like image.rs:70."""
+    if len(data) > pre.max_input_bytes:
+        raise ModalityError(f"image payload {len(data)} B exceeds max_input_bytes {pre.max_input_bytes}")
+    try:
+        from PIL import Image  # decode only; not part of the hashing path
+        img = Image.open(io.BytesIO(data))
+        img.load()
+    except Exception as e:  # noqa: BLE001 - any decoder failure is a modality error
+        raise ModalityError(f"image decode: {e}") from None
+    if img.mode == "L":
+        return np.asarray(img, dtype=np.uint8), PIX_GRAY8
+    if img.mode == "RGBA":
+        return np.asarray(img, dtype=np.uint8), PIX_RGBA8
+    return np.asarray(img.convert("RGB"), dtype=np.uint8), PIX_RGB8
+
+
+def _exact_digest(data: bytes) -> np.ndarray:
+    from .blake3 import blake3_digest
+    return np.frombuffer(blake3_digest(data), np.uint8).reshape(1, 32)
+
+
+def _single(data: bytes, pre: PreprocessConfig, algo: int, tenant_id: int, record_id: int) -> Record:
+    arr, pixfmt = _decode(data, pre)
+    recs, status = fingerprint_frames(arr[None], algo=algo, pixfmt=pixfmt,
+                                      exact=_exact_digest(data), preprocess=pre)
+    if status[0] != 0:
+        h, w = arr.shape[:2]
+        raise ModalityError(
+            f"image {w}x{h} outside [{pre.min_dimension}, {pre.max_dimension}] px")
+    return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Image,
+                  format_version=FORMAT_VERSION, algorithm=_TAG[algo], config_hash=0,
+                  fingerprint=recs[0].tobytes(), embedding=None, model_id=None, metadata=b"",
+                  text=None)
+
+
+def fingerprint(data: bytes, tenant_id: int, record_id: int) -> Record:
+    return fingerprint_with(data, tenant_id, record_id, PreprocessConfig())
+
+
+def fingerprint_with(data: bytes, tenant_id: int, record_id: int,
+                     preprocess: PreprocessConfig) -> Record:
+    return _single(data, preprocess, MULTI, tenant_id, record_id)
+
+
+def fingerprint_phash(data: bytes, preprocess: PreprocessConfig, tenant_id: int, record_id: int) -> Record:
+    return _single(data, preprocess, PHASH, tenant_id, record_id)
+
+
+def fingerprint_dhash(data: bytes, preprocess: PreprocessConfig, tenant_id: int, record_id: int) -> Record:
+    return _single(data, preprocess, DHASH, tenant_id, record_id)
+
+
+def fingerprint_ahash(data: bytes, preprocess: PreprocessConfig, tenant_id: int, record_id: int) -> Record:
+    return _single(data, preprocess, AHASH, tenant_id, record_id)
+
+
+def global_hashes(record_bytes_: bytes) -> dict:
+    """Extract the 64-bit global hashes from a 168-B or 536-B record (SURVEY 8f N2 offsets)."""
+    b = bytes(record_bytes_)
+    rd = lambda off: int.from_bytes(b[off:off + 8], "little")  # noqa: E731
+    if len(b) == 536:
+        return {"ahash": rd(32 + 32), "phash": rd(32 + 168 + 32), "dhash": rd(32 + 336 + 32)}
+    if len(b) == 168:
+        return {"global": rd(32)}
+    raise ModalityError(f"not an image fingerprint: {len(b)} bytes")

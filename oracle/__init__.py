@@ -62,6 +62,14 @@ def _declare(l):
     l.ucfp_oracle_image_synth.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t]
 
 
+def num_threads() -> int:
+    return int(lib().ucfp_oracle_num_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().ucfp_oracle_set_threads(int(n))
+
+
 ALGO = {"ahash": 1, "phash": 2, "dhash": 4, "multi": 7}
 _BPP = {0: 1, 1: 3, 2: 4}
 

@@ -21,6 +21,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/ucfp_dct32.h"
 
@@ -186,12 +189,15 @@ int ucfp_oracle_image_hash_batch(uint32_t algo, const uint8_t* frames, size_t n,
                                  uint8_t* out, int32_t* status) {
     size_t rec = algo == 7 ? 536 : 168;
     int bad = (w < min_dim || h < min_dim || w > max_dim || h > max_dim);
-    uint8_t* norm = (uint8_t*)malloc(NORM * NORM);
+    /* frames are independent: OpenMP over the batch for the timed CPU baseline */
+#pragma omp parallel for schedule(dynamic, 4)
     for (size_t i = 0; i < n; i++) {
+        uint8_t* norm = (uint8_t*)malloc(NORM * NORM);
         uint8_t* o = out + i * rec;
         if (bad) {
             memset(o, 0, rec);
             if (status) status[i] = -1;
+            free(norm);
             continue;
         }
         if (status) status[i] = 0;
@@ -213,8 +219,8 @@ int ucfp_oracle_image_hash_batch(uint32_t algo, const uint8_t* frames, size_t n,
             ucfp_oracle_image_hashes17(norm, (int)algo, hs);
             write_fp(o, ex, hs);
         }
+        free(norm);
     }
-    free(norm);
     return 0;
 }
 
@@ -226,6 +232,7 @@ static inline uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 void ucfp_oracle_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first) {
+#pragma omp parallel for
     for (size_t k = 0; k < n; k++) {
         uint64_t idx = first + k;
         for (uint32_t y = 0; y < h; y++)
@@ -235,4 +242,19 @@ void ucfp_oracle_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, 
                 frames[(k * h + y) * (size_t)w + x] = ramp ^ (uint8_t)(mix64(pix) >> 60);
             }
     }
+}
+
+int ucfp_oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void ucfp_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }

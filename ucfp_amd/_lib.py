@@ -42,6 +42,18 @@ SIGNATURES = {
 }
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (SONAME
+    libamdhip64.so.7) and resolves it by path; if /opt/rocm's copy were loaded first the process
+    would hold two HIP/HSA runtimes and torch would lose the device.  Loading torch's copy first
+    makes our DT_NEEDED libamdhip64.so.7 bind to the same runtime, so device pointers and
+    hipStream_t handles are shared between torch (memory/stream plumbing) and our kernels."""
+    try:
+        import torch  # noqa: F401  (plumbing only; the kernels do not use torch)
+    except ImportError:
+        return
+
+
 def load() -> C.CDLL:
     """dlopen the in-tree library and declare every signature. Raises if it is not built."""
     global _lib
@@ -51,6 +63,7 @@ def load() -> C.CDLL:
                 raise ImportError(
                     f"{SO_PATH} is missing: run `python -m ucfp_amd.build` (or "
                     "__graft_entry__.build()). ucfp_amd has no CPU fallback.")
+            _preload_hip_runtime()
             lib = C.CDLL(SO_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

@@ -120,6 +120,67 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
 int ucfp_image_synth_dev(ucfp_ctx* ctx, uint8_t* frames, size_t n, uint32_t width,
                          uint32_t height, size_t first_index, void* stream);
 
+/* =============================== INDEX ========================================
+ * Replaces `trait IndexBackend` kNN (src/index/mod.rs:29-35) as implemented by
+ * EmbeddedBackend::knn (src/index/embedded/mod.rs:268-360): exact brute-force top-k inside
+ * one tenant.  COSINE_F32 is the reference's kernel (dot_product :454-472, l2_norm :475-477,
+ * insert_topk :484-495); HAMMING64 is the new capability BASELINE config 5 asks for behind
+ * /v1/query (the reference has no Hamming search: SURVEY F3).  redb stays the source of
+ * truth on the Rust side; this object is the GPU-resident mirror of one shard.
+ *
+ * Ordering: best first; ties broken by ascending record_id (the reference leaves tie order to
+ * rayon's split, i.e. unspecified).  Hamming: distance d = popcount(q ^ x), score = 1 - d/64
+ * so that "higher is better" holds (src/core/mod.rs:113-115).  Cosine: score =
+ * dot/(|q||v|); zero-norm rows are skipped, a zero-norm query yields no hits (:283-286,:328-330).
+ */
+typedef struct ucfp_index ucfp_index;
+
+typedef enum ucfp_index_kind {
+    UCFP_INDEX_HAMMING64 = 1, /* rows are uint64_t                                   */
+    UCFP_INDEX_COSINE_F32 = 2 /* rows are float[dim]                                 */
+} ucfp_index_kind;
+
+#define UCFP_INDEX_APPEND_ONLY 1u /* no id->row map: upsert appends, delete unsupported   */
+#define UCFP_INDEX_MAX_K 128u      /* web caps k at 100 (web/src/routes/api/search/+server.ts:11) */
+#define UCFP_INVALID_ID 0xffffffffffffffffull
+
+int ucfp_index_create(ucfp_ctx* ctx, int kind, uint32_t dim, uint32_t flags, ucfp_index** out);
+void ucfp_index_destroy(ucfp_index* idx);
+
+/* IndexBackend::upsert (src/index/mod.rs:20-22): rows with a known id are overwritten in
+ * place, new ids are appended to the tenant's contiguous range. Host pointers. */
+int ucfp_index_upsert(ucfp_index* idx, uint32_t tenant, const uint64_t* ids, const void* rows, size_t n);
+/* Bulk append of device-resident rows (APPEND_ONLY indexes; corpus loaders, benches). */
+int ucfp_index_append_dev(ucfp_index* idx, uint32_t tenant, const uint64_t* d_ids, const void* d_rows,
+                          size_t n, void* stream);
+/* IndexBackend::delete (src/index/mod.rs:24-27). `n_removed` may be NULL. */
+int ucfp_index_delete(ucfp_index* idx, uint32_t tenant, const uint64_t* ids, size_t n, size_t* n_removed);
+int ucfp_index_size(ucfp_index* idx, uint32_t tenant, size_t* out);
+/* IndexBackend::flush (src/index/mod.rs:63): waits for queued device work. */
+int ucfp_index_flush(ucfp_index* idx);
+
+/* IndexBackend::knn for a batch of queries (nq = 1 is the reference's call).
+ *   queries     nq rows of the index kind (host memory)
+ *   out_ids     nq x k   record ids, UCFP_INVALID_ID past out_counts[q]
+ *   out_scores  nq x k   f32 score (higher is better)
+ *   out_dist    nq x k   Hamming distance (HAMMING64 only; may be NULL)
+ *   out_counts  nq       hits returned for each query (<= k)
+ * An unknown tenant or k = 0 returns zero hits, like the reference (:275-277). */
+int ucfp_index_search(ucfp_index* idx, uint32_t tenant, const void* queries, size_t nq, uint32_t k,
+                      uint64_t* out_ids, float* out_scores, uint32_t* out_dist, uint32_t* out_counts);
+/* Same with device pointers, enqueued on `stream` (no synchronisation). */
+int ucfp_index_search_dev(ucfp_index* idx, uint32_t tenant, const void* d_queries, size_t nq, uint32_t k,
+                          uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_dist,
+                          uint32_t* d_out_counts, void* stream);
+
+/* Final step of a sharded search: merge `parts` per-shard top-k lists -- the
+ * all-gathered [parts][nq][k] ids + keys -- into one. Keys: Hamming distance (kind
+ * HAMMING64) or the order-preserving u32 image of -score (COSINE_F32) as produced by
+ * ucfp_index_search_dev in d_out_dist. Device pointers. */
+int ucfp_topk_merge_dev(ucfp_ctx* ctx, int kind, const uint64_t* d_part_ids, const uint32_t* d_part_keys,
+                        uint32_t parts, size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
+                        uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream);
+
 /* BLAKE3-256 (default hash mode) of a HOST buffer: the `exact` digest the reference stores in
  * ImageFingerprint.exact (BLAKE3 of the uploaded bytes). Host code; no device needed. */
 int ucfp_blake3(const uint8_t* data, size_t len, uint8_t out[32]);

@@ -62,6 +62,45 @@ def _declare(l):
     l.ucfp_oracle_image_synth.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t]
 
 
+def cosine_knn(ids, rows, query, k, ref_fold=False):
+    """Cosine kNN with the reference's exact score arithmetic. Order: (score desc, id asc);
+    ref_fold=True runs the reference's insert_topk as one sequential fold instead (its tie
+    order differs, see ucfp_oracle_index.c). Returns (ids, scores)."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    query = np.ascontiguousarray(query, dtype=np.float32)
+    n = ids.shape[0]
+    dim = query.shape[0]
+    assert rows.size == n * dim
+    out_ids = np.zeros(max(k, 1), np.uint64)
+    out_sc = np.zeros(max(k, 1), np.float32)
+    f = lib().ucfp_oracle_cosine_knn_ref_fold if ref_fold else lib().ucfp_oracle_cosine_knn
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                  C.c_void_p, C.c_void_p]
+    m = f(ids.ctypes.data, rows.ctypes.data, n, dim, query.ctypes.data, k, out_ids.ctypes.data,
+          out_sc.ctypes.data)
+    return out_ids[:m].copy(), out_sc[:m].copy()
+
+
+def hamming_topk(ids, codes, queries, k):
+    """Returns (ids [nq,k], dist [nq,k], counts [nq]); order (d asc, id asc)."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    codes = np.ascontiguousarray(codes, dtype=np.uint64)
+    queries = np.ascontiguousarray(queries, dtype=np.uint64)
+    nq = queries.shape[0]
+    out_ids = np.zeros((nq, k), np.uint64)
+    out_d = np.zeros((nq, k), np.uint32)
+    out_c = np.zeros(nq, np.uint32)
+    f = lib().ucfp_oracle_hamming_topk
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                  C.c_void_p, C.c_void_p, C.c_void_p]
+    f(ids.ctypes.data, codes.ctypes.data, ids.shape[0], queries.ctypes.data, nq, k,
+      out_ids.ctypes.data, out_d.ctypes.data, out_c.ctypes.data)
+    return out_ids, out_d, out_c
+
+
 def num_threads() -> int:
     return int(lib().ucfp_oracle_num_threads())
 

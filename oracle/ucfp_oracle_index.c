@@ -1,0 +1,178 @@
+/*
+ * ucfp_oracle_index.c -- CPU restatement of the kNN hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * COSINE: PINNED.  Restates, line for line in meaning, the in-tree reference code
+ *   dot_product  src/index/embedded/mod.rs:454-472  (8 independent f32 accumulators over
+ *                chunks_exact(8), sequential sum of the 8, then the sequential remainder)
+ *   l2_norm      :475-477   insert_topk :484-495   knn phase 2 :324-356
+ * Scores are bit-identical to the reference's arithmetic.  TIES: the reference has no total
+ * order -- insert_topk puts a later equal score IN FRONT while the buffer is filling
+ * (partition_point(|s| s > score)), rejects it once full, and rayon's fold/reduce split decides
+ * which rows meet in which buffer -- so equal scores come out in an unspecified order.  Two
+ * entry points therefore:
+ *   ucfp_oracle_cosine_knn           the specification the HIP path implements:
+ *                                    (score desc, record_id asc), a total order;
+ *   ucfp_oracle_cosine_knn_ref_fold  the reference's insert_topk run as ONE sequential fold in
+ *                                    ascending record_id (redb range-scan order, :300-302),
+ *                                    kept to show both agree whenever scores are distinct.
+ * Pinned by the reference's own tests (src/index/embedded/mod.rs:522-589,
+ * src/server/tests.rs:53-113), replayed in tests/test_oracle_index.py.
+ *
+ * HAMMING: the reference has no Hamming search -> nothing to pin; this is the
+ * specification itself: d = popcount(q ^ x), order (d asc, id asc).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static float dot_product(const float* a, const float* b, size_t len) {
+    float accs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t chunks = len / 8;
+    for (size_t c = 0; c < chunks; c++)
+        for (int j = 0; j < 8; j++) accs[j] += a[c * 8 + j] * b[c * 8 + j];
+    float sum = 0.0f; /* accs.iter().sum(): f32 Sum folds from 0.0 */
+    for (int j = 0; j < 8; j++) sum += accs[j];
+    for (size_t i = chunks * 8; i < len; i++) sum += a[i] * b[i];
+    return sum;
+}
+
+static float l2_norm(const float* v, size_t len) { return sqrtf(dot_product(v, v, len)); }
+
+typedef struct {
+    uint64_t id;
+    float score;
+} hit_t;
+
+/* insert_topk: sorted-descending vec, partition_point(|s| s > score) */
+static void insert_topk(hit_t* local, size_t* len, uint64_t rid, float score, size_t k) {
+    if (*len < k) {
+        size_t pos = 0;
+        while (pos < *len && local[pos].score > score) pos++;
+        memmove(local + pos + 1, local + pos, (*len - pos) * sizeof(hit_t));
+        local[pos].id = rid;
+        local[pos].score = score;
+        (*len)++;
+    } else if (*len > 0 && score > local[*len - 1].score) {
+        size_t pos = 0;
+        while (pos < *len && local[pos].score > score) pos++;
+        memmove(local + pos + 1, local + pos, (*len - 1 - pos) * sizeof(hit_t));
+        local[pos].id = rid;
+        local[pos].score = score;
+    }
+}
+
+typedef struct {
+    uint64_t id;
+    size_t row;
+} idrow_t;
+static int cmp_idrow(const void* a, const void* b) {
+    uint64_t x = ((const idrow_t*)a)->id, y = ((const idrow_t*)b)->id;
+    return (x > y) - (x < y);
+}
+
+/* returns number of hits (<= k). rows: n x dim. Faithful sequential fold (see header). */
+size_t ucfp_oracle_cosine_knn_ref_fold(const uint64_t* ids, const float* rows, size_t n, size_t dim,
+                              const float* query, size_t k, uint64_t* out_ids, float* out_scores) {
+    if (dim == 0 || k == 0) return 0; /* :275-277 */
+    float q_norm = l2_norm(query, dim);
+    if (q_norm == 0.0f) return 0; /* :283-286 */
+    idrow_t* order = (idrow_t*)malloc((n ? n : 1) * sizeof(idrow_t));
+    for (size_t i = 0; i < n; i++) {
+        order[i].id = ids[i];
+        order[i].row = i;
+    }
+    qsort(order, n, sizeof(idrow_t), cmp_idrow);
+    hit_t* local = (hit_t*)malloc((k + 1) * sizeof(hit_t));
+    size_t len = 0;
+    for (size_t i = 0; i < n; i++) {
+        const float* v = rows + order[i].row * dim;
+        float v_norm = l2_norm(v, dim);
+        if (v_norm == 0.0f) continue; /* :328-330 */
+        float score = dot_product(query, v, dim) / (q_norm * v_norm);
+        if (score != score) continue; /* NaN: dropped (reference: unspecified) */
+        insert_topk(local, &len, order[i].id, score, k);
+    }
+    for (size_t i = 0; i < len; i++) {
+        out_ids[i] = local[i].id;
+        out_scores[i] = local[i].score;
+    }
+    free(local);
+    free(order);
+    return len;
+}
+
+static int cmp_hit_total(const void* a, const void* b) {
+    const hit_t* x = (const hit_t*)a;
+    const hit_t* y = (const hit_t*)b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    return (x->id > y->id) - (x->id < y->id);
+}
+
+/* The specification: reference arithmetic, total order (score desc, id asc). */
+size_t ucfp_oracle_cosine_knn(const uint64_t* ids, const float* rows, size_t n, size_t dim,
+                              const float* query, size_t k, uint64_t* out_ids, float* out_scores) {
+    if (dim == 0 || k == 0) return 0;
+    float q_norm = l2_norm(query, dim);
+    if (q_norm == 0.0f) return 0;
+    hit_t* all = (hit_t*)malloc((n ? n : 1) * sizeof(hit_t));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        const float* v = rows + i * dim;
+        float v_norm = l2_norm(v, dim);
+        if (v_norm == 0.0f) continue;
+        float score = dot_product(query, v, dim) / (q_norm * v_norm);
+        if (score != score) continue;
+        all[m].id = ids[i];
+        all[m].score = score;
+        m++;
+    }
+    qsort(all, m, sizeof(hit_t), cmp_hit_total);
+    size_t len = m < k ? m : k;
+    for (size_t i = 0; i < len; i++) {
+        out_ids[i] = all[i].id;
+        out_scores[i] = all[i].score;
+    }
+    free(all);
+    return len;
+}
+
+typedef struct {
+    uint32_t d;
+    uint64_t id;
+} hd_t;
+static int cmp_hd(const void* a, const void* b) {
+    const hd_t* x = (const hd_t*)a;
+    const hd_t* y = (const hd_t*)b;
+    if (x->d != y->d) return x->d < y->d ? -1 : 1;
+    return (x->id > y->id) - (x->id < y->id);
+}
+
+/* Hamming top-k for nq queries; outputs nq x k (padded with id = ~0, d = ~0). */
+void ucfp_oracle_hamming_topk(const uint64_t* ids, const uint64_t* codes, size_t n,
+                              const uint64_t* queries, size_t nq, size_t k, uint64_t* out_ids,
+                              uint32_t* out_dist, uint32_t* out_counts) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t q = 0; q < nq; q++) {
+        /* bounded selection: keep the k best in a small sorted buffer */
+        hd_t* best = (hd_t*)malloc((k + 1) * sizeof(hd_t));
+        size_t len = 0;
+        for (size_t i = 0; i < n; i++) {
+            hd_t c;
+            c.d = (uint32_t)__builtin_popcountll(queries[q] ^ codes[i]);
+            c.id = ids[i];
+            if (len == k && cmp_hd(&c, &best[len - 1]) >= 0) continue;
+            size_t pos = len;
+            while (pos > 0 && cmp_hd(&c, &best[pos - 1]) < 0) pos--;
+            if (len < k) len++;
+            memmove(best + pos + 1, best + pos, (len - 1 - pos) * sizeof(hd_t));
+            best[pos] = c;
+        }
+        for (size_t i = 0; i < k; i++) {
+            out_ids[q * k + i] = i < len ? best[i].id : ~0ull;
+            out_dist[q * k + i] = i < len ? best[i].d : 0xffffffffu;
+        }
+        out_counts[q] = (uint32_t)len;
+        free(best);
+    }
+}

@@ -1,0 +1,229 @@
+"""GPU parity for the kNN index through the C ABI.
+
+Hamming: bit-exact ids + distances vs the oracle (order d asc, id asc).  Cosine: ids equal and
+scores within 1e-5 of the oracle's reference-exact arithmetic (tolerance stated by BASELINE
+north_star).  Also replays the reference's own index tests (src/index/embedded/mod.rs:522-589):
+round trip ordering, tenant isolation, delete, records without embedding."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-5
+
+
+def _planted_corpus(rng, n, nq, planted_per_q=6):
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    queries = rng.integers(0, 2**64, nq, dtype=np.uint64)
+    # plant near neighbours (Hamming 0..8) and exact duplicates (ties on distance)
+    for q in range(nq):
+        for j in range(planted_per_q):
+            pos = rng.integers(0, n)
+            flips = rng.choice(64, size=rng.integers(0, 9), replace=False)
+            mask = np.uint64(0)
+            for f in flips:
+                mask |= np.uint64(1) << np.uint64(f)
+            codes[pos] = queries[q] ^ mask
+    ids = rng.permutation(np.arange(n, dtype=np.uint64) * np.uint64(7) + np.uint64(3))
+    return ids, codes, queries
+
+
+@pytest.mark.parametrize("n,nq,k", [(1000, 1, 10), (5000, 7, 10), (70000, 64, 10), (200000, 130, 10),
+                                    (300000, 33, 1), (50000, 20, 37), (20000, 5, 100), (5, 3, 10)])
+def test_hamming_matches_oracle(gpu_ctx, oracle, n, nq, k):
+    from ucfp_amd import index
+    rng = np.random.default_rng(n + nq + k)
+    ids, codes, queries = _planted_corpus(rng, n, nq)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    ix.upsert(3, ids, codes)
+    assert ix.size(3) == n
+    g_ids, g_sc, g_d, g_c = ix.search(3, queries, k)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+    assert np.array_equal(g_c, o_c)
+    assert np.array_equal(g_d, o_d)
+    assert np.array_equal(g_ids, o_ids)
+    valid = g_d != 0xFFFFFFFF
+    assert np.allclose(g_sc[valid], 1.0 - g_d[valid] / 64.0)
+    ix.close()
+
+
+def test_hamming_massive_ties_and_duplicates(gpu_ctx, oracle):
+    """All rows identical (every distance ties) and a corpus of few distinct codes: the id
+    tie-break alone decides, under the heaviest slow-path load."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(9)
+    n = 40000
+    ids = rng.permutation(n).astype(np.uint64)
+    for codes in (np.full(n, 0xDEADBEEFCAFEF00D, np.uint64),
+                  rng.choice(np.array([1, 3, 7, 2**63], np.uint64), n)):
+        ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+        ix.upsert(0, ids, codes)
+        q = np.array([0xDEADBEEFCAFEF00D, 0, 1], np.uint64)
+        g_ids, _, g_d, g_c = ix.search(0, q, 10)
+        o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, q, 10)
+        assert np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids) and np.array_equal(g_c, o_c)
+        ix.close()
+
+
+def test_hamming_adversarial_order(gpu_ctx, oracle):
+    """The sample pre-pass only sees the head of the corpus; put all near neighbours at the tail
+    and far codes (distance ~64) at the head so tau0 is useless. Correctness must not depend on it."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(4)
+    n = 300000
+    q = rng.integers(0, 2**64, 8, dtype=np.uint64)
+    codes = np.empty(n, np.uint64)
+    codes[:] = ~q[0]                       # far from q[0] everywhere
+    codes[n - 5000:] = q[0] ^ rng.integers(0, 2**12, 5000, dtype=np.uint64)  # near, at the tail
+    ids = np.arange(n, dtype=np.uint64)[::-1].copy()
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    ix.upsert(0, ids, codes)
+    g_ids, _, g_d, g_c = ix.search(0, q, 10)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, q, 10)
+    assert np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids)
+    ix.close()
+
+
+def test_upsert_overwrite_delete_tenants(gpu_ctx, oracle):
+    from ucfp_amd import index
+    rng = np.random.default_rng(1)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    ids = np.arange(1000, dtype=np.uint64)
+    codes = rng.integers(0, 2**64, 1000, dtype=np.uint64)
+    ix.upsert(1, ids, codes)
+    ix.upsert(2, ids[:10], codes[:10])
+    # overwrite half of tenant 1, including a duplicate id inside the batch (last wins)
+    new = rng.integers(0, 2**64, 501, dtype=np.uint64)
+    up_ids = np.concatenate([ids[:500], ids[:1]])
+    ix.upsert(1, up_ids, new)
+    codes[:500] = new[:500]
+    codes[0] = new[500]
+    assert ix.size(1) == 1000 and ix.size(2) == 10 and ix.size(99) == 0
+    assert ix.delete(1, np.array([5, 6, 7, 100000], np.uint64)) == 3
+    keep = np.ones(1000, bool)
+    keep[[5, 6, 7]] = False
+    q = rng.integers(0, 2**64, 9, dtype=np.uint64)
+    g_ids, _, g_d, g_c = ix.search(1, q, 10)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids[keep], codes[keep], q, 10)
+    assert np.array_equal(g_ids, o_ids) and np.array_equal(g_d, o_d)
+    # tenant isolation + unknown tenant + k = 0
+    g2, _, _, c2 = ix.search(2, q[:1], 10)
+    assert c2[0] == 10 and set(g2[0]) == set(range(10))
+    _, _, _, c3 = ix.search(42, q[:1], 10)
+    assert c3[0] == 0
+    _, _, _, c0 = ix.search(1, q[:1], 0)
+    assert c0[0] == 0
+    ix.close()
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(2000, 768, 3, 10), (5000, 384, 17, 10), (3000, 100, 40, 5),
+                                        (1500, 3, 4, 10), (800, 1536, 2, 20), (50, 33, 2, 100)])
+def test_cosine_matches_oracle(gpu_ctx, oracle, n, dim, nq, k):
+    from ucfp_amd import index
+    rng = np.random.default_rng(n + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[rng.integers(0, n, 5)] = 0.0            # zero-norm rows are skipped
+    ids = rng.permutation(n).astype(np.uint64) + np.uint64(10)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    queries[0] = rows[7] * 3.0                   # an exact direction match -> score ~ 1
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    for q in range(nq):
+        o_ids, o_sc = oracle.cosine_knn(ids, rows, queries[q], k)
+        m = len(o_ids)
+        assert g_c[q] == m
+        assert np.abs(g_sc[q, :m] - o_sc).max() <= COS_TOL, (q, g_sc[q, :m], o_sc)
+        # ids must agree wherever the oracle's neighbouring scores differ by more than the tolerance
+        gap_ok = np.ones(m, bool)
+        if m > 1:
+            close = np.abs(np.diff(o_sc)) <= 2 * COS_TOL
+            gap_ok[:-1] &= ~close
+            gap_ok[1:] &= ~close
+        if m == k and m > 0:
+            gap_ok[-1] = False   # the k-th may swap with the (k+1)-th inside the tolerance
+        assert np.array_equal(g_ids[q, :m][gap_ok], o_ids[gap_ok])
+    ix.close()
+
+
+def test_cosine_reference_index_tests(gpu_ctx):
+    """src/index/embedded/mod.rs:522-589 replayed on GpuIndex with Records."""
+    from ucfp_amd import index
+    from ucfp_amd.core import Modality, Record
+
+    def rec(tenant, rid, emb):
+        return Record(tenant, rid, Modality.Image, 1, "test", 0, b"fp", embedding=emb, model_id="test-model")
+
+    db = index.GpuIndex(ctx=gpu_ctx)
+    db.upsert([rec(1, 100, [1.0, 0.0, 0.0]), rec(1, 200, [0.0, 1.0, 0.0]), rec(1, 300, [0.7, 0.7, 0.0])])
+    hits = db.knn(1, [0.6, 0.6, 0.0], 2)
+    assert len(hits) == 2 and hits[0].record_id == 300 and hits[0].score > hits[1].score
+    assert all(h.tenant_id == 1 and h.source == "vector" for h in hits)
+    # knn_ignores_other_tenants
+    db2 = index.GpuIndex(ctx=gpu_ctx)
+    db2.upsert([rec(1, 1, [1.0, 0.0]), rec(2, 1, [1.0, 0.0])])
+    hits = db2.knn(1, [1.0, 0.0], 10)
+    assert len(hits) == 1 and hits[0].tenant_id == 1
+    # delete_removes_records
+    db3 = index.GpuIndex(ctx=gpu_ctx)
+    db3.upsert([rec(1, 1, [1.0, 0.0]), rec(1, 2, [0.0, 1.0])])
+    db3.delete(1, [1])
+    hits = db3.knn(1, [1.0, 0.0], 10)
+    assert len(hits) == 1 and hits[0].record_id == 2
+    # knn_skips_records_with_no_embedding (and dimension mismatch)
+    db4 = index.GpuIndex(ctx=gpu_ctx)
+    without = rec(1, 9, None)
+    db4.upsert([without, rec(1, 10, [1.0, 0.0])])
+    hits = db4.knn(1, [1.0, 0.0], 10)
+    assert len(hits) == 1 and hits[0].record_id == 10
+    # empty query / k = 0 / zero-norm query -> []
+    assert db4.knn(1, [], 10) == [] and db4.knn(1, [1.0, 0.0], 0) == [] and db4.knn(1, [0.0, 0.0], 10) == []
+
+
+def test_image_records_feed_hamming_space(gpu_ctx, oracle):
+    """End to end on one GPU: hash frames, upsert the Records, query by pHash."""
+    from ucfp_amd import image, index
+    from ucfp_amd.core import Modality, Record
+    rng = np.random.default_rng(3)
+    frames = oracle.image_synth(64, 256, 256, 0)
+    frames[40] = frames[10]
+    frames[40, :4, :4] ^= 1                  # near-duplicate of frame 10
+    recs, _ = image.fingerprint_frames(frames, algo=image.MULTI, ctx=gpu_ctx)
+    db = index.GpuIndex(ctx=gpu_ctx)
+    db.upsert([Record(0, i, Modality.Image, 1, image.ALGORITHM_MULTIHASH, 0, recs[i].tobytes()) for i in range(64)])
+    ph = image.global_hashes(recs[10].tobytes())["phash"]
+    hits = db.hamming(0, image.ALGORITHM_PHASH, ph, 3)
+    assert hits[0].record_id == 10 and hits[0].distance == 0 and hits[0].score == 1.0
+    assert hits[1].record_id == 40
+
+
+def test_topk_merge_dev_matches_global(gpu_ctx, oracle, torch_cuda):
+    """The multi-GPU final step on one device: split a corpus into 4 shards, search each,
+    merge the stacked partial lists, compare with the oracle over the whole corpus."""
+    torch = torch_cuda
+    from ucfp_amd import index
+    rng = np.random.default_rng(8)
+    n, nq, k, parts = 80000, 50, 10, 4
+    ids, codes, queries = _planted_corpus(rng, n, nq)
+    shard_ids, shard_keys = [], []
+    for p in range(parts):
+        sl = slice(p * n // parts, (p + 1) * n // parts)
+        ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+        ix.upsert(0, ids[sl], codes[sl])
+        gi, _, gd, _ = ix.search(0, queries, k)
+        shard_ids.append(gi)
+        shard_keys.append(gd)
+        ix.close()
+    pid = torch.from_numpy(np.stack(shard_ids).astype(np.int64)).cuda()
+    pk = torch.from_numpy(np.stack(shard_keys).astype(np.int32)).cuda()
+    out_ids = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    out_keys = torch.zeros((nq, k), dtype=torch.int32, device="cuda")
+    out_sc = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    out_cnt = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    index.topk_merge_dev(index.HAMMING64, pid.data_ptr(), pk.data_ptr(), parts, nq, k, out_ids.data_ptr(),
+                         out_sc.data_ptr(), out_keys.data_ptr(), out_cnt.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream, ctx=gpu_ctx)
+    torch.cuda.synchronize()
+    o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+    assert np.array_equal(out_ids.cpu().numpy().astype(np.uint64), o_ids)
+    assert np.array_equal(out_keys.cpu().numpy().astype(np.uint32), o_d)

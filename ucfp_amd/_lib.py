@@ -36,6 +36,19 @@ SIGNATURES = {
     "ucfp_image_hash_batch": (C.c_int, [
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
         C.c_size_t, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_index_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ucfp_index_destroy": (None, [C.c_void_p]),
+    "ucfp_index_upsert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ucfp_index_append_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ucfp_index_delete": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ucfp_index_size": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t)]),
+    "ucfp_index_flush": (C.c_int, [C.c_void_p]),
+    "ucfp_index_search": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_index_search_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t,
+                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                        C.c_uint32, C.c_size_t, C.c_void_p]),

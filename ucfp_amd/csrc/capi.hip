@@ -13,16 +13,22 @@
 #include "common.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char* fmt, ...) {
+namespace ucfp {
+// shared by every translation unit that implements part of the C ABI
+int capi_fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
 }
+}  // namespace ucfp
+
+namespace {
+#define fail ucfp::capi_fail
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
@@ -61,6 +67,10 @@ int grow(uint8_t** p, size_t* cap, size_t need) {
 }
 
 }  // namespace
+
+namespace ucfp {
+int ctx_device(const ucfp_ctx* ctx) { return ctx->device; }
+}  // namespace ucfp
 
 extern "C" {
 

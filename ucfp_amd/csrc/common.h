@@ -14,4 +14,42 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
 int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,
                        hipStream_t stream);
 
+// hamming.hip
+struct HammingPlan {
+    uint32_t qgroups = 0;       // ceil(nq / 64)
+    uint32_t slices = 0;        // corpus slices (one wave per slice x qgroup)
+    size_t per_slice = 0;
+    size_t sample_n = 0;        // codes in the tau0 sample pre-pass
+    uint32_t sample_parts = 0;
+    size_t per_part = 0;
+    int cap = 24;               // lane-private candidate list capacity
+};
+HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k);
+size_t hamming_workspace_bytes(const HammingPlan& p, uint32_t nq, uint32_t k);
+int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
+                          const uint64_t* queries, uint32_t nq, uint32_t k, uint8_t* ws,
+                          const HammingPlan& p, uint64_t* out_ids, uint32_t* out_dist,
+                          float* out_scores, uint32_t* out_cnt, hipStream_t stream);
+int launch_hamming_scores(const uint32_t* dist, size_t total, float* scores, hipStream_t stream);
+
+// topk.hip
+struct SelectPlan {
+    uint32_t slices = 0;
+    size_t per_slice = 0;
+};
+SelectPlan select_plan(size_t n, uint32_t nq);
+int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, const SelectPlan& p,
+                           uint32_t nq, uint32_t k, uint64_t* part_ids, uint32_t* part_key,
+                           uint32_t* part_cnt, hipStream_t stream);
+int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts,
+                          uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key,
+                          uint32_t* out_cnt, hipStream_t stream);
+
+// cosine.hip
+int launch_cosine_norms(const float* rows, size_t n, uint32_t dim, float* norms, hipStream_t stream);
+int cosine_queries_per_pass(uint32_t dim);
+int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                       const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream);
+int launch_cosine_scores_from_keys(const uint32_t* keys, size_t total, float* scores, hipStream_t stream);
+
 }  // namespace ucfp

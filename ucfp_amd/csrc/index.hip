@@ -1,0 +1,514 @@
+// index.hip -- GPU-resident shard of the kNN index and its C ABI (ucfp_index_*).
+//
+// Mirrors `trait IndexBackend` (src/index/mod.rs:17-78) for the kNN part: upsert / delete / knn /
+// flush, scoped by tenant.  Layout in HBM: one contiguous range per tenant (the analogue of the
+// reference's `(tenant_id, 0)..=(tenant_id, u64::MAX)` key range, src/index/embedded/mod.rs:300-302):
+//   ids   u64[n]            record ids, row-aligned with
+//   rows  u64[n]            (HAMMING64)   or   f32[n][dim] + norms f32[n]   (COSINE_F32)
+// Capacity doubles on growth; delete swaps the last row into the hole, so a tenant scan is
+// always one dense stream.  The id -> row map lives on the host (the caller of this ABI is a host
+// thread of the ingest route); APPEND_ONLY indexes skip it.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ucfp_hip.h"
+#include "common.h"
+
+namespace ucfp {
+int capi_fail(int code, const char* fmt, ...);  // capi.hip
+int ctx_device(const ucfp_ctx* ctx);            // capi.hip
+}  // namespace ucfp
+
+using ucfp::capi_fail;
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return capi_fail(UCFP_E_INDEX, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t need) {
+        if (cap >= need) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = need + need / 4 + 4096;
+        HIP_TRY(hipMalloc((void**)&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Shard {
+    uint64_t* ids = nullptr;
+    uint8_t* rows = nullptr;
+    float* norms = nullptr;
+    size_t n = 0, cap = 0;
+    std::unordered_map<uint64_t, size_t> pos;  // id -> row (unless APPEND_ONLY)
+    std::vector<uint64_t> host_ids;            // row -> id (unless APPEND_ONLY)
+};
+
+__global__ void scatter_rows_kernel(const uint64_t* __restrict__ src_ids, const uint8_t* __restrict__ src_rows,
+                                    const uint64_t* __restrict__ dst_row, size_t n, size_t row_bytes,
+                                    uint64_t* __restrict__ ids, uint8_t* __restrict__ rows) {
+    // one block per staged item; threads copy the row in 4-byte words
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    const size_t r = dst_row[i];
+    if (threadIdx.x == 0) ids[r] = src_ids[i];
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src_rows + i * row_bytes);
+    uint32_t* d = reinterpret_cast<uint32_t*>(rows + r * row_bytes);
+    for (size_t w = threadIdx.x; w < row_bytes / 4; w += blockDim.x) d[w] = s[w];
+}
+
+__global__ void gather_norms_kernel(const float* __restrict__ src, const uint64_t* __restrict__ dst_row, size_t n,
+                                    float* __restrict__ norms) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) norms[dst_row[i]] = src[i];
+}
+
+}  // namespace
+
+struct ucfp_index {
+    ucfp_ctx* ctx = nullptr;
+    int device = 0;
+    int kind = 0;
+    uint32_t dim = 0;
+    uint32_t flags = 0;
+    size_t row_bytes = 0;
+    std::mutex mu;
+    std::map<uint32_t, Shard> shards;
+    hipStream_t stream = nullptr;  // host-pointer entry points run here
+    DevBuf ws;                     // search workspace (partials, keys, ...)
+    hipEvent_t ws_done = nullptr;  // orders successive searches' use of `ws` across streams
+    DevBuf stage;                  // host<->device staging
+};
+
+namespace {
+
+int shard_reserve(ucfp_index* ix, Shard& s, size_t need, hipStream_t st) {
+    if (need <= s.cap) return 0;
+    size_t ncap = s.cap ? s.cap * 2 : 1024;
+    while (ncap < need) ncap *= 2;
+    uint64_t* nids = nullptr;
+    uint8_t* nrows = nullptr;
+    float* nnorms = nullptr;
+    HIP_TRY(hipMalloc((void**)&nids, ncap * 8));
+    HIP_TRY(hipMalloc((void**)&nrows, ncap * ix->row_bytes));
+    if (ix->kind == UCFP_INDEX_COSINE_F32) HIP_TRY(hipMalloc((void**)&nnorms, ncap * 4));
+    if (s.n) {
+        HIP_TRY(hipMemcpyAsync(nids, s.ids, s.n * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(nrows, s.rows, s.n * ix->row_bytes, hipMemcpyDeviceToDevice, st));
+        if (nnorms) HIP_TRY(hipMemcpyAsync(nnorms, s.norms, s.n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s.ids) (void)hipFree(s.ids);
+    if (s.rows) (void)hipFree(s.rows);
+    if (s.norms) (void)hipFree(s.norms);
+    s.ids = nids;
+    s.rows = nrows;
+    s.norms = nnorms;
+    s.cap = ncap;
+    return 0;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Device-side search over one shard; everything enqueued on `st`. Outputs are device pointers.
+// d_keys_out receives the sort key (Hamming distance / inverted score image); may be the
+// caller's d_out_dist or an internal buffer.
+int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size_t nq, uint32_t k,
+                     uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_keys, uint32_t* d_out_cnt,
+                     hipStream_t st) {
+    const size_t n = s ? s->n : 0;
+    if (ix->kind == UCFP_INDEX_HAMMING64) {
+        ucfp::HammingPlan p = ucfp::hamming_plan(n, (uint32_t)nq, k);
+        size_t need = ucfp::hamming_workspace_bytes(p, (uint32_t)nq, k) + 4096;
+        uint32_t* keys = d_out_keys;
+        size_t keys_off = 0;
+        if (!keys) {
+            keys_off = align256(need);
+            need = keys_off + nq * k * 4;
+        }
+        int rc = ix->ws.ensure(need);
+        if (rc) return rc;
+        if (!keys) keys = reinterpret_cast<uint32_t*>(ix->ws.p + keys_off);
+        ucfp::launch_hamming_search(s ? reinterpret_cast<const uint64_t*>(s->rows) : nullptr, s ? s->ids : nullptr,
+                                    n, reinterpret_cast<const uint64_t*>(d_queries), (uint32_t)nq, k, ix->ws.p, p,
+                                    d_out_ids, keys, d_out_scores, d_out_cnt, st);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // ---- cosine ----
+    const uint32_t dim = ix->dim;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_ids, 0xff, nq * k * 8, st));
+        if (d_out_keys) HIP_TRY(hipMemsetAsync(d_out_keys, 0xff, nq * k * 4, st));
+        HIP_TRY(hipMemsetAsync(d_out_cnt, 0, nq * 4, st));
+        if (d_out_scores) {
+            int rc = ix->ws.ensure(nq * k * 4 + 256);
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(ix->ws.p, 0xff, nq * k * 4, st));
+            ucfp::launch_cosine_scores_from_keys(reinterpret_cast<uint32_t*>(ix->ws.p), nq * k, d_out_scores, st);
+        }
+        return 0;
+    }
+    const int qpp = ucfp::cosine_queries_per_pass(dim);
+    if (qpp < 1) return capi_fail(UCFP_E_UNSUPPORTED, "cosine dim %u does not fit one query row in LDS", dim);
+    // chunk the query batch so the key matrix stays under ~2 GiB
+    size_t chunk = (size_t)2048 * 1024 * 1024 / (4 * n);
+    if (chunk < (size_t)qpp) chunk = qpp;
+    if (chunk > nq) chunk = nq;
+    ucfp::SelectPlan sp = ucfp::select_plan(n, (uint32_t)chunk);
+    size_t off = 0;
+    const size_t o_qn = off;
+    off = align256(off + nq * 4);
+    const size_t o_keys = off;
+    off = align256(off + chunk * n * 4);
+    const size_t o_pid = off;
+    off = align256(off + (size_t)sp.slices * chunk * k * 8);
+    const size_t o_pk = off;
+    off = align256(off + (size_t)sp.slices * chunk * k * 4);
+    const size_t o_pc = off;
+    off = align256(off + (size_t)sp.slices * chunk * 4);
+    const size_t o_ok = off;
+    off = align256(off + nq * k * 4);
+    int rc = ix->ws.ensure(off);
+    if (rc) return rc;
+    uint8_t* w = ix->ws.p;
+    float* qn = reinterpret_cast<float*>(w + o_qn);
+    uint32_t* keymat = reinterpret_cast<uint32_t*>(w + o_keys);
+    uint32_t* okeys = d_out_keys ? d_out_keys : reinterpret_cast<uint32_t*>(w + o_ok);
+    const float* q = reinterpret_cast<const float*>(d_queries);
+    ucfp::launch_cosine_norms(q, nq, dim, qn, st);
+    for (size_t q0 = 0; q0 < nq; q0 += chunk) {
+        const size_t qc = nq - q0 < chunk ? nq - q0 : chunk;
+        for (size_t p0 = 0; p0 < qc; p0 += qpp) {
+            const uint32_t np = (uint32_t)(qc - p0 < (size_t)qpp ? qc - p0 : qpp);
+            ucfp::launch_cosine_keys(reinterpret_cast<const float*>(s->rows), s->norms, n, dim,
+                                     q + (q0 + p0) * dim, qn + q0 + p0, np, keymat + p0 * n, st);
+        }
+        ucfp::SelectPlan spc = ucfp::select_plan(n, (uint32_t)qc);
+        if (spc.slices > sp.slices) spc = sp;  // never exceed the reserved partial space
+        ucfp::launch_select_topk_u32(keymat, s->ids, n, spc, (uint32_t)qc, k, reinterpret_cast<uint64_t*>(w + o_pid),
+                                     reinterpret_cast<uint32_t*>(w + o_pk), reinterpret_cast<uint32_t*>(w + o_pc), st);
+        ucfp::launch_topk_merge_u32(reinterpret_cast<uint64_t*>(w + o_pid), reinterpret_cast<uint32_t*>(w + o_pk),
+                                    spc.slices, (uint32_t)qc, k, d_out_ids + q0 * k, okeys + q0 * k, d_out_cnt + q0,
+                                    st);
+    }
+    if (d_out_scores) ucfp::launch_cosine_scores_from_keys(okeys, nq * k, d_out_scores, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_search_args(ucfp_index* ix, const void* q, size_t nq, uint32_t k, const void* ids, const void* cnt) {
+    if (!ix) return capi_fail(UCFP_E_INVALID, "index is NULL");
+    if (k > UCFP_INDEX_MAX_K) return capi_fail(UCFP_E_INVALID, "k = %u exceeds UCFP_INDEX_MAX_K = %u", k, UCFP_INDEX_MAX_K);
+    if (nq && k && (!q || !ids || !cnt)) return capi_fail(UCFP_E_INVALID, "queries/out_ids/out_counts is NULL");
+    if (nq > 0x7fffffu) return capi_fail(UCFP_E_INVALID, "query batch %zu too large for one call", nq);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ucfp_index_create(ucfp_ctx* ctx, int kind, uint32_t dim, uint32_t flags, ucfp_index** out) {
+    if (!ctx || !out) return capi_fail(UCFP_E_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    if (kind != UCFP_INDEX_HAMMING64 && kind != UCFP_INDEX_COSINE_F32)
+        return capi_fail(UCFP_E_UNSUPPORTED, "unknown index kind %d", kind);
+    if (kind == UCFP_INDEX_COSINE_F32 && (dim == 0 || dim > 65536))
+        return capi_fail(UCFP_E_INVALID, "cosine index needs 1 <= dim <= 65536 (got %u)", dim);
+    ucfp_index* ix = new (std::nothrow) ucfp_index();
+    if (!ix) return capi_fail(UCFP_E_INDEX, "out of host memory");
+    ix->ctx = ctx;
+    ix->device = ucfp::ctx_device(ctx);
+    ix->kind = kind;
+    ix->dim = kind == UCFP_INDEX_HAMMING64 ? 1 : dim;
+    ix->flags = flags;
+    ix->row_bytes = kind == UCFP_INDEX_HAMMING64 ? 8 : (size_t)dim * 4;
+    hipError_t e = hipSetDevice(ix->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ws_done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        delete ix;
+        return capi_fail(UCFP_E_INDEX, "index stream creation failed: %s", hipGetErrorString(e));
+    }
+    *out = ix;
+    return UCFP_OK;
+}
+
+void ucfp_index_destroy(ucfp_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : ix->shards) {
+        if (kv.second.ids) (void)hipFree(kv.second.ids);
+        if (kv.second.rows) (void)hipFree(kv.second.rows);
+        if (kv.second.norms) (void)hipFree(kv.second.norms);
+    }
+    ix->ws.release();
+    ix->stage.release();
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    if (ix->ws_done) (void)hipEventDestroy(ix->ws_done);
+    delete ix;
+}
+
+int ucfp_index_upsert(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, const void* rows, size_t n) {
+    if (!ix) return capi_fail(UCFP_E_INVALID, "index is NULL");
+    if (n == 0) return UCFP_OK;
+    if (!ids || !rows) return capi_fail(UCFP_E_INVALID, "ids/rows is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    Shard& s = ix->shards[tenant];
+    hipStream_t st = ix->stream;
+    const bool mapped = !(ix->flags & UCFP_INDEX_APPEND_ONLY);
+    // resolve target rows on the host; within a batch the LAST occurrence of an id wins
+    std::vector<uint64_t> dst(n);
+    std::vector<uint8_t> keep(n, 1);
+    size_t new_n = s.n;
+    if (mapped) {
+        std::unordered_map<uint64_t, size_t> last;
+        last.reserve(n * 2);
+        for (size_t i = 0; i < n; i++) last[ids[i]] = i;
+        for (size_t i = 0; i < n; i++) {
+            if (last[ids[i]] != i) {
+                keep[i] = 0;
+                continue;
+            }
+            auto it = s.pos.find(ids[i]);
+            if (it != s.pos.end()) dst[i] = it->second;
+            else dst[i] = new_n++;
+        }
+    } else {
+        for (size_t i = 0; i < n; i++) dst[i] = new_n++;
+    }
+    int rc = shard_reserve(ix, s, new_n, st);
+    if (rc) return rc;
+    // compact the kept items into the staging buffer: ids | dst | rows | (norms)
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) m += keep[i];
+    const size_t o_ids = 0, o_dst = align256(m * 8), o_rows = align256(o_dst + m * 8);
+    const size_t o_norm = align256(o_rows + m * ix->row_bytes);
+    rc = ix->stage.ensure(o_norm + m * 4 + 256);
+    if (rc) return rc;
+    std::vector<uint64_t> h_ids(m), h_dst(m);
+    std::vector<uint8_t> h_rows(m * ix->row_bytes);
+    size_t j = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!keep[i]) continue;
+        h_ids[j] = ids[i];
+        h_dst[j] = dst[i];
+        memcpy(h_rows.data() + j * ix->row_bytes, (const uint8_t*)rows + i * ix->row_bytes, ix->row_bytes);
+        j++;
+    }
+    uint8_t* sp = ix->stage.p;
+    HIP_TRY(hipMemcpyAsync(sp + o_ids, h_ids.data(), m * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sp + o_dst, h_dst.data(), m * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sp + o_rows, h_rows.data(), m * ix->row_bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)m), dim3(64), 0, st,
+                       reinterpret_cast<const uint64_t*>(sp + o_ids), sp + o_rows,
+                       reinterpret_cast<const uint64_t*>(sp + o_dst), m, ix->row_bytes, s.ids, s.rows);
+    if (ix->kind == UCFP_INDEX_COSINE_F32) {
+        ucfp::launch_cosine_norms(reinterpret_cast<const float*>(sp + o_rows), m, ix->dim,
+                                  reinterpret_cast<float*>(sp + o_norm), st);
+        hipLaunchKernelGGL(gather_norms_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(sp + o_norm), reinterpret_cast<const uint64_t*>(sp + o_dst),
+                           m, s.norms);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // staging vectors are stack-owned
+    if (mapped) {
+        s.host_ids.resize(new_n);
+        for (size_t t = 0; t < m; t++) {
+            s.pos[h_ids[t]] = h_dst[t];
+            s.host_ids[h_dst[t]] = h_ids[t];
+        }
+    }
+    s.n = new_n;
+    return UCFP_OK;
+}
+
+int ucfp_index_append_dev(ucfp_index* ix, uint32_t tenant, const uint64_t* d_ids, const void* d_rows, size_t n,
+                          void* stream) {
+    if (!ix) return capi_fail(UCFP_E_INVALID, "index is NULL");
+    if (!(ix->flags & UCFP_INDEX_APPEND_ONLY))
+        return capi_fail(UCFP_E_UNSUPPORTED, "append_dev needs an index created with UCFP_INDEX_APPEND_ONLY");
+    if (n == 0) return UCFP_OK;
+    if (!d_ids || !d_rows) return capi_fail(UCFP_E_INVALID, "ids/rows is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    Shard& s = ix->shards[tenant];
+    hipStream_t st = (hipStream_t)stream;
+    int rc = shard_reserve(ix, s, s.n + n, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(s.ids + s.n, d_ids, n * 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.rows + s.n * ix->row_bytes, d_rows, n * ix->row_bytes, hipMemcpyDeviceToDevice, st));
+    if (ix->kind == UCFP_INDEX_COSINE_F32)
+        ucfp::launch_cosine_norms(reinterpret_cast<const float*>(s.rows + s.n * ix->row_bytes), n, ix->dim,
+                                  s.norms + s.n, st);
+    HIP_TRY(hipGetLastError());
+    s.n += n;
+    return UCFP_OK;
+}
+
+int ucfp_index_delete(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, size_t n, size_t* n_removed) {
+    if (n_removed) *n_removed = 0;
+    if (!ix) return capi_fail(UCFP_E_INVALID, "index is NULL");
+    if (ix->flags & UCFP_INDEX_APPEND_ONLY)
+        return capi_fail(UCFP_E_UNSUPPORTED, "delete on an APPEND_ONLY index");
+    if (n && !ids) return capi_fail(UCFP_E_INVALID, "ids is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    auto sit = ix->shards.find(tenant);
+    if (sit == ix->shards.end()) return UCFP_OK;  // deleting from an unknown tenant is a no-op
+    Shard& s = sit->second;
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = ix->stream;
+    size_t removed = 0;
+    for (size_t i = 0; i < n; i++) {
+        auto it = s.pos.find(ids[i]);
+        if (it == s.pos.end()) continue;
+        const size_t r = it->second, last = s.n - 1;
+        if (r != last) {
+            HIP_TRY(hipMemcpyAsync(s.ids + r, s.ids + last, 8, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s.rows + r * ix->row_bytes, s.rows + last * ix->row_bytes, ix->row_bytes,
+                                   hipMemcpyDeviceToDevice, st));
+            if (s.norms) HIP_TRY(hipMemcpyAsync(s.norms + r, s.norms + last, 4, hipMemcpyDeviceToDevice, st));
+            const uint64_t moved = s.host_ids[last];
+            s.host_ids[r] = moved;
+            s.pos[moved] = r;
+        }
+        s.pos.erase(it);
+        s.host_ids.pop_back();
+        s.n--;
+        removed++;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_removed) *n_removed = removed;
+    return UCFP_OK;
+}
+
+int ucfp_index_size(ucfp_index* ix, uint32_t tenant, size_t* out) {
+    if (!ix || !out) return capi_fail(UCFP_E_INVALID, "index/out is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    auto it = ix->shards.find(tenant);
+    *out = it == ix->shards.end() ? 0 : it->second.n;
+    return UCFP_OK;
+}
+
+int ucfp_index_flush(ucfp_index* ix) {
+    if (!ix) return capi_fail(UCFP_E_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return UCFP_OK;
+}
+
+int ucfp_index_search_dev(ucfp_index* ix, uint32_t tenant, const void* d_queries, size_t nq, uint32_t k,
+                          uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_dist, uint32_t* d_out_counts,
+                          void* stream) {
+    int rc = check_search_args(ix, d_queries, nq, k, d_out_ids, d_out_counts);
+    if (rc) return rc;
+    if (nq == 0) return UCFP_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_counts, 0, nq * 4, st));
+        return UCFP_OK;
+    }
+    auto it = ix->shards.find(tenant);
+    const Shard* s = it == ix->shards.end() ? nullptr : &it->second;
+    // the workspace is shared: a search may start only after the previous one (on any stream) is done
+    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    rc = search_shard_dev(ix, s, d_queries, nq, k, d_out_ids, d_out_scores, d_out_dist, d_out_counts, st);
+    HIP_TRY(hipEventRecord(ix->ws_done, st));
+    return rc;
+}
+
+int ucfp_index_search(ucfp_index* ix, uint32_t tenant, const void* queries, size_t nq, uint32_t k,
+                      uint64_t* out_ids, float* out_scores, uint32_t* out_dist, uint32_t* out_counts) {
+    int rc = check_search_args(ix, queries, nq, k, out_ids, out_counts);
+    if (rc) return rc;
+    if (nq == 0) return UCFP_OK;
+    if (k == 0) {
+        memset(out_counts, 0, nq * 4);
+        return UCFP_OK;
+    }
+    // results buffer (own allocation: the shared staging buffer may be re-grown by search)
+    const size_t qbytes = nq * ix->row_bytes;
+    const size_t o_q = 0, o_ids = align256(qbytes), o_sc = align256(o_ids + nq * k * 8);
+    const size_t o_d = align256(o_sc + nq * k * 4), o_c = align256(o_d + nq * k * 4);
+    const size_t total = align256(o_c + nq * 4);
+    hipStream_t st;
+    uint8_t* buf = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        HIP_TRY(hipSetDevice(ix->device));
+        st = ix->stream;
+        HIP_TRY(hipMalloc((void**)&buf, total));
+    }
+    hipError_t e = hipMemcpyAsync(buf + o_q, queries, qbytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = ucfp_index_search_dev(ix, tenant, buf + o_q, nq, k, reinterpret_cast<uint64_t*>(buf + o_ids),
+                                   reinterpret_cast<float*>(buf + o_sc), reinterpret_cast<uint32_t*>(buf + o_d),
+                                   reinterpret_cast<uint32_t*>(buf + o_c), st);
+        if (rc == 0) {
+            e = hipMemcpyAsync(out_ids, buf + o_ids, nq * k * 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && out_scores)
+                e = hipMemcpyAsync(out_scores, buf + o_sc, nq * k * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && out_dist)
+                e = hipMemcpyAsync(out_dist, buf + o_d, nq * k * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_counts, buf + o_c, nq * 4, hipMemcpyDeviceToHost, st);
+        }
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (rc) return rc;
+    if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "search copy failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return capi_fail(UCFP_E_INDEX, "search failed: %s", hipGetErrorString(e2));
+    return UCFP_OK;
+}
+
+int ucfp_topk_merge_dev(ucfp_ctx* ctx, int kind, const uint64_t* d_part_ids, const uint32_t* d_part_keys,
+                        uint32_t parts, size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
+                        uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream) {
+    if (!ctx) return capi_fail(UCFP_E_INVALID, "ctx is NULL");
+    if (kind != UCFP_INDEX_HAMMING64 && kind != UCFP_INDEX_COSINE_F32)
+        return capi_fail(UCFP_E_UNSUPPORTED, "unknown index kind %d", kind);
+    if (nq == 0 || k == 0) return UCFP_OK;
+    if (!d_part_ids || !d_part_keys || !d_out_ids || !d_out_keys || !d_out_counts)
+        return capi_fail(UCFP_E_INVALID, "merge buffers must not be NULL");
+    if (k > UCFP_INDEX_MAX_K) return capi_fail(UCFP_E_INVALID, "k too large");
+    hipStream_t st = (hipStream_t)stream;
+    ucfp::launch_topk_merge_u32(d_part_ids, d_part_keys, parts, (uint32_t)nq, k, d_out_ids, d_out_keys, d_out_counts, st);
+    if (d_out_scores) {
+        if (kind == UCFP_INDEX_HAMMING64) ucfp::launch_hamming_scores(d_out_keys, nq * k, d_out_scores, st);
+        else ucfp::launch_cosine_scores_from_keys(d_out_keys, nq * k, d_out_scores, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return UCFP_OK;
+}
+
+}  // extern "C"

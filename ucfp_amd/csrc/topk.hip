@@ -1,0 +1,207 @@
+// topk.hip -- selection primitives shared by the Hamming and cosine searches.
+//
+// Keys are u32, SMALLER IS BETTER (Hamming distance, or the inverted order-image of a cosine
+// score); 0xffffffff marks "no entry".  Order everywhere: (key ascending, record_id ascending).
+//
+//   select_topk_u32   row-parallel selection from a precomputed key row keys[q][0..n):
+//                     lane = row (coalesced), ONE wave-shared candidate list in LDS and a
+//                     wave-uniform threshold tau = current k-th key, so after warm-up a wave
+//                     only leaves its load/compare loop for the rare row that beats tau.
+//   topk_merge_u32    one wave per query merges `parts` sorted partial lists; used for the
+//                     slices of one GPU and, after the RCCL all-gather, for the shards of a node.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace ucfp {
+
+namespace {
+constexpr int kWave = 64;
+constexpr int kSelCap = 256;  // wave-shared candidate slots (>= k + 64)
+
+__device__ __forceinline__ bool key_less(uint32_t d1, uint64_t i1, uint32_t d2, uint64_t i2) {
+    return d1 < d2 || (d1 == d2 && i1 < i2);
+}
+
+// wave-wide argmin over (key, id) pairs held one per lane
+__device__ __forceinline__ void wave_argmin(uint32_t& bd, uint64_t& bi) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t od = __shfl_xor(bd, off, kWave);
+        const uint64_t oi = __shfl_xor(bi, off, kWave);
+        if (key_less(od, oi, bd, bi)) {
+            bd = od;
+            bi = oi;
+        }
+    }
+}
+}  // namespace
+
+// grid (slices, nq), block 64. keys: [nq][n]; ids: [n].
+// partial out: [slice][q][k] ids/keys, [slice][q] counts.
+__global__ __launch_bounds__(64) void select_topk_u32(const uint32_t* __restrict__ keys,
+                                                      const uint64_t* __restrict__ ids, size_t n,
+                                                      size_t per_slice, uint32_t nq, uint32_t k,
+                                                      uint64_t* __restrict__ part_ids,
+                                                      uint32_t* __restrict__ part_key,
+                                                      uint32_t* __restrict__ part_cnt) {
+    __shared__ uint64_t l_id[2][kSelCap];
+    __shared__ uint32_t l_key[2][kSelCap];
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.y;
+    const uint32_t* __restrict__ kq = keys + (size_t)q * n;
+    const size_t s0 = (size_t)blockIdx.x * per_slice;
+    const size_t s1 = s0 + per_slice < n ? s0 + per_slice : n;
+    uint32_t tau = 0xffffffffu;  // wave-uniform: accept keys < tau, or == tau while it is a real key
+    uint32_t cnt = 0;            // wave-uniform
+    int cur = 0;
+
+    // keep the best min(cnt, k) entries of list `cur`, sorted, into list `cur ^ 1`
+    auto prune = [&]() {
+        const int nxt = cur ^ 1;
+        uint32_t ld = 0;
+        uint64_t li = 0;
+        bool first = true;
+        uint32_t kept = 0;
+        const uint32_t want = cnt < k ? cnt : k;
+        for (uint32_t r = 0; r < want; r++) {
+            uint32_t bd = 0xffffffffu;
+            uint64_t bi = ~0ull;
+            for (uint32_t e = lane; e < cnt; e += kWave) {
+                const uint32_t dd = l_key[cur][e];
+                const uint64_t ii = l_id[cur][e];
+                if ((first || key_less(ld, li, dd, ii)) && key_less(dd, ii, bd, bi)) {
+                    bd = dd;
+                    bi = ii;
+                }
+            }
+            wave_argmin(bd, bi);
+            if (bd == 0xffffffffu && bi == ~0ull) break;
+            if (lane == 0) {
+                l_key[nxt][r] = bd;
+                l_id[nxt][r] = bi;
+            }
+            ld = bd;
+            li = bi;
+            first = false;
+            kept++;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        cnt = kept;
+        cur = nxt;
+        if (cnt >= k) tau = l_key[cur][k - 1];
+    };
+
+    for (size_t base = s0; base < s1; base += kWave) {
+        const size_t row = base + lane;
+        const uint32_t key = row < s1 ? kq[row] : 0xffffffffu;
+        const bool hit = key != 0xffffffffu && key <= tau;
+        const uint64_t mask = __ballot(hit);
+        if (mask) {
+            if (hit) {
+                const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                l_key[cur][pos] = key;
+                l_id[cur][pos] = ids[row];
+            }
+            cnt += (uint32_t)__popcll(mask);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (cnt > (uint32_t)(kSelCap - kWave)) prune();
+        }
+    }
+    prune();
+    const size_t obase = ((size_t)blockIdx.x * nq + q) * k;
+    for (uint32_t e = lane; e < k; e += kWave) {
+        const bool v = e < cnt;
+        part_ids[obase + e] = v ? l_id[cur][e] : ~0ull;
+        part_key[obase + e] = v ? l_key[cur][e] : 0xffffffffu;
+    }
+    if (lane == 0) part_cnt[(size_t)blockIdx.x * nq + q] = cnt;
+}
+
+// One wave per query. parts x k candidates; invalid entries carry key 0xffffffff.
+// Output: best k by (key, id) ascending, each (key, id) pair emitted once.
+__global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict__ part_ids,
+                                                     const uint32_t* __restrict__ part_key,
+                                                     uint32_t parts, uint32_t nq, uint32_t k,
+                                                     uint64_t* __restrict__ out_ids,
+                                                     uint32_t* __restrict__ out_key,
+                                                     uint32_t* __restrict__ out_cnt) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t total = parts * k;
+    uint32_t ld = 0;
+    uint64_t li = 0;
+    bool first = true;
+    uint32_t emitted = 0;
+    for (uint32_t r = 0; r < k; r++) {
+        uint32_t bd = 0xffffffffu;
+        uint64_t bi = ~0ull;
+        for (uint32_t c = lane; c < total; c += kWave) {
+            const uint32_t p = c / k, e = c - p * k;
+            const size_t off = ((size_t)p * nq + q) * k + e;
+            const uint32_t dd = part_key[off];
+            const uint64_t ii = part_ids[off];
+            if (dd == 0xffffffffu) continue;
+            if ((first || key_less(ld, li, dd, ii)) && key_less(dd, ii, bd, bi)) {
+                bd = dd;
+                bi = ii;
+            }
+        }
+        wave_argmin(bd, bi);
+        if (bd == 0xffffffffu) break;
+        if (lane == 0) {
+            out_ids[(size_t)q * k + r] = bi;
+            out_key[(size_t)q * k + r] = bd;
+        }
+        ld = bd;
+        li = bi;
+        first = false;
+        emitted++;
+    }
+    if (lane == 0) {
+        for (uint32_t r = emitted; r < k; r++) {
+            out_ids[(size_t)q * k + r] = ~0ull;
+            out_key[(size_t)q * k + r] = 0xffffffffu;
+        }
+        out_cnt[q] = emitted;
+    }
+}
+
+SelectPlan select_plan(size_t n, uint32_t nq) {
+    SelectPlan p;
+    const uint32_t want_waves = 256 * 16;
+    uint32_t slices = nq ? (want_waves + nq - 1) / nq : 1;
+    const size_t max_slices = (n + 8191) / 8192;
+    if (slices > max_slices) slices = (uint32_t)(max_slices ? max_slices : 1);
+    if (slices < 1) slices = 1;
+    p.per_slice = (n + slices - 1) / slices;
+    p.per_slice = (p.per_slice + 63) & ~(size_t)63;
+    p.slices = (uint32_t)((n + p.per_slice - 1) / (p.per_slice ? p.per_slice : 1));
+    if (p.slices < 1) p.slices = 1;
+    return p;
+}
+
+int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, const SelectPlan& p,
+                           uint32_t nq, uint32_t k, uint64_t* part_ids, uint32_t* part_key,
+                           uint32_t* part_cnt, hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(select_topk_u32, dim3(p.slices, nq), dim3(64), 0, stream, keys, ids, n, p.per_slice, nq,
+                       k, part_ids, part_key, part_cnt);
+    return 0;
+}
+
+int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,
+                          uint32_t k, uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt,
+                          hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(topk_merge_u32, dim3(nq), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, out_ids,
+                       out_key, out_cnt);
+    return 0;
+}
+
+}  // namespace ucfp

@@ -1,0 +1,198 @@
+"""kNN index -- host-side mirror of `trait IndexBackend` (src/index/mod.rs:17-78) for the vector
+path, backed by the GPU-resident shard behind the C ABI (ucfp_index_*).
+
+    GpuIndex.upsert(records)          IndexBackend::upsert   src/index/mod.rs:20-22
+    GpuIndex.delete(tenant, ids)      IndexBackend::delete   :24-27
+    GpuIndex.knn(tenant, query, k)    IndexBackend::knn      :29-35  (cosine over Record.embedding,
+                                      as EmbeddedBackend::knn src/index/embedded/mod.rs:268-360)
+    GpuIndex.hamming(tenant, h, k)    the new Hamming search behind /v1/query
+    GpuIndex.flush()                  IndexBackend::flush    :63
+
+The reference keeps redb as the source of truth; this object is the device mirror of one shard
+(one process per GPU).  `ShardedIndex` in ucfp_amd/sharded.py spreads a corpus over the ranks of a
+node and merges per-shard top-k after an RCCL all-gather.
+"""
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .core import Hit, HitSource, Record
+from .errors import InvalidArgument
+
+HAMMING64, COSINE_F32 = 1, 2
+APPEND_ONLY = 1
+MAX_K = 128
+INVALID_ID = 0xFFFFFFFFFFFFFFFF
+
+
+class DeviceIndex:
+    """Thin RAII wrapper over one ucfp_index handle (one kind, one dim)."""
+
+    def __init__(self, kind: int, dim: int = 0, flags: int = 0, ctx=None):
+        self._lib = _lib.load()
+        self.ctx = ctx or _lib.default_context()
+        self.kind, self.dim, self.flags = kind, dim, flags
+        h = C.c_void_p()
+        _lib.check(self._lib.ucfp_index_create(self.ctx.handle, kind, dim, flags, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_index_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- mutation ----
+    def _rows(self, rows):
+        if self.kind == HAMMING64:
+            a = np.ascontiguousarray(rows, dtype=np.uint64).reshape(-1)
+        else:
+            a = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.dim)
+        return a
+
+    def upsert(self, tenant: int, ids, rows) -> None:
+        ids = np.ascontiguousarray(ids, dtype=np.uint64).reshape(-1)
+        rows = self._rows(rows)
+        if rows.shape[0] != ids.shape[0]:
+            raise InvalidArgument("ids and rows disagree on the number of records")
+        _lib.check(self._lib.ucfp_index_upsert(self.handle, tenant, ids.ctypes.data, rows.ctypes.data,
+                                               ids.shape[0]))
+
+    def append_dev(self, tenant: int, ids_ptr: int, rows_ptr: int, n: int, stream: int = 0) -> None:
+        _lib.check(self._lib.ucfp_index_append_dev(self.handle, tenant, ids_ptr, rows_ptr, n, stream or None))
+
+    def delete(self, tenant: int, ids) -> int:
+        ids = np.ascontiguousarray(ids, dtype=np.uint64).reshape(-1)
+        removed = C.c_size_t(0)
+        _lib.check(self._lib.ucfp_index_delete(self.handle, tenant, ids.ctypes.data, ids.shape[0],
+                                               C.byref(removed)))
+        return int(removed.value)
+
+    def size(self, tenant: int) -> int:
+        out = C.c_size_t(0)
+        _lib.check(self._lib.ucfp_index_size(self.handle, tenant, C.byref(out)))
+        return int(out.value)
+
+    def flush(self) -> None:
+        _lib.check(self._lib.ucfp_index_flush(self.handle))
+
+    # ---- search ----
+    def search(self, tenant: int, queries, k: int):
+        """Host-memory batch search. Returns (ids [nq,k] u64, scores [nq,k] f32, keys [nq,k] u32,
+        counts [nq] u32); keys = Hamming distance, or the inverted order image of the cosine score."""
+        q = self._rows(queries)
+        nq = q.shape[0]
+        kk = max(k, 1)
+        ids = np.full((nq, kk), INVALID_ID, np.uint64)
+        scores = np.zeros((nq, kk), np.float32)
+        keys = np.full((nq, kk), 0xFFFFFFFF, np.uint32)
+        counts = np.zeros(nq, np.uint32)
+        _lib.check(self._lib.ucfp_index_search(self.handle, tenant, q.ctypes.data, nq, k, ids.ctypes.data,
+                                               scores.ctypes.data, keys.ctypes.data, counts.ctypes.data))
+        return ids[:, :k], scores[:, :k], keys[:, :k], counts
+
+    def search_dev(self, tenant: int, queries_ptr: int, nq: int, k: int, out_ids_ptr: int,
+                   out_scores_ptr: int, out_keys_ptr: int, out_counts_ptr: int, stream: int = 0) -> None:
+        _lib.check(self._lib.ucfp_index_search_dev(self.handle, tenant, queries_ptr, nq, k, out_ids_ptr,
+                                                   out_scores_ptr or None, out_keys_ptr or None,
+                                                   out_counts_ptr, stream or None))
+
+
+def topk_merge_dev(kind: int, part_ids_ptr: int, part_keys_ptr: int, parts: int, nq: int, k: int,
+                   out_ids_ptr: int, out_scores_ptr: int, out_keys_ptr: int, out_counts_ptr: int,
+                   stream: int = 0, ctx=None) -> None:
+    ctx = ctx or _lib.default_context()
+    _lib.check(_lib.load().ucfp_topk_merge_dev(ctx.handle, kind, part_ids_ptr, part_keys_ptr, parts, nq, k,
+                                               out_ids_ptr, out_scores_ptr or None, out_keys_ptr,
+                                               out_counts_ptr, stream or None))
+
+
+class GpuIndex:
+    """IndexBackend-shaped facade: cosine kNN over `Record.embedding` plus Hamming search over
+    64-bit hashes pulled out of `Record.fingerprint`.  Embedding indexes are keyed by dimension,
+    like the reference skips rows whose stored length differs from the query's
+    (src/index/embedded/mod.rs:307-309)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self._cos = {}        # dim -> DeviceIndex
+        self._ham = {}        # hash space name -> DeviceIndex
+
+    def _cosine(self, dim: int) -> DeviceIndex:
+        ix = self._cos.get(dim)
+        if ix is None:
+            ix = self._cos[dim] = DeviceIndex(COSINE_F32, dim, 0, self.ctx)
+        return ix
+
+    def _hamming(self, space: str) -> DeviceIndex:
+        ix = self._ham.get(space)
+        if ix is None:
+            ix = self._ham[space] = DeviceIndex(HAMMING64, 0, 0, self.ctx)
+        return ix
+
+    def upsert(self, records: Sequence[Record]) -> None:
+        """Embeddings go to the cosine index of their dimension; image records also feed the
+        Hamming spaces `<algorithm>` with their 64-bit global hashes (SURVEY 8f N2 offsets)."""
+        by_cos, by_ham = {}, {}
+        for r in records:
+            if r.embedding is not None and len(r.embedding) > 0:
+                by_cos.setdefault((r.tenant_id, len(r.embedding)), []).append(r)
+            for space, h in _hash_spaces(r):
+                by_ham.setdefault((r.tenant_id, space), []).append((r.record_id, h))
+        for (tenant, dim), recs in by_cos.items():
+            ids = np.array([r.record_id for r in recs], np.uint64)
+            rows = np.array([r.embedding for r in recs], np.float32)
+            self._cosine(dim).upsert(tenant, ids, rows)
+        for (tenant, space), items in by_ham.items():
+            ids = np.array([i for i, _ in items], np.uint64)
+            rows = np.array([h for _, h in items], np.uint64)
+            self._hamming(space).upsert(tenant, ids, rows)
+
+    def delete(self, tenant_id: int, record_ids: Iterable[int]) -> None:
+        ids = np.array(list(record_ids), np.uint64)
+        for ix in list(self._cos.values()) + list(self._ham.values()):
+            ix.delete(tenant_id, ids)
+
+    def knn(self, tenant_id: int, query: Sequence[float], k: int, _filter: Optional[bytes] = None) -> List[Hit]:
+        """EmbeddedBackend::knn: empty query or k == 0 -> [] (src/index/embedded/mod.rs:275-277)."""
+        q = np.asarray(query, np.float32).reshape(-1)
+        if q.size == 0 or k == 0:
+            return []
+        ix = self._cos.get(q.size)
+        if ix is None:
+            return []
+        ids, scores, _, counts = ix.search(tenant_id, q[None, :], min(k, MAX_K))
+        return [Hit(tenant_id=tenant_id, record_id=int(ids[0, i]), score=float(scores[0, i]),
+                    source=HitSource.Vector) for i in range(int(counts[0]))]
+
+    def hamming(self, tenant_id: int, space: str, query_hash: int, k: int) -> List[Hit]:
+        if k == 0 or space not in self._ham:
+            return []
+        ids, scores, dist, counts = self._ham[space].search(
+            tenant_id, np.array([query_hash], np.uint64), min(k, MAX_K))
+        return [Hit(tenant_id=tenant_id, record_id=int(ids[0, i]), score=float(scores[0, i]),
+                    source=HitSource.Hamming, distance=int(dist[0, i])) for i in range(int(counts[0]))]
+
+    def flush(self) -> None:
+        for ix in list(self._cos.values()) + list(self._ham.values()):
+            ix.flush()
+
+
+def _hash_spaces(r: Record):
+    """(space, u64) pairs a record contributes to Hamming search."""
+    fp = r.fingerprint
+    rd = lambda off: int.from_bytes(fp[off:off + 8], "little")  # noqa: E731
+    if r.algorithm == "imgfprint-multihash-v1" and len(fp) == 536:
+        return [("imgfprint-ahash-v1", rd(64)), ("imgfprint-phash-v1", rd(232)), ("imgfprint-dhash-v1", rd(400))]
+    if r.algorithm in ("imgfprint-ahash-v1", "imgfprint-phash-v1", "imgfprint-dhash-v1") and len(fp) == 168:
+        return [(r.algorithm, rd(32))]
+    if r.algorithm in ("simhash-b64-tf", "simhash-b64-idf") and len(fp) == 8:
+        return [(r.algorithm, rd(0))]
+    return []

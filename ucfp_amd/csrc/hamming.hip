@@ -217,6 +217,12 @@ __global__ void hamming_scores(const uint32_t* __restrict__ dist, size_t total, 
 HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     HammingPlan p;
     p.qgroups = (nq + kWave - 1) / kWave;
+    p.cap = k <= 16 ? 24 : k <= 40 ? 64 : 160;
+    if (n == 0) {  // empty shard: nothing to scan, no partial lists
+        p.slices = 0;
+        p.sample_parts = 0;
+        return p;
+    }
     // enough independent waves to fill 256 CUs several times over, slices of >= 4096 codes
     const uint32_t want_waves = 256 * 16;
     uint32_t slices = (want_waves + p.qgroups - 1) / p.qgroups;

@@ -35,6 +35,11 @@ def parse():
     ap.add_argument("--frames", type=int, default=100_000, help="frames per GPU (BASELINE: 100k)")
     ap.add_argument("--cpu-sample", type=int, default=8192,
                     help="frames of the same workload timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--ann-corpus", type=int, default=100_000_000,
+                    help="TOTAL 64-bit fingerprints in the sharded Hamming corpus (BASELINE configs[4]: "
+                         "100M; split evenly over the ranks = strong scaling). 0 skips the ANN leg")
+    ap.add_argument("--ann-queries", type=int, default=4096)
+    ap.add_argument("--ann-steps", type=int, default=5)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)")
     return ap.parse_args()
@@ -61,6 +66,72 @@ def cpu_baseline(sample: int, gpu_records_head):
                   f"{dt * cores:.1f} core-s); C restatement oracle/ucfp_oracle_image.c, "
                   "not the reference Rust binary (no Rust toolchain, SDK crates un-vendored)",
         "gpu_matches_oracle_on_sample": parity,
+    }
+
+
+def bench_ann(args, rank, world, dev, ctx):
+    """Secondary leg (BASELINE configs[4]): /v1/query Hamming k=10 over a corpus sharded across
+    the ranks, one all-gather of per-shard top-k, merge on every rank. Returns a dict (rank 0)."""
+    import torch
+    import torch.distributed as dist
+    from ucfp_amd import index, sharded
+
+    k, nq = 10, args.ann_queries
+    start, end = sharded.shard_range(args.ann_corpus, rank, world)
+    n_local = end - start
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED + rank)
+    codes = torch.randint(-2**63, 2**63 - 1, (n_local,), dtype=torch.int64, device=dev, generator=g)
+    ids = torch.arange(start, end, dtype=torch.int64, device=dev)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(0xC0FFEE)
+    queries = torch.randint(-2**63, 2**63 - 1, (nq,), dtype=torch.int64, device=dev, generator=gq)
+    # plant a true neighbour (Hamming <= 3) for every second query, spread over the shards
+    for j in range(0, nq, 2):
+        owner = (j // 2) % world
+        if owner == rank and n_local:
+            pos = (j * 7919) % n_local
+            codes[pos] = queries[j] ^ (1 << (j % 61)) ^ (1 << ((j * 3) % 59))
+    six = sharded.ShardedIndex(index.HAMMING64, ctx=ctx)
+    six.append_local(ids, codes)
+    torch.cuda.synchronize()
+    del codes, ids
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(2):
+        six.search(queries, k)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.ann_steps):
+        out = six.search(queries, k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out_ids, _, out_keys, out_cnt = out
+    planted_found = int((out_keys[0::2, 0] <= 3).sum().item())
+    if rank != 0:
+        return None
+    qps = nq * args.ann_steps / dt
+    pairs_per_s = qps * args.ann_corpus
+    valu_peak = 256 * 128 * 2.4e9           # lane-ops/s: 256 CUs x 4 SIMD-32, 2.4 GHz (= 157.3 TF / 2)
+    return {
+        "metric": "ANN queries/sec (Hamming k=10, brute force, exact)", "value": qps, "unit": "queries/s",
+        "corpus_total": args.ann_corpus, "corpus_per_gpu": n_local, "queries_per_batch": nq, "k": k,
+        "ms_per_batch": dt / args.ann_steps * 1e3, "scaling": "strong",
+        "exchange": "one all-gather of nq*k*(8+4) B per rank + merge on every rank" if world > 1 else "none",
+        "pairs_per_s": pairs_per_s,
+        "roofline": {"bound": "valu", "achieved": pairs_per_s * 5 / world / 1e12, "peak": valu_peak / 1e12,
+                     "unit": "T lane-op/s per GPU (5 VALU ops per code-query pair)",
+                     "frac": pairs_per_s * 5 / world / valu_peak,
+                     "hbm_GBs_per_gpu": (nq / 64) * n_local * 8 / (dt / args.ann_steps) / 1e9},
+        "planted_neighbours_found": f"{planted_found}/{(nq + 1) // 2}",
     }
 
 
@@ -161,11 +232,22 @@ def main():
                 "traffic": args.traffic_bytes,
             },
         }
+        res["ann"] = None
         if args.cpu_sample > 0 and world == 1:
             head = out[:min(args.cpu_sample, n)].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), head)
         elif args.cpu_sample > 0:
             res["cpu_baseline"] = None  # measured at N=1 only (see BENCH at n_gpus=1)
+    else:
+        res = None
+    # ---- secondary leg: sharded Hamming ANN (frees the image batch first) ----
+    del frames, out, status
+    torch.cuda.empty_cache()
+    if args.ann_corpus > 0:
+        ann = bench_ann(args, rank, world, dev, ctx)
+        if rank == 0:
+            res["ann"] = ann
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

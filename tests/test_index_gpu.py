@@ -84,6 +84,39 @@ def test_hamming_adversarial_order(gpu_ctx, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("n,nq,k", [(1_200_000, 70, 10), (2_500_000, 9, 10), (1_100_000, 3, 64)])
+def test_hamming_two_tier_matches_oracle(gpu_ctx, oracle, n, nq, k):
+    """n >= 2^20 takes the prefix + fast-filter path (hamming_scan_fast / hamming_final_merge)."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(n + k)
+    ids, codes, queries = _planted_corpus(rng, n, nq, planted_per_q=12)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    ix.upsert(0, ids, codes)
+    g_ids, _, g_d, g_c = ix.search(0, queries, k)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+    assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids)
+    ix.close()
+
+
+def test_hamming_two_tier_overflow_falls_back(gpu_ctx, oracle):
+    """Prefix far from the query (tau1 = 64) and a tail full of near rows: every candidate list
+    overflows, the device-side flag routes the batch through the robust tier, results stay exact."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(77)
+    n = 1_300_000
+    q = rng.integers(0, 2**64, 5, dtype=np.uint64)
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    codes[: n // 4] = ~q[0]                                   # prefix: distance 64 from q[0]
+    codes[n // 2:] = q[0] ^ rng.integers(0, 2**10, n - n // 2, dtype=np.uint64)  # tail: d <= 10
+    ids = rng.permutation(n).astype(np.uint64)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    ix.upsert(0, ids, codes)
+    g_ids, _, g_d, g_c = ix.search(0, q, 10)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, q, 10)
+    assert np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids) and np.array_equal(g_c, o_c)
+    ix.close()
+
+
 def test_upsert_overwrite_delete_tenants(gpu_ctx, oracle):
     from ucfp_amd import index
     rng = np.random.default_rng(1)

@@ -17,12 +17,19 @@ int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t
 // hamming.hip
 struct HammingPlan {
     uint32_t qgroups = 0;       // ceil(nq / 64)
-    uint32_t slices = 0;        // corpus slices (one wave per slice x qgroup)
-    size_t per_slice = 0;
+    int cap = 24;               // lane-private candidate list capacity (robust tier)
     size_t sample_n = 0;        // codes in the tau0 sample pre-pass
     uint32_t sample_parts = 0;
     size_t per_part = 0;
-    int cap = 24;               // lane-private candidate list capacity
+    size_t robust_n = 0;        // robust tier covers [0, robust_n) (== n when `fast` is off)
+    uint32_t slices = 0;        // robust tier: one wave per (slice, qgroup)
+    size_t per_slice = 0;
+    bool fast = false;          // fast tier covers [robust_n, n)
+    uint32_t fslices = 0;
+    size_t fper_slice = 0;
+    uint32_t cand_cap = 0;      // candidate slots per query in global memory
+    uint32_t fb_slices = 0;     // fallback robust scan over [0, n), device-gated on overflow
+    size_t fb_per_slice = 0;
 };
 HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k);
 size_t hamming_workspace_bytes(const HammingPlan& p, uint32_t nq, uint32_t k);
@@ -41,9 +48,10 @@ SelectPlan select_plan(size_t n, uint32_t nq);
 int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, const SelectPlan& p,
                            uint32_t nq, uint32_t k, uint64_t* part_ids, uint32_t* part_key,
                            uint32_t* part_cnt, hipStream_t stream);
+// run_flag: optional device word; when non-null the merge only runs if it is non-zero
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts,
                           uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key,
-                          uint32_t* out_cnt, hipStream_t stream);
+                          uint32_t* out_cnt, const uint32_t* run_flag, hipStream_t stream);
 
 // cosine.hip
 int launch_cosine_norms(const float* rows, size_t n, uint32_t dim, float* norms, hipStream_t stream);

@@ -214,7 +214,7 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
                                      reinterpret_cast<uint32_t*>(w + o_pk), reinterpret_cast<uint32_t*>(w + o_pc), st);
         ucfp::launch_topk_merge_u32(reinterpret_cast<uint64_t*>(w + o_pid), reinterpret_cast<uint32_t*>(w + o_pk),
                                     spc.slices, (uint32_t)qc, k, d_out_ids + q0 * k, okeys + q0 * k, d_out_cnt + q0,
-                                    st);
+                                    nullptr, st);
     }
     if (d_out_scores) ucfp::launch_cosine_scores_from_keys(okeys, nq * k, d_out_scores, st);
     HIP_TRY(hipGetLastError());
@@ -502,7 +502,8 @@ int ucfp_topk_merge_dev(ucfp_ctx* ctx, int kind, const uint64_t* d_part_ids, con
         return capi_fail(UCFP_E_INVALID, "merge buffers must not be NULL");
     if (k > UCFP_INDEX_MAX_K) return capi_fail(UCFP_E_INVALID, "k too large");
     hipStream_t st = (hipStream_t)stream;
-    ucfp::launch_topk_merge_u32(d_part_ids, d_part_keys, parts, (uint32_t)nq, k, d_out_ids, d_out_keys, d_out_counts, st);
+    ucfp::launch_topk_merge_u32(d_part_ids, d_part_keys, parts, (uint32_t)nq, k, d_out_ids, d_out_keys, d_out_counts,
+                                nullptr, st);
     if (d_out_scores) {
         if (kind == UCFP_INDEX_HAMMING64) ucfp::launch_hamming_scores(d_out_keys, nq * k, d_out_scores, st);
         else ucfp::launch_cosine_scores_from_keys(d_out_keys, nq * k, d_out_scores, st);

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
                                                      uint32_t parts, uint32_t nq, uint32_t k,
                                                      uint64_t* __restrict__ out_ids,
                                                      uint32_t* __restrict__ out_key,
-                                                     uint32_t* __restrict__ out_cnt) {
+                                                     uint32_t* __restrict__ out_cnt,
+                                                     const uint32_t* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t total = parts * k;
@@ -197,10 +199,10 @@ int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, 
 
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,
                           uint32_t k, uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt,
-                          hipStream_t stream) {
+                          const uint32_t* run_flag, hipStream_t stream) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(topk_merge_u32, dim3(nq), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, out_ids,
-                       out_key, out_cnt);
+                       out_key, out_cnt, run_flag);
     return 0;
 }
 

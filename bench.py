@@ -120,16 +120,21 @@ def bench_ann(args, rank, world, dev, ctx):
         return None
     qps = nq * args.ann_steps / dt
     pairs_per_s = qps * args.ann_corpus
-    valu_peak = 256 * 128 * 2.4e9           # lane-ops/s: 256 CUs x 4 SIMD-32, 2.4 GHz (= 157.3 TF / 2)
+    # un-packed 32-bit VALU: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-op/s (the 157.3 TF
+    # datasheet figure counts packed FMA); tools/ubench_valu.hip measures 35-41 T on this chip
+    # (profiles/r01/ubench_valu.txt). The scan issues 73 VALU ops per 16 code-query pairs per lane.
+    valu_peak = 256 * 64 * 2.4e9
+    ops_per_pair = 73.0 / 16.0
     return {
         "metric": "ANN queries/sec (Hamming k=10, brute force, exact)", "value": qps, "unit": "queries/s",
         "corpus_total": args.ann_corpus, "corpus_per_gpu": n_local, "queries_per_batch": nq, "k": k,
         "ms_per_batch": dt / args.ann_steps * 1e3, "scaling": "strong",
         "exchange": "one all-gather of nq*k*(8+4) B per rank + merge on every rank" if world > 1 else "none",
         "pairs_per_s": pairs_per_s,
-        "roofline": {"bound": "valu", "achieved": pairs_per_s * 5 / world / 1e12, "peak": valu_peak / 1e12,
-                     "unit": "T lane-op/s per GPU (5 VALU ops per code-query pair)",
-                     "frac": pairs_per_s * 5 / world / valu_peak,
+        "roofline": {"bound": "valu", "achieved": pairs_per_s * ops_per_pair / world / 1e12,
+                     "peak": valu_peak / 1e12,
+                     "unit": "T lane-op/s per GPU (4.56 VALU ops per code-query pair: 2 xor, 2 bcnt, 0.56 min3/cmp)",
+                     "frac": pairs_per_s * ops_per_pair / world / valu_peak,
                      "hbm_GBs_per_gpu": (nq / 64) * n_local * 8 / (dt / args.ann_steps) / 1e9},
         "planted_neighbours_found": f"{planted_found}/{(nq + 1) // 2}",
     }

@@ -120,6 +120,37 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
 int ucfp_image_synth_dev(ucfp_ctx* ctx, uint8_t* frames, size_t n, uint32_t width,
                          uint32_t height, size_t first_index, void* stream);
 
+/* =============================== TEXT =========================================
+ * Replaces the arithmetic behind
+ *   text::fingerprint_minhash_with::<128>   src/modality/text.rs:182-236  (1032-B MinHashSig<128>)
+ *   text::fingerprint_simhash_tf / _idf     src/modality/text.rs:328-421  (8-B SimHash64)
+ *   text::fingerprint_lsh                   src/modality/text.rs:437-446  (same bytes as minhash)
+ * i.e. txtfp::MinHashFingerprinter / SimHashFingerprinter.  Documents are passed as one UTF-8
+ * blob plus n+1 byte offsets.
+ *   UCFP_TEXT_RAW_ASCII     the GPU canonicalises (ASCII lower-casing; NFKC / case fold / Cf+Bidi
+ *                           stripping are the identity on ASCII) and segments (UAX#29 restricted
+ *                           to ASCII).  A document holding a byte >= 0x80 gets status
+ *                           UCFP_TEXT_NEEDS_HOST: the host canonicalises + tokenises it
+ *                           (Unicode tables live there) and resubmits it as
+ *   UCFP_TEXT_PRETOKENIZED  tokens already canonical, separated by single spaces.
+ * status[i]: 0, UCFP_TEXT_NEEDS_HOST, UCFP_E_MODALITY (no tokens), UCFP_E_UNSUPPORTED (one token,
+ * or a run of fewer than k tokens, longer than the 4 KiB tile).
+ */
+#define UCFP_TEXT_RAW_ASCII 0
+#define UCFP_TEXT_PRETOKENIZED 1
+#define UCFP_TEXT_NEEDS_HOST 1
+#define UCFP_MINHASH_BYTES 1032 /* txtfp::MinHashSig<128>: u16 schema = 1, 6 pad, 128 x u64 LE */
+#define UCFP_SIMHASH_BYTES 8
+
+int ucfp_text_minhash_batch_dev(ucfp_ctx* ctx, const uint8_t* d_utf8, const uint64_t* d_offsets, size_t n,
+                                int mode, uint32_t shingle_k, uint8_t* d_out, int32_t* d_status, void* stream);
+int ucfp_text_minhash_batch(ucfp_ctx* ctx, const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode,
+                            uint32_t shingle_k, uint8_t* out, int32_t* status);
+int ucfp_text_simhash_batch_dev(ucfp_ctx* ctx, const uint8_t* d_utf8, const uint64_t* d_offsets, size_t n,
+                                int mode, uint8_t* d_out, int32_t* d_status, void* stream);
+int ucfp_text_simhash_batch(ucfp_ctx* ctx, const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode,
+                            uint8_t* out, int32_t* status);
+
 /* =============================== INDEX ========================================
  * Replaces `trait IndexBackend` kNN (src/index/mod.rs:29-35) as implemented by
  * EmbeddedBackend::knn (src/index/embedded/mod.rs:268-360): exact brute-force top-k inside

@@ -101,6 +101,58 @@ def hamming_topk(ids, codes, queries, k):
     return out_ids, out_d, out_c
 
 
+def xxh3_64(data: bytes) -> int:
+    f = lib().ucfp_oracle_xxh3_64
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_char_p, C.c_size_t]
+    return int(f(data, len(data)))
+
+
+def text_canon(text: bytes, mode: int = 0):
+    """Canonical token stream (tokens joined by one space). Returns (stream bytes, n_tokens);
+    n_tokens = -1 for non-ASCII input in raw mode."""
+    out = C.create_string_buffer(len(text) + 2)
+    olen = C.c_size_t(0)
+    f = lib().ucfp_oracle_text_canon
+    f.restype = C.c_long
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
+    nt = f(text, len(text), mode, out, C.byref(olen))
+    return out.raw[:olen.value], int(nt)
+
+
+def _pack_docs(docs):
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    for i, d in enumerate(docs):
+        offs[i + 1] = offs[i] + len(d)
+    blob = np.frombuffer(b"".join(docs) + b"\0", np.uint8).copy()
+    return blob, offs
+
+
+def text_minhash_batch(docs, mode: int = 0, k: int = 5):
+    """docs: list of bytes. Returns (records [n,1032] u8, status [n] i32)."""
+    blob, offs = _pack_docs(docs)
+    n = len(docs)
+    out = np.zeros((n, 1032), np.uint8)
+    st = np.zeros(n, np.int32)
+    f = lib().ucfp_oracle_text_minhash_batch
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    f(blob.ctypes.data, offs.ctypes.data, n, mode, k, out.ctypes.data, st.ctypes.data)
+    return out, st
+
+
+def text_simhash_batch(docs, mode: int = 0):
+    blob, offs = _pack_docs(docs)
+    n = len(docs)
+    out = np.zeros((n, 8), np.uint8)
+    st = np.zeros(n, np.int32)
+    f = lib().ucfp_oracle_text_simhash_batch
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    f(blob.ctypes.data, offs.ctypes.data, n, mode, out.ctypes.data, st.ctypes.data)
+    return out, st
+
+
 def num_threads() -> int:
     return int(lib().ucfp_oracle_num_threads())
 

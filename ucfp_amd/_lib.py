@@ -36,6 +36,14 @@ SIGNATURES = {
     "ucfp_image_hash_batch": (C.c_int, [
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
         C.c_size_t, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_text_minhash_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_text_minhash_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,
+                                          C.c_void_p, C.c_void_p]),
+    "ucfp_text_simhash_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_text_simhash_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                          C.c_void_p, C.c_void_p]),
     "ucfp_index_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ucfp_index_destroy": (None, [C.c_void_p]),
     "ucfp_index_upsert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),

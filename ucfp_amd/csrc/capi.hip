@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "../../include/ucfp_hip.h"
 #include "common.h"
@@ -201,6 +202,83 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
     if (status) HIP_TRY(hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return UCFP_OK;
+}
+
+// ---------------------------------- text ----------------------------------------------
+
+static int text_check(ucfp_ctx* ctx, const void* utf8, const void* offsets, size_t n, int mode, const void* out) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (mode != UCFP_TEXT_RAW_ASCII && mode != UCFP_TEXT_PRETOKENIZED)
+        return fail(UCFP_E_INVALID, "unknown text mode %d", mode);
+    if (n && (!offsets || !out)) return fail(UCFP_E_INVALID, "offsets/out is NULL");
+    if (n > 0x7fffffffu) return fail(UCFP_E_INVALID, "batch of %zu documents exceeds one launch", n);
+    (void)utf8;
+    return UCFP_OK;
+}
+
+int ucfp_text_minhash_batch_dev(ucfp_ctx* ctx, const uint8_t* d_utf8, const uint64_t* d_offsets, size_t n,
+                                int mode, uint32_t shingle_k, uint8_t* d_out, int32_t* d_status, void* stream) {
+    int rc = text_check(ctx, d_utf8, d_offsets, n, mode, d_out);
+    if (rc) return rc;
+    if (shingle_k == 0 || shingle_k > 64) return fail(UCFP_E_MODALITY, "shingle k must be in [1, 64] (got %u)", shingle_k);
+    ucfp::launch_text_minhash(d_utf8, d_offsets, n, mode, shingle_k, d_out, d_status, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UCFP_OK;
+}
+
+int ucfp_text_simhash_batch_dev(ucfp_ctx* ctx, const uint8_t* d_utf8, const uint64_t* d_offsets, size_t n,
+                                int mode, uint8_t* d_out, int32_t* d_status, void* stream) {
+    int rc = text_check(ctx, d_utf8, d_offsets, n, mode, d_out);
+    if (rc) return rc;
+    ucfp::launch_text_simhash(d_utf8, d_offsets, n, mode, d_out, d_status, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UCFP_OK;
+}
+
+static int text_host(ucfp_ctx* ctx, bool sim, const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode,
+                     uint32_t k, uint8_t* out, int32_t* status) {
+    int rc = text_check(ctx, utf8, offsets, n, mode, out);
+    if (rc) return rc;
+    if (n == 0) return UCFP_OK;
+    if (!sim && (k == 0 || k > 64)) return fail(UCFP_E_MODALITY, "shingle k must be in [1, 64] (got %u)", k);
+    const size_t base = offsets[0], total = offsets[n] - offsets[0];
+    for (size_t i = 0; i < n; i++)
+        if (offsets[i + 1] < offsets[i]) return fail(UCFP_E_INVALID, "offsets must be non-decreasing");
+    const size_t rec = sim ? UCFP_SIMHASH_BYTES : UCFP_MINHASH_BYTES;
+    const size_t o_off = (total + 16 + 255) & ~(size_t)255;
+    const size_t in_bytes = o_off + (n + 1) * 8;
+    const size_t o_st = (n * rec + 255) & ~(size_t)255;
+    const size_t out_bytes = o_st + n * 4;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = grow(&ctx->stage_in, &ctx->stage_in_cap, in_bytes);
+    if (rc) return rc;
+    rc = grow(&ctx->stage_out, &ctx->stage_out_cap, out_bytes);
+    if (rc) return rc;
+    hipStream_t st = ctx->host_stream;
+    std::vector<uint64_t> rel(n + 1);
+    for (size_t i = 0; i <= n; i++) rel[i] = offsets[i] - base;
+    if (total) HIP_TRY(hipMemcpyAsync(ctx->stage_in, utf8 + base, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->stage_in + o_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    const uint64_t* d_off = reinterpret_cast<const uint64_t*>(ctx->stage_in + o_off);
+    int32_t* d_st = reinterpret_cast<int32_t*>(ctx->stage_out + o_st);
+    if (sim) ucfp::launch_text_simhash(ctx->stage_in, d_off, n, mode, ctx->stage_out, d_st, st);
+    else ucfp::launch_text_minhash(ctx->stage_in, d_off, n, mode, k, ctx->stage_out, d_st, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, ctx->stage_out, n * rec, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d_st, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return UCFP_OK;
+}
+
+int ucfp_text_minhash_batch(ucfp_ctx* ctx, const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode,
+                            uint32_t shingle_k, uint8_t* out, int32_t* status) {
+    return text_host(ctx, false, utf8, offsets, n, mode, shingle_k, out, status);
+}
+
+int ucfp_text_simhash_batch(ucfp_ctx* ctx, const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode,
+                            uint8_t* out, int32_t* status) {
+    return text_host(ctx, true, utf8, offsets, n, mode, 1, out, status);
 }
 
 int ucfp_image_synth_dev(ucfp_ctx* ctx, uint8_t* frames, size_t n, uint32_t width, uint32_t height,

@@ -60,4 +60,10 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
                        const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream);
 int launch_cosine_scores_from_keys(const uint32_t* keys, size_t total, float* scores, hipStream_t stream);
 
+// text.hip
+int launch_text_minhash(const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode, uint32_t k,
+                        uint8_t* out, int32_t* status, hipStream_t stream);
+int launch_text_simhash(const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode, uint8_t* out,
+                        int32_t* status, hipStream_t stream);
+
 }  // namespace ucfp

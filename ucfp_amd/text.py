@@ -1,0 +1,220 @@
+"""Text fingerprinting -- host-side mirror of src/modality/text.rs.
+
+    fingerprint_minhash(text, tenant_id, record_id)                 text.rs:172-174
+    fingerprint_minhash_with(text, opts, tenant_id, record_id)      text.rs:182-236  (H = 128)
+    fingerprint_simhash_tf / fingerprint_simhash_idf                text.rs:328-362
+    fingerprint_lsh                                                 text.rs:437-446
+
+plus the batched form (`minhash_batch` / `simhash_batch`).  Hashing runs in the HIP library.
+ASCII documents go to the GPU raw (it lower-cases and segments them); a document with non-ASCII
+characters is canonicalised (NFKC + case fold + Bidi/Cf stripping, text.rs:112-114) and segmented
+(UAX#29 via the `regex` module) here on the host, then submitted pre-tokenised -- Unicode tables are
+host business (SURVEY "hard parts").
+"""
+import ctypes as C
+import unicodedata
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .core import Modality, Record
+from .errors import ModalityError, UnsupportedError
+
+DEFAULT_K = 5        # text.rs:39
+DEFAULT_H = 128      # text.rs:41
+ALGORITHM_MINHASH_128 = "minhash-h128"
+ALGORITHM_SIMHASH_TF = "simhash-b64-tf"
+ALGORITHM_SIMHASH_IDF = "simhash-b64-idf"
+ALGORITHM_LSH = "minhash-lsh-h128"
+FORMAT_VERSION = 1   # txtfp::FORMAT_VERSION as stored by text.rs:227
+
+RAW_ASCII, PRETOKENIZED = 0, 1
+NEEDS_HOST = 1
+MINHASH_BYTES, SIMHASH_BYTES = 1032, 8
+
+# The only config_hash the reference pins (src/server/tests.rs:1158-1161): default canonicalizer,
+# "shingle-k=5/word-uax29", "minhash-h128".  txtfp::config_hash itself is not available offline.
+_PINNED_CONFIG_HASH = {("nfkc", True, True, True, "shingle-k=5/word-uax29", ALGORITHM_MINHASH_128):
+                       2_212_816_233_060_047_056}
+
+
+@dataclass
+class Canonicalizer:
+    """txtfp::Canonicalizer knobs as exposed by handlers.rs:547-586."""
+    normalization: str = "nfkc"     # nfc | nfkc | none
+    case_fold: bool = True
+    strip_bidi: bool = True
+    strip_format: bool = True
+
+    def apply(self, s: str) -> str:
+        if self.normalization == "nfkc":
+            s = unicodedata.normalize("NFKC", s)
+        elif self.normalization == "nfc":
+            s = unicodedata.normalize("NFC", s)
+        if self.case_fold:
+            s = s.casefold()
+            if self.normalization in ("nfkc", "nfc"):
+                s = unicodedata.normalize(self.normalization.upper(), s)
+        if self.strip_bidi or self.strip_format:
+            s = "".join(ch for ch in s if unicodedata.category(ch) != "Cf")
+        return s
+
+    def is_default(self) -> bool:
+        return self == Canonicalizer()
+
+
+@dataclass
+class TextOpts:
+    """text.rs:116-147."""
+    canonicalizer: Canonicalizer = field(default_factory=Canonicalizer)
+    tokenizer: str = "word"          # word | grapheme | cjk-jp | cjk-ko (text.rs:71-82)
+    k: int = DEFAULT_K
+    h: int = DEFAULT_H
+    preprocess: Optional[str] = None  # html | markdown | pdf: not on the hot path
+
+    def tokenizer_tag(self) -> str:   # text.rs:152-159
+        return {"word": f"shingle-k={self.k}/word-uax29", "grapheme": f"shingle-k={self.k}/grapheme-uax29",
+                "cjk-jp": f"shingle-k={self.k}/cjk-jp", "cjk-ko": f"shingle-k={self.k}/cjk-ko"}[self.tokenizer]
+
+
+def config_hash(canon: Canonicalizer, tokenizer_tag: str, algorithm: str) -> int:
+    """txtfp::config_hash stand-in: the reference's pinned value for the default configuration,
+    otherwise XXH3-free FNV-1a of a canonical description (documented as NOT txtfp's value)."""
+    key = (canon.normalization, canon.case_fold, canon.strip_bidi, canon.strip_format, tokenizer_tag, algorithm)
+    if key in _PINNED_CONFIG_HASH:
+        return _PINNED_CONFIG_HASH[key]
+    h = 0xCBF29CE484222325
+    for b in repr(key).encode():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _host_tokens(s: str) -> List[str]:
+    import regex  # UAX#29 default word boundaries
+    return [t for t in regex.split(r"(?w)\b", s, flags=regex.V1) if any(ch.isalnum() for ch in t)]
+
+
+def _prepare(text: str, opts: TextOpts) -> Tuple[bytes, int]:
+    """-> (bytes for the GPU, mode)."""
+    if opts.tokenizer != "word":
+        raise UnsupportedError(f"tokenizer `{opts.tokenizer}` is not built into the HIP path")
+    c = opts.canonicalizer
+    if text.isascii() and c.case_fold:
+        return text.encode("ascii"), RAW_ASCII
+    toks = _host_tokens(c.apply(text))
+    return " ".join(toks).encode("utf-8"), PRETOKENIZED
+
+
+def _pack(docs: Sequence[bytes]):
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    np.cumsum([len(d) for d in docs], out=offs[1:])
+    blob = np.frombuffer(b"".join(docs) + b"\0" * 16, np.uint8)
+    return blob, offs
+
+
+def _run(kind: str, docs: Sequence[bytes], mode: int, k: int, ctx=None):
+    ctx = ctx or _lib.default_context()
+    lib = _lib.load()
+    blob, offs = _pack(docs)
+    n = len(docs)
+    rec = SIMHASH_BYTES if kind == "simhash" else MINHASH_BYTES
+    out = np.zeros((n, rec), np.uint8)
+    status = np.zeros(n, np.int32)
+    if kind == "simhash":
+        _lib.check(lib.ucfp_text_simhash_batch(ctx.handle, blob.ctypes.data, offs.ctypes.data, n, mode,
+                                               out.ctypes.data, status.ctypes.data))
+    else:
+        _lib.check(lib.ucfp_text_minhash_batch(ctx.handle, blob.ctypes.data, offs.ctypes.data, n, mode, k,
+                                               out.ctypes.data, status.ctypes.data))
+    return out, status
+
+
+def _batch(kind: str, texts: Sequence[str], opts: TextOpts, ctx=None):
+    """Split into the raw-ASCII and the host-pretokenised group, one launch each."""
+    prepared = [_prepare(t, opts) for t in texts]
+    rec = SIMHASH_BYTES if kind == "simhash" else MINHASH_BYTES
+    out = np.zeros((len(texts), rec), np.uint8)
+    status = np.zeros(len(texts), np.int32)
+    for mode in (RAW_ASCII, PRETOKENIZED):
+        idx = [i for i, (_, m) in enumerate(prepared) if m == mode]
+        if not idx:
+            continue
+        o, s = _run(kind, [prepared[i][0] for i in idx], mode, opts.k, ctx)
+        out[idx] = o
+        status[idx] = s
+    return out, status
+
+
+def minhash_batch(texts: Sequence[str], opts: Optional[TextOpts] = None, ctx=None):
+    """-> (records uint8 [n, 1032], status int32 [n])."""
+    return _batch("minhash", texts, opts or TextOpts(), ctx)
+
+
+def simhash_batch(texts: Sequence[str], opts: Optional[TextOpts] = None, ctx=None):
+    return _batch("simhash", texts, opts or TextOpts(), ctx)
+
+
+def _raise_for(status: int):
+    if status == -1:
+        raise ModalityError("text has no tokens after canonicalisation")
+    if status == -2:
+        raise UnsupportedError("a token (or a run of fewer than k tokens) exceeds the 4 KiB tile")
+    if status != 0:
+        raise ModalityError(f"text fingerprint failed with status {status}")
+
+
+def fingerprint_minhash(text: str, tenant_id: int, record_id: int) -> Record:
+    return fingerprint_minhash_with(text, TextOpts(), tenant_id, record_id)
+
+
+def fingerprint_minhash_with(text: str, opts: TextOpts, tenant_id: int, record_id: int) -> Record:
+    if opts.h != DEFAULT_H:
+        raise UnsupportedError("only H = 128 is built (the reference's public entry point, text.rs:172-174)")
+    recs, status = minhash_batch([text], opts)
+    _raise_for(int(status[0]))
+    return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Text, format_version=FORMAT_VERSION,
+                  algorithm=ALGORITHM_MINHASH_128,
+                  config_hash=config_hash(opts.canonicalizer, opts.tokenizer_tag(), ALGORITHM_MINHASH_128),
+                  fingerprint=recs[0].tobytes(), embedding=None, model_id=None, metadata=b"", text=text)
+
+
+def _simhash(text: str, opts: TextOpts, tag: str, tenant_id: int, record_id: int) -> Record:
+    recs, status = simhash_batch([text], opts)
+    _raise_for(int(status[0]))
+    tok_tag = {"word": "word-uax29", "grapheme": "grapheme-uax29", "cjk-jp": "cjk-jp", "cjk-ko": "cjk-ko"}[opts.tokenizer]
+    return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Text, format_version=FORMAT_VERSION,
+                  algorithm=tag, config_hash=config_hash(opts.canonicalizer, tok_tag, tag),
+                  fingerprint=recs[0].tobytes(), embedding=None, model_id=None, metadata=b"", text=text)
+
+
+def fingerprint_simhash_tf(text: str, opts: TextOpts, tenant_id: int, record_id: int) -> Record:
+    return _simhash(text, opts, ALGORITHM_SIMHASH_TF, tenant_id, record_id)
+
+
+def fingerprint_simhash_idf(text: str, opts: TextOpts, idf, tenant_id: int, record_id: int) -> Record:
+    """The server always passes IdfTable::default() (handlers.rs:410): an empty table weights every
+    token 1.0, i.e. TF weighting; a non-empty table is not supported on the HIP path."""
+    if idf:
+        raise UnsupportedError("non-empty IdfTable is not built into the HIP path")
+    return _simhash(text, opts, ALGORITHM_SIMHASH_IDF, tenant_id, record_id)
+
+
+def fingerprint_lsh(text: str, opts: TextOpts, tenant_id: int, record_id: int) -> Record:
+    rec = fingerprint_minhash_with(text, opts, tenant_id, record_id)
+    rec.algorithm = ALGORITHM_LSH
+    return rec
+
+
+def lsh_band_keys(record: bytes, bands: int = 16, rows: int = 8) -> List[int]:
+    """Band keys over the 128 slots (the reference has no band index; 16 x 8 uses
+    every slot).  Key = FNV-1a over the band's slot bytes."""
+    assert bands * rows <= 128 and len(record) == MINHASH_BYTES
+    keys = []
+    for b in range(bands):
+        h = 0xCBF29CE484222325
+        for byte in record[8 + 8 * rows * b: 8 + 8 * rows * (b + 1)]:
+            h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        keys.append(h)
+    return keys

@@ -120,6 +120,53 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
 int ucfp_image_synth_dev(ucfp_ctx* ctx, uint8_t* frames, size_t n, uint32_t width,
                          uint32_t height, size_t first_index, void* stream);
 
+/* =============================== AUDIO ========================================
+ * Replaces the arithmetic behind
+ *   audio::fingerprint_wang_with      src/modality/audio.rs:64-98    ([WangHash], 8 B each)
+ *   audio::fingerprint_haitsma_with   src/modality/audio.rs:181-224  (u32 per frame)
+ * i.e. audiofp::classical::{Wang, Haitsma}::extract and audiofp::dsp::resample::linear.
+ * Input: mono f32 PCM.  Wang requires 8 kHz (audio.rs:422-430) -- other rates are rejected with
+ * UCFP_E_MODALITY; resample upstream (ucfp_audio_resample_linear*).  Haitsma resamples to 5 kHz
+ * itself, like the reference (audio.rs:194-200).
+ */
+typedef struct ucfp_wang_config { /* audiofp WangConfig; defaults algorithms_manifest.rs:553-592 */
+    uint32_t fan_out;          /* 10  */
+    uint32_t target_zone_t;    /* 63 frames */
+    uint32_t target_zone_f;    /* 64 bins   */
+    uint32_t peaks_per_sec;    /* 30  */
+    float min_anchor_mag_db;   /* -50 (dB re full-scale sine) */
+} ucfp_wang_config;
+
+typedef struct ucfp_haitsma_config { /* audiofp HaitsmaConfig; defaults manifest :655-672 */
+    float fmin; /* 300  */
+    float fmax; /* 2000 */
+} ucfp_haitsma_config;
+
+#define UCFP_WANG_HASH_BYTES 8 /* u32 LE f_a(9)|f_b(9)|dt(14), u32 LE t_anchor (LandmarkScatter.svelte:4) */
+
+/* Upper bound on the hashes n samples can produce (for sizing `out`). */
+size_t ucfp_audio_wang_max_hashes(size_t n_samples, const ucfp_wang_config* cfg);
+/* Host buffers; *n_hashes receives the number produced (if it exceeds cap_hashes the output is
+ * truncated and UCFP_E_INVALID is returned). cfg NULL = defaults. */
+int ucfp_audio_wang(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate, const ucfp_wang_config* cfg,
+                    uint8_t* out, size_t cap_hashes, size_t* n_hashes);
+/* Device buffers; d_n_hashes is a device u64 (total produced, may exceed cap). No sync. */
+int ucfp_audio_wang_dev(ucfp_ctx* ctx, const float* d_pcm, size_t n, uint32_t sample_rate,
+                        const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes, uint64_t* d_n_hashes,
+                        void* stream);
+
+size_t ucfp_audio_haitsma_frames(size_t n_samples, uint32_t sample_rate);
+int ucfp_audio_haitsma(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate,
+                       const ucfp_haitsma_config* cfg, uint32_t* out, size_t cap_frames, size_t* n_frames);
+/* Device buffers; the input must already be at 5 kHz (use ucfp_audio_resample_linear_dev). */
+int ucfp_audio_haitsma_dev(ucfp_ctx* ctx, const float* d_pcm5k, size_t n, const ucfp_haitsma_config* cfg,
+                           uint32_t* d_out, size_t cap_frames, void* stream);
+
+/* audiofp::dsp::resample::linear. Output length = floor(n * sr_out / sr_in). */
+size_t ucfp_audio_resample_len(size_t n, uint32_t sr_in, uint32_t sr_out);
+int ucfp_audio_resample_linear_dev(ucfp_ctx* ctx, const float* d_in, size_t n, uint32_t sr_in, uint32_t sr_out,
+                                   float* d_out, size_t cap, void* stream);
+
 /* =============================== TEXT =========================================
  * Replaces the arithmetic behind
  *   text::fingerprint_minhash_with::<128>   src/modality/text.rs:182-236  (1032-B MinHashSig<128>)

@@ -153,6 +153,86 @@ def text_simhash_batch(docs, mode: int = 0):
     return out, st
 
 
+class WangCfg(C.Structure):
+    """audiofp::classical::WangConfig; defaults src/server/algorithms_manifest.rs:553-592."""
+    _fields_ = [("fan_out", C.c_uint32), ("target_zone_t", C.c_uint32), ("target_zone_f", C.c_uint32),
+                ("peaks_per_sec", C.c_uint32), ("min_anchor_mag_db", C.c_float)]
+
+    @classmethod
+    def default(cls):
+        return cls(10, 63, 64, 30, -50.0)
+
+
+def resample_linear(x, sr_in: int, sr_out: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    l = lib()
+    l.ucfp_oracle_resample_len.restype = C.c_size_t
+    l.ucfp_oracle_resample_len.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32]
+    m = l.ucfp_oracle_resample_len(x.size, sr_in, sr_out)
+    out = np.zeros(m, np.float32)
+    l.ucfp_oracle_resample_linear.restype = None
+    l.ucfp_oracle_resample_linear.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
+    if m:
+        l.ucfp_oracle_resample_linear(x.ctypes.data, x.size, sr_in, sr_out, out.ctypes.data)
+    return out
+
+
+def stft_power(x, n_fft: int, hop: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    T = 1 + (x.size - n_fft) // hop if x.size >= n_fft else 0
+    P = np.zeros((T, n_fft // 2), np.float32)
+    f = lib().ucfp_oracle_stft_power
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    if T:
+        f(x.ctypes.data, x.size, n_fft, hop, P.ctypes.data)
+    return P
+
+
+def wang_peaks(P, peaks_per_sec: int = 30):
+    P = np.ascontiguousarray(P, dtype=np.float32)
+    T = P.shape[0]
+    f = lib().ucfp_oracle_wang_peaks
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = f(P.ctypes.data, T, peaks_per_sec, None, None, None)
+    t = np.zeros(n, np.uint32)
+    k = np.zeros(n, np.uint32)
+    p = np.zeros(n, np.float32)
+    if n:
+        f(P.ctypes.data, T, peaks_per_sec, t.ctypes.data, k.ctypes.data, p.ctypes.data)
+    return t, k, p
+
+
+def wang(x, cfg=None, cap: int = 0) -> np.ndarray:
+    """8 kHz mono f32 -> WangHash array [n, 2] u32 (hash, t_anchor)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    cfg = cfg or WangCfg.default()
+    cap = cap or max(64, (x.size // 8000 + 2) * cfg.peaks_per_sec * cfg.fan_out)
+    out = np.zeros((cap, 2), np.uint32)
+    f = lib().ucfp_oracle_wang
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(WangCfg), C.c_void_p, C.c_size_t]
+    n = f(x.ctypes.data, x.size, C.byref(cfg), out.ctypes.data, cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def haitsma(x, sample_rate: int, fmin: float = 300.0, fmax: float = 2000.0) -> np.ndarray:
+    """mono f32 at any rate (linear resample to 5 kHz like src/modality/audio.rs:194-200) -> u32 frames."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if sample_rate != 5000:
+        x = resample_linear(x, sample_rate, 5000)
+    T = 1 + (x.size - 2048) // 64 if x.size >= 2048 else 0
+    out = np.zeros(T, np.uint32)
+    f = lib().ucfp_oracle_haitsma_5k
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]
+    if T:
+        f(x.ctypes.data, x.size, fmin, fmax, out.ctypes.data)
+    return out
+
+
 def num_threads() -> int:
     return int(lib().ucfp_oracle_num_threads())
 

@@ -16,6 +16,17 @@ _lib = None
 _lock = threading.Lock()
 
 
+class WangConfig(C.Structure):
+    """ucfp_wang_config (audiofp WangConfig; defaults src/server/algorithms_manifest.rs:553-592)."""
+    _fields_ = [("fan_out", C.c_uint32), ("target_zone_t", C.c_uint32), ("target_zone_f", C.c_uint32),
+                ("peaks_per_sec", C.c_uint32), ("min_anchor_mag_db", C.c_float)]
+
+
+class HaitsmaConfig(C.Structure):
+    """ucfp_haitsma_config (defaults manifest :655-672)."""
+    _fields_ = [("fmin", C.c_float), ("fmax", C.c_float)]
+
+
 class ImagePreprocess(C.Structure):
     """ucfp_image_preprocess (imgfprint::PreprocessConfig guards)."""
     _fields_ = [("max_dimension", C.c_uint32), ("min_dimension", C.c_uint32)]
@@ -36,6 +47,19 @@ SIGNATURES = {
     "ucfp_image_hash_batch": (C.c_int, [
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
         C.c_size_t, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_audio_wang_max_hashes": (C.c_size_t, [C.c_size_t, C.POINTER(WangConfig)]),
+    "ucfp_audio_wang": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(WangConfig), C.c_void_p,
+                                  C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ucfp_audio_wang_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(WangConfig),
+                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ucfp_audio_haitsma_frames": (C.c_size_t, [C.c_size_t, C.c_uint32]),
+    "ucfp_audio_haitsma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(HaitsmaConfig),
+                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ucfp_audio_haitsma_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(HaitsmaConfig), C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
+    "ucfp_audio_resample_len": (C.c_size_t, [C.c_size_t, C.c_uint32, C.c_uint32]),
+    "ucfp_audio_resample_linear_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
+                                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_text_minhash_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_text_minhash_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,

@@ -1,0 +1,130 @@
+"""Audio fingerprinting -- host-side mirror of src/modality/audio.rs.
+
+    fingerprint_wang(samples, sample_rate, tenant_id, record_id)              audio.rs:46-60
+    fingerprint_wang_with(samples, sample_rate, cfg, tenant_id, record_id)    audio.rs:64-98
+    fingerprint_haitsma / fingerprint_haitsma_with                            audio.rs:164-224
+    StreamingWangSession(sample_rate, tenant_id, record_id).push/.finalize    audio.rs:414-480
+
+All DSP runs in the HIP library through the C ABI (ucfp_audio_*); this module validates arguments
+the way the reference does and wraps bytes into `Record`s.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from .core import Modality, Record
+from .errors import ModalityError
+
+ALGORITHM_WANG = "audiofp-wang-v1"
+ALGORITHM_HAITSMA = "audiofp-haitsma-v1"
+WANG_SR, HAITSMA_SR = 8000, 5000
+
+
+@dataclass
+class WangConfig:
+    """audiofp::classical::WangConfig; defaults src/server/algorithms_manifest.rs:553-592."""
+    fan_out: int = 10
+    target_zone_t: int = 63
+    target_zone_f: int = 64
+    peaks_per_sec: int = 30
+    min_anchor_mag_db: float = -50.0
+
+    def _c(self):
+        return _lib.WangConfig(self.fan_out, self.target_zone_t, self.target_zone_f, self.peaks_per_sec,
+                               self.min_anchor_mag_db)
+
+
+@dataclass
+class HaitsmaConfig:
+    """audiofp::classical::HaitsmaConfig; defaults manifest :655-672."""
+    fmin: float = 300.0
+    fmax: float = 2000.0
+
+    def _c(self):
+        return _lib.HaitsmaConfig(self.fmin, self.fmax)
+
+
+def _check_rate(sample_rate: int):
+    if not (0 < int(sample_rate) <= 384_000):
+        raise ModalityError(f"invalid sample rate {sample_rate}")   # audio.rs:74-75
+
+
+def wang_hashes(samples, sample_rate: int, cfg: Optional[WangConfig] = None, ctx=None) -> np.ndarray:
+    """-> uint32 [n, 2]: (packed hash, t_anchor) -- the byte image of audiofp's [WangHash]."""
+    ctx = ctx or _lib.default_context()
+    _check_rate(sample_rate)
+    x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    c = (cfg or WangConfig())._c()
+    lib = _lib.load()
+    cap = max(1, int(lib.ucfp_audio_wang_max_hashes(x.size, C.byref(c))))
+    out = np.zeros((cap, 2), np.uint32)
+    n = C.c_size_t(0)
+    _lib.check(lib.ucfp_audio_wang(ctx.handle, x.ctypes.data, x.size, sample_rate, C.byref(c), out.ctypes.data,
+                                   cap, C.byref(n)))
+    return out[: n.value].copy()
+
+
+def haitsma_frames(samples, sample_rate: int, cfg: Optional[HaitsmaConfig] = None, ctx=None) -> np.ndarray:
+    ctx = ctx or _lib.default_context()
+    _check_rate(sample_rate)
+    x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    c = (cfg or HaitsmaConfig())._c()
+    lib = _lib.load()
+    cap = max(1, int(lib.ucfp_audio_haitsma_frames(x.size, sample_rate)))
+    out = np.zeros(cap, np.uint32)
+    n = C.c_size_t(0)
+    _lib.check(lib.ucfp_audio_haitsma(ctx.handle, x.ctypes.data, x.size, sample_rate, C.byref(c), out.ctypes.data,
+                                      cap, C.byref(n)))
+    return out[: n.value].copy()
+
+
+def _record(algo: str, payload: bytes, tenant_id: int, record_id: int) -> Record:
+    # format_version 1, config_hash 0: audio.rs:89-91
+    return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Audio, format_version=1,
+                  algorithm=algo, config_hash=0, fingerprint=payload, embedding=None, model_id=None, metadata=b"",
+                  text=None)
+
+
+def fingerprint_wang(samples, sample_rate: int, tenant_id: int, record_id: int) -> Record:
+    return fingerprint_wang_with(samples, sample_rate, WangConfig(), tenant_id, record_id)
+
+
+def fingerprint_wang_with(samples, sample_rate: int, cfg: WangConfig, tenant_id: int, record_id: int) -> Record:
+    return _record(ALGORITHM_WANG, wang_hashes(samples, sample_rate, cfg).tobytes(), tenant_id, record_id)
+
+
+def fingerprint_haitsma(samples, sample_rate: int, tenant_id: int, record_id: int) -> Record:
+    return fingerprint_haitsma_with(samples, sample_rate, HaitsmaConfig(), tenant_id, record_id)
+
+
+def fingerprint_haitsma_with(samples, sample_rate: int, cfg: HaitsmaConfig, tenant_id: int, record_id: int) -> Record:
+    return _record(ALGORITHM_HAITSMA, haitsma_frames(samples, sample_rate, cfg).tobytes(), tenant_id, record_id)
+
+
+class StreamingWangSession:
+    """Push/finalize wrapper (audio.rs:414-480). Hashes are a function of the whole signal (per-second
+    peak caps, forward target zones), so the session buffers PCM and emits at `finalize`; `push`
+    returns no records -- allowed by the reference contract ("typically zero or one")."""
+
+    def __init__(self, sample_rate: int, tenant_id: int, record_id: int):
+        if sample_rate != WANG_SR:
+            raise ModalityError(f"Wang requires 8 kHz mono input (got {sample_rate} Hz); resample upstream")
+        self._chunks: List[np.ndarray] = []
+        self.tenant_id, self.record_id = tenant_id, record_id
+
+    def push(self, samples) -> List[Record]:
+        self._chunks.append(np.asarray(samples, dtype=np.float32).reshape(-1))
+        return []
+
+    def finalize(self) -> List[Record]:
+        if not self._chunks:
+            return []
+        x = np.concatenate(self._chunks)
+        self._chunks = []
+        h = wang_hashes(x, WANG_SR)
+        if h.shape[0] == 0:
+            return []
+        return [_record(ALGORITHM_WANG, h.tobytes(), self.tenant_id, self.record_id)]

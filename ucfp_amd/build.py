@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libucfp_hip.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def sources():

@@ -1,0 +1,464 @@
+// audio.hip -- Wang landmark hashes and Haitsma-Kalker sub-fingerprints for gfx950.
+//
+// Replaces the arithmetic behind audio::fingerprint_wang_with (src/modality/audio.rs:64-98) and
+// audio::fingerprint_haitsma_with (audio.rs:181-224), i.e. audiofp's Wang::extract /
+// Haitsma::extract / dsp::resample::linear.  Spec: DESIGN.md "Audio spec" A1..A8; CPU statement:
+// oracle/ (audio).  Every float step is one IEEE f32 operation in the order the oracle uses (the
+// library is built with -ffp-contract=off), so the integer outputs are bit-identical.
+//
+//   resample_linear   A1   one thread per output sample
+//   stft_power<N>     A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT held in
+//                          LDS (8/16 KiB per wave, twiddles in LDS), butterflies of a stage are
+//                          independent so the wave runs them 64 at a time with no block barrier;
+//                          Wang: power spectrum to HBM; Haitsma: 33 band energies per frame
+//   wang_rowmax/cand  A5   separable neighbourhood maximum, then the exact tie rule only on the
+//                          (rare) cells that equal their window maximum
+//   wang_select       A5   one wave per second of audio: rank by strength, keep peaks_per_sec,
+//                          order by (t, k)
+//   wang_pair_*       A6   one thread per anchor walks the time-sorted peaks (audio.rs:965-1003)
+//   haitsma_bits      A8   sign of the time/frequency double difference
+// Long inputs are processed in chunks of frames so the spilled spectrogram stays bounded.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ucfp_fft_tw.h"
+#include "common.h"
+
+namespace ucfp {
+
+namespace {
+
+__constant__ float c_tw[1024][2] = UCFP_FFT_TW_INIT;
+
+constexpr int kWangN = 1024, kWangHop = 128, kWangBins = 512, kRT = 7, kRK = 15, kWangSr = 8000;
+constexpr int kHkN = 2048, kHkHop = 64, kHkBands = 33;
+constexpr int kCandCap = 320;   // > (63/8 + 1) * (512/16) possible peaks per second
+
+// ---- A1 ----------------------------------------------------------------------------------
+__global__ void resample_linear_kernel(const float* __restrict__ in, size_t n, uint32_t sr_in, uint32_t sr_out,
+                                       float* __restrict__ out, size_t m) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t num = (uint64_t)i * sr_in;  // < 2^64 for any buffer that fits in memory
+    const size_t idx = (size_t)(num / sr_out);
+    const uint32_t rem = (uint32_t)(num % sr_out);
+    const float frac = (float)((double)rem / (double)sr_out);
+    const float x0 = in[idx], x1 = in[idx + 1 < n ? idx + 1 : n - 1];
+    const float d = x1 - x0;
+    const float mm = d * frac;
+    out[i] = x0 + mm;
+}
+
+// ---- A2/A3: one wave per frame ---------------------------------------------------------------
+template <int N>
+struct FftLds {
+    float tw[1024][2];
+    float re[4][N];
+    float im[4][N];
+    float band[4][64];
+};
+
+template <int N, bool HAITSMA>
+__global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict__ x, size_t first_frame,
+                                                         size_t n_frames, int hop, float* __restrict__ out,
+                                                         const uint32_t* __restrict__ edges) {
+    constexpr int BITS = N == 1024 ? 10 : 11;
+    constexpr int TWS = 2048 / N;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    FftLds<N>& L = *reinterpret_cast<FftLds<N>*>(lds_raw);
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        L.tw[i][0] = c_tw[i][0];
+        L.tw[i][1] = c_tw[i][1];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* re = L.re[wave];
+    float* im = L.im[wave];
+    // frames are dealt to waves round-robin over the whole grid
+    for (size_t f = (size_t)blockIdx.x * 4 + wave; f < n_frames; f += (size_t)gridDim.x * 4) {
+        const float* src = x + (first_frame + f) * (size_t)hop;
+#pragma unroll 4
+        for (int n = lane; n < N; n += 64) {
+            float c = L.tw[(n * TWS) & 1023][0];
+            if (n * TWS >= 1024) c = -c;
+            const float w = 0.5f - 0.5f * c;
+            const uint32_t r = __brev((uint32_t)n) >> (32 - BITS);
+            re[r] = src[n] * w;
+            im[r] = 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int s = 1; s <= BITS; s++) {
+            const int half = 1 << (s - 1), tstep = 2048 >> s;
+#pragma unroll 4
+            for (int bf = lane; bf < N / 2; bf += 64) {
+                const int j = bf & (half - 1);
+                const int i0 = ((bf >> (s - 1)) << s) + j, i1 = i0 + half;
+                const float c = L.tw[j * tstep][0], sn = L.tw[j * tstep][1];
+                const float xr = re[i1], xi = im[i1];
+                const float t1 = xr * c, t2 = xi * sn, t3 = xr * sn, t4 = xi * c;
+                const float vr = t1 - t2, vi = t3 + t4;
+                const float ur = re[i0], ui = im[i0];
+                re[i0] = ur + vr;
+                im[i0] = ui + vi;
+                re[i1] = ur - vr;
+                im[i1] = ui - vi;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!HAITSMA) {
+            float* o = out + f * (size_t)(N / 2);
+#pragma unroll 4
+            for (int k = lane; k < N / 2; k += 64) {
+                const float a = re[k] * re[k], b = im[k] * im[k];
+                o[k] = a + b;
+            }
+        } else {
+            // power into re[] (in place), then lane b sums band b sequentially (same order as the oracle)
+#pragma unroll 4
+            for (int k = lane; k < N / 2; k += 64) {
+                const float a = re[k] * re[k], b = im[k] * im[k];
+                re[k] = a + b;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kHkBands) {
+                float e = 0.0f;
+                for (uint32_t k = edges[lane]; k < edges[lane + 1]; k++) e = e + re[k];
+                out[f * (size_t)kHkBands + lane] = e;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- A5: peaks ---------------------------------------------------------------------------------
+// P / rowmax hold frames [w0, w0 + wn) of the spectrogram (window incl. halo), row-major 512 bins.
+__global__ void wang_rowmax_kernel(const float* __restrict__ P, size_t wn, float* __restrict__ rowmax) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= wn * kWangBins) return;
+    const int k = (int)(i & (kWangBins - 1));
+    const float* row = P + (i - k);
+    const int k0 = k - kRK < 0 ? 0 : k - kRK, k1 = k + kRK > kWangBins - 1 ? kWangBins - 1 : k + kRK;
+    float m = row[k0];
+    for (int kk = k0 + 1; kk <= k1; kk++) m = fmaxf(m, row[kk]);
+    rowmax[i] = m;
+}
+
+// Emit candidates for frames [e0, e1) (absolute); the window buffer starts at absolute frame w0.
+__global__ void wang_cand_kernel(const float* __restrict__ P, const float* __restrict__ rowmax, size_t w0,
+                                 size_t wn, size_t e0, size_t e1, size_t total_frames,
+                                 uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ cand_t,
+                                 uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t ne = e1 - e0;
+    if (i >= ne * kWangBins) return;
+    const int k = (int)(i & (kWangBins - 1));
+    const size_t t = e0 + (i >> 9);           // absolute frame
+    const size_t lt = t - w0;                 // row inside the window buffer
+    const float v = P[lt * kWangBins + k];
+    if (!(v > 0.0f)) return;
+    const long t0 = (long)t - kRT < 0 ? 0 : (long)t - kRT;
+    const long t1 = t + kRT >= total_frames ? (long)total_frames - 1 : (long)t + kRT;
+    float m = rowmax[((size_t)t0 - w0) * kWangBins + k];
+    for (long tt = t0 + 1; tt <= t1; tt++) m = fmaxf(m, rowmax[((size_t)tt - w0) * kWangBins + k]);
+    if (v != m) return;
+    // v is a window maximum; an equal value earlier in (t, k) order wins the tie
+    const int k0 = k - kRK < 0 ? 0 : k - kRK, k1 = k + kRK > kWangBins - 1 ? kWangBins - 1 : k + kRK;
+    for (long tt = t0; tt <= (long)t; tt++) {
+        const float* row = P + ((size_t)tt - w0) * kWangBins;
+        const int kend = tt == (long)t ? k - 1 : k1;
+        for (int kk = k0; kk <= kend; kk++)
+            if (row[kk] == v) return;
+    }
+    (void)wn;
+    const uint32_t sec = (uint32_t)((t * kWangHop) / kWangSr);
+    const uint32_t pos = atomicAdd(&cand_cnt[sec], 1u);
+    if (pos < (uint32_t)kCandCap) {
+        cand_t[(size_t)sec * kCandCap + pos] = (uint32_t)t;
+        cand_k[(size_t)sec * kCandCap + pos] = (uint32_t)k;
+        cand_p[(size_t)sec * kCandCap + pos] = v;
+    }
+}
+
+// one wave per second: keep the `pps` strongest, ordered by (t, k)
+__global__ __launch_bounds__(64) void wang_select_kernel(const uint32_t* __restrict__ cand_cnt,
+                                                         const uint32_t* __restrict__ cand_t,
+                                                         const uint32_t* __restrict__ cand_k,
+                                                         const float* __restrict__ cand_p, uint32_t pps,
+                                                         uint32_t* __restrict__ sel_cnt, uint32_t* __restrict__ sel_t,
+                                                         uint32_t* __restrict__ sel_k, float* __restrict__ sel_p) {
+    __shared__ uint32_t st[kCandCap], sk[kCandCap];
+    __shared__ float sp[kCandCap];
+    __shared__ uint8_t keep[kCandCap];
+    const uint32_t sec = blockIdx.x;
+    const int lane = threadIdx.x;
+    uint32_t n = cand_cnt[sec];
+    n = n < (uint32_t)kCandCap ? n : (uint32_t)kCandCap;
+    for (uint32_t i = lane; i < n; i += 64) {
+        st[i] = cand_t[(size_t)sec * kCandCap + i];
+        sk[i] = cand_k[(size_t)sec * kCandCap + i];
+        sp[i] = cand_p[(size_t)sec * kCandCap + i];
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) {
+        uint32_t rank = 0;
+        const float p = sp[i];
+        const uint32_t t = st[i], k = sk[i];
+        for (uint32_t j = 0; j < n; j++) {
+            const float q = sp[j];
+            const bool before = q > p || (q == p && (st[j] < t || (st[j] == t && sk[j] < k)));
+            rank += before ? 1u : 0u;
+        }
+        keep[i] = rank < pps ? 1 : 0;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) {
+        if (!keep[i]) continue;
+        uint32_t pos = 0;
+        const uint32_t t = st[i], k = sk[i];
+        for (uint32_t j = 0; j < n; j++)
+            if (keep[j] && (st[j] < t || (st[j] == t && sk[j] < k))) pos++;
+        sel_t[(size_t)sec * pps + pos] = t;
+        sel_k[(size_t)sec * pps + pos] = k;
+        sel_p[(size_t)sec * pps + pos] = sp[i];
+    }
+    if (lane == 0) sel_cnt[sec] = n < pps ? n : pps;
+}
+
+// single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                              uint32_t* __restrict__ out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < n; base += 1024) {
+        const size_t i = base + tid;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t c = carry;
+        if (i < n) out[i] = c + woff + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = c + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+__global__ void wang_compact_kernel(const uint32_t* __restrict__ sel_cnt, const uint32_t* __restrict__ sel_off,
+                                    const uint32_t* __restrict__ sel_t, const uint32_t* __restrict__ sel_k,
+                                    const float* __restrict__ sel_p, uint32_t n_sec, uint32_t pps,
+                                    uint32_t* __restrict__ pt, uint32_t* __restrict__ pk, float* __restrict__ pp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_sec * pps) return;
+    const uint32_t sec = (uint32_t)(i / pps), j = (uint32_t)(i - (size_t)sec * pps);
+    if (j >= sel_cnt[sec]) return;
+    const uint32_t o = sel_off[sec] + j;
+    pt[o] = sel_t[i];
+    pk[o] = sel_k[i];
+    pp[o] = sel_p[i];
+}
+
+// ---- A6: pairing (src/modality/audio.rs:965-1003) ------------------------------------------------
+template <bool EMIT>
+__global__ void wang_pair_kernel(const uint32_t* __restrict__ pt, const uint32_t* __restrict__ pk,
+                                 const float* __restrict__ pp, const uint32_t* __restrict__ np_ptr,
+                                 uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, float floor_p,
+                                 uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
+                                 uint32_t* __restrict__ out, size_t cap) {
+    const uint32_t np = *np_ptr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    uint32_t taken = 0;
+    if (pp[i] >= floor_p) {
+        const uint32_t ta = pt[i], ka = pk[i];
+        size_t o = EMIT ? offs[i] : 0;
+        for (uint32_t j = i + 1; j < np && taken < fan_out; j++) {
+            const int32_t dt = (int32_t)pt[j] - (int32_t)ta;
+            if (dt <= 0) continue;
+            if (dt > (int32_t)zone_t) break;
+            int32_t df = (int32_t)pk[j] - (int32_t)ka;
+            df = df < 0 ? -df : df;
+            if (df > (int32_t)zone_f) continue;
+            if (EMIT && o < cap) {
+                out[2 * o] = (ka << 23) | (pk[j] << 14) | ((uint32_t)dt & 0x3fffu);
+                out[2 * o + 1] = ta;
+            }
+            o++;
+            taken++;
+        }
+    }
+    if (!EMIT) counts[i] = taken;
+}
+
+__global__ void copy_u32_kernel(const uint32_t* __restrict__ src, uint64_t* __restrict__ dst) { *dst = *src; }
+
+// ---- A8 ------------------------------------------------------------------------------------
+__global__ void haitsma_bits_kernel(const float* __restrict__ E, size_t first, size_t n, uint32_t* __restrict__ out) {
+    // E holds frames [first - 1, first + n) when first > 0 (row 0 = previous frame), else [0, n)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t row = first > 0 ? i + 1 : i;
+    const float* cur = E + row * kHkBands;
+    const bool has_prev = first > 0 || i > 0;
+    const float* prv = cur - kHkBands;
+    uint32_t h = 0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) {
+        const float c = cur[b] - cur[b + 1];
+        const float p = has_prev ? prv[b] - prv[b + 1] : 0.0f;
+        const float dd = c - p;
+        if (dd > 0.0f) h |= 1u << b;
+    }
+    out[first + i] = h;
+}
+
+inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+size_t audio_resample_len(size_t n, uint32_t sr_in, uint32_t sr_out) {
+    return (size_t)(((unsigned __int128)n * sr_out) / sr_in);
+}
+
+int launch_resample_linear(const float* in, size_t n, uint32_t sr_in, uint32_t sr_out, float* out,
+                           hipStream_t stream) {
+    const size_t m = audio_resample_len(n, sr_in, sr_out);
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(resample_linear_kernel, dim3(blocks_for(m, 256)), dim3(256), 0, stream, in, n, sr_in, sr_out,
+                       out, m);
+    return 0;
+}
+
+size_t audio_stft_frames(size_t n, int N, int hop) { return n >= (size_t)N ? 1 + (n - N) / hop : 0; }
+
+// ---- Wang orchestration ------------------------------------------------------------------------
+constexpr size_t kChunkFrames = 32768;  // 64 MiB of spilled power spectrum per chunk
+
+WangWs wang_ws_layout(size_t n_samples, uint32_t pps) {
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    WangWs w;
+    w.frames = audio_stft_frames(n_samples, kWangN, kWangHop);
+    w.n_sec = w.frames ? (uint32_t)(((w.frames - 1) * kWangHop) / kWangSr + 1) : 0;
+    const size_t win = (w.frames < kChunkFrames ? w.frames : kChunkFrames) + 2 * kRT;
+    size_t off = 0;
+    w.P = off;        off = align(off + win * kWangBins * 4);
+    w.rowmax = off;   off = align(off + win * kWangBins * 4);
+    w.cand_cnt = off; off = align(off + (size_t)w.n_sec * 4);
+    w.cand_t = off;   off = align(off + (size_t)w.n_sec * kCandCap * 4);
+    w.cand_k = off;   off = align(off + (size_t)w.n_sec * kCandCap * 4);
+    w.cand_p = off;   off = align(off + (size_t)w.n_sec * kCandCap * 4);
+    w.sel_cnt = off;  off = align(off + ((size_t)w.n_sec + 1) * 4);
+    w.sel_off = off;  off = align(off + ((size_t)w.n_sec + 1) * 4);
+    w.sel_t = off;    off = align(off + (size_t)w.n_sec * pps * 4);
+    w.sel_k = off;    off = align(off + (size_t)w.n_sec * pps * 4);
+    w.sel_p = off;    off = align(off + (size_t)w.n_sec * pps * 4);
+    const size_t maxp = (size_t)w.n_sec * pps;
+    w.pt = off;       off = align(off + maxp * 4);
+    w.pk = off;       off = align(off + maxp * 4);
+    w.pp = off;       off = align(off + maxp * 4);
+    w.pair_cnt = off; off = align(off + (maxp + 1) * 4);
+    w.pair_off = off; off = align(off + (maxp + 1) * 4);
+    w.total = off + 256;
+    return w;
+}
+
+int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
+                float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* out_count,
+                hipStream_t stream) {
+    if (w.frames == 0 || pps == 0) {
+        (void)hipMemsetAsync(out_count, 0, 8, stream);
+        return 0;
+    }
+    auto f32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+    (void)hipMemsetAsync(u32(w.cand_cnt), 0, (size_t)w.n_sec * 4, stream);
+    const size_t lds = sizeof(FftLds<kWangN>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_power_kernel<kWangN, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (size_t e0 = 0; e0 < w.frames; e0 += kChunkFrames) {
+        const size_t e1 = e0 + kChunkFrames < w.frames ? e0 + kChunkFrames : w.frames;
+        const size_t w0 = e0 >= (size_t)kRT ? e0 - kRT : 0;
+        const size_t w1 = e1 + kRT < w.frames ? e1 + kRT : w.frames;
+        const size_t wn = w1 - w0;
+        unsigned grid = blocks_for(wn, 4);
+        if (grid > 256 * 8) grid = 256 * 8;
+        hipLaunchKernelGGL((stft_power_kernel<kWangN, false>), dim3(grid), dim3(256), lds, stream, pcm8k, w0, wn,
+                           kWangHop, f32(w.P), (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(wang_rowmax_kernel, dim3(blocks_for(wn * kWangBins, 256)), dim3(256), 0, stream, f32(w.P),
+                           wn, f32(w.rowmax));
+        hipLaunchKernelGGL(wang_cand_kernel, dim3(blocks_for((e1 - e0) * kWangBins, 256)), dim3(256), 0, stream,
+                           f32(w.P), f32(w.rowmax), w0, wn, e0, e1, w.frames, u32(w.cand_cnt), u32(w.cand_t),
+                           u32(w.cand_k), f32(w.cand_p));
+    }
+    hipLaunchKernelGGL(wang_select_kernel, dim3(w.n_sec), dim3(64), 0, stream, u32(w.cand_cnt), u32(w.cand_t),
+                       u32(w.cand_k), f32(w.cand_p), pps, u32(w.sel_cnt), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p));
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, u32(w.sel_cnt), (size_t)w.n_sec,
+                       u32(w.sel_off));
+    hipLaunchKernelGGL(wang_compact_kernel, dim3(blocks_for((size_t)w.n_sec * pps, 256)), dim3(256), 0, stream,
+                       u32(w.sel_cnt), u32(w.sel_off), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p), w.n_sec, pps,
+                       u32(w.pt), u32(w.pk), f32(w.pp));
+    const size_t maxp = (size_t)w.n_sec * pps;
+    const uint32_t* np_ptr = u32(w.sel_off) + w.n_sec;  // total peaks
+    (void)hipMemsetAsync(u32(w.pair_cnt), 0, (maxp + 1) * 4, stream);
+    hipLaunchKernelGGL(wang_pair_kernel<false>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
+                       u32(w.pk), f32(w.pp), np_ptr, fan_out, zone_t, zone_f, floor_power, u32(w.pair_cnt),
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, u32(w.pair_cnt), maxp,
+                       u32(w.pair_off));
+    hipLaunchKernelGGL(wang_pair_kernel<true>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
+                       u32(w.pk), f32(w.pp), np_ptr, fan_out, zone_t, zone_f, floor_power, (uint32_t*)nullptr,
+                       (const uint32_t*)u32(w.pair_off), out, cap);
+    hipLaunchKernelGGL(copy_u32_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)(u32(w.pair_off) + maxp),
+                       out_count);
+    return 0;
+}
+
+// ---- Haitsma orchestration -----------------------------------------------------------------------
+size_t haitsma_ws_bytes(size_t n5k) {
+    const size_t frames = audio_stft_frames(n5k, kHkN, kHkHop);
+    const size_t chunk = frames < kChunkFrames * 4 ? frames : kChunkFrames * 4;
+    return (chunk + 1) * kHkBands * 4 + 64 * 4 + 1024;
+}
+
+int launch_haitsma(const float* pcm5k, size_t n, const uint32_t* h_edges, uint8_t* ws, uint32_t* out,
+                   hipStream_t stream) {
+    const size_t frames = audio_stft_frames(n, kHkN, kHkHop);
+    if (frames == 0) return 0;
+    uint32_t* d_edges = reinterpret_cast<uint32_t*>(ws);
+    float* E = reinterpret_cast<float*>(ws + 64 * 4);
+    (void)hipMemcpyAsync(d_edges, h_edges, (kHkBands + 1) * 4, hipMemcpyHostToDevice, stream);
+    const size_t lds = sizeof(FftLds<kHkN>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_power_kernel<kHkN, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t chunk = kChunkFrames * 4;
+    for (size_t e0 = 0; e0 < frames; e0 += chunk) {
+        const size_t e1 = e0 + chunk < frames ? e0 + chunk : frames;
+        const size_t w0 = e0 > 0 ? e0 - 1 : 0;  // one frame of history for the time difference
+        const size_t wn = e1 - w0;
+        unsigned grid = blocks_for(wn, 4);
+        if (grid > 256 * 4) grid = 256 * 4;
+        hipLaunchKernelGGL((stft_power_kernel<kHkN, true>), dim3(grid), dim3(256), lds, stream, pcm5k, w0, wn, kHkHop,
+                           E, (const uint32_t*)d_edges);
+        hipLaunchKernelGGL(haitsma_bits_kernel, dim3(blocks_for(e1 - e0, 256)), dim3(256), 0, stream, E, e0, e1 - e0,
+                           out);
+    }
+    return 0;
+}
+
+}  // namespace ucfp

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -52,6 +53,10 @@ struct ucfp_ctx {
     uint8_t* stage_out = nullptr;
     size_t stage_out_cap = 0;
     hipStream_t host_stream = nullptr;
+    // audio workspace (spilled spectrogram chunk, candidate lists), shared by successive calls
+    uint8_t* audio_ws = nullptr;
+    size_t audio_ws_cap = 0;
+    hipEvent_t audio_done = nullptr;
 };
 
 namespace {
@@ -100,6 +105,7 @@ int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
     c->device = device_id;
     hipError_t e2 = hipMalloc((void**)&c->norm_ws, kNormWsFrames * 65536);
     if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->audio_done, hipEventDisableTiming);
     if (e2 != hipSuccess) {
         ucfp_ctx_destroy(c);
         return fail(UCFP_E_INDEX, "context allocation failed: %s", hipGetErrorString(e2));
@@ -115,6 +121,8 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->stage_in) (void)hipFree(c->stage_in);
     if (c->stage_out) (void)hipFree(c->stage_out);
     if (c->host_stream) (void)hipStreamDestroy(c->host_stream);
+    if (c->audio_ws) (void)hipFree(c->audio_ws);
+    if (c->audio_done) (void)hipEventDestroy(c->audio_done);
     delete c;
 }
 
@@ -201,6 +209,189 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
     HIP_TRY(hipMemcpyAsync(out, d_out, n * rec, hipMemcpyDeviceToHost, st));
     if (status) HIP_TRY(hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return UCFP_OK;
+}
+
+// ---------------------------------- audio ---------------------------------------------
+
+static ucfp_wang_config wang_defaults() { return ucfp_wang_config{10u, 63u, 64u, 30u, -50.0f}; }
+
+static int wang_cfg_check(const ucfp_wang_config& c) {
+    if (c.fan_out < 1 || c.fan_out > 64 || c.target_zone_t < 1 || c.target_zone_t > 512 || c.target_zone_f < 1 ||
+        c.target_zone_f > 1024 || c.peaks_per_sec < 1 || c.peaks_per_sec > 256)
+        return fail(UCFP_E_MODALITY, "WangConfig outside the ranges of /v1/algorithms");
+    return UCFP_OK;
+}
+
+size_t ucfp_audio_wang_max_hashes(size_t n_samples, const ucfp_wang_config* cfg) {
+    const ucfp_wang_config c = cfg ? *cfg : wang_defaults();
+    const size_t frames = ucfp::audio_stft_frames(n_samples, 1024, 128);
+    if (!frames) return 0;
+    const size_t n_sec = ((frames - 1) * 128) / 8000 + 1;
+    return n_sec * c.peaks_per_sec * c.fan_out;
+}
+
+int ucfp_audio_wang_dev(ucfp_ctx* ctx, const float* d_pcm, size_t n, uint32_t sample_rate,
+                        const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes, uint64_t* d_n_hashes,
+                        void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (!d_n_hashes || (n && !d_pcm) || (cap_hashes && !d_out)) return fail(UCFP_E_INVALID, "NULL buffer");
+    if (sample_rate != 8000)
+        return fail(UCFP_E_MODALITY, "Wang requires 8 kHz mono input (got %u Hz); resample upstream", sample_rate);
+    const ucfp_wang_config c = cfg ? *cfg : wang_defaults();
+    int rc = wang_cfg_check(c);
+    if (rc) return rc;
+    const ucfp::WangWs w = ucfp::wang_ws_layout(n, c.peaks_per_sec);
+    const float floor_p = (float)(65536.0 * pow(10.0, (double)c.min_anchor_mag_db / 10.0));
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = grow(&ctx->audio_ws, &ctx->audio_ws_cap, w.total);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, ctx->audio_done, 0));
+    ucfp::launch_wang(d_pcm, n, c.fan_out, c.target_zone_t, c.target_zone_f, c.peaks_per_sec, floor_p, ctx->audio_ws,
+                      w, reinterpret_cast<uint32_t*>(d_out), cap_hashes, d_n_hashes, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->audio_done, st));
+    return UCFP_OK;
+}
+
+int ucfp_audio_wang(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate, const ucfp_wang_config* cfg,
+                    uint8_t* out, size_t cap_hashes, size_t* n_hashes) {
+    if (!ctx || !n_hashes) return fail(UCFP_E_INVALID, "ctx/n_hashes is NULL");
+    *n_hashes = 0;
+    if (n && !pcm) return fail(UCFP_E_INVALID, "pcm is NULL");
+    if (sample_rate != 8000)
+        return fail(UCFP_E_MODALITY, "Wang requires 8 kHz mono input (got %u Hz); resample upstream", sample_rate);
+    HIP_TRY(hipSetDevice(ctx->device));
+    float* d_pcm = nullptr;
+    uint8_t* d_out = nullptr;
+    uint64_t* d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_pcm, (n ? n : 1) * 4));
+    hipError_t e = hipMalloc((void**)&d_out, (cap_hashes ? cap_hashes : 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_cnt, 8);
+    int rc = UCFP_OK;
+    uint64_t cnt = 0;
+    hipStream_t st = ctx->host_stream;
+    if (e == hipSuccess && n) e = hipMemcpyAsync(d_pcm, pcm, n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = ucfp_audio_wang_dev(ctx, d_pcm, n, sample_rate, cfg, d_out, cap_hashes, d_cnt, st);
+        if (rc == UCFP_OK) {
+            e = hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess && cnt) {
+                const size_t m = cnt < cap_hashes ? (size_t)cnt : cap_hashes;
+                e = hipMemcpy(out, d_out, m * 8, hipMemcpyDeviceToHost);
+            }
+        }
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(d_pcm);
+    if (d_out) (void)hipFree(d_out);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(UCFP_E_INDEX, "wang failed: %s", hipGetErrorString(e));
+    *n_hashes = (size_t)cnt;
+    if (cnt > cap_hashes) return fail(UCFP_E_INVALID, "output holds %zu hashes, %llu produced", cap_hashes, (unsigned long long)cnt);
+    return UCFP_OK;
+}
+
+size_t ucfp_audio_resample_len(size_t n, uint32_t sr_in, uint32_t sr_out) {
+    return sr_in ? ucfp::audio_resample_len(n, sr_in, sr_out) : 0;
+}
+
+int ucfp_audio_resample_linear_dev(ucfp_ctx* ctx, const float* d_in, size_t n, uint32_t sr_in, uint32_t sr_out,
+                                   float* d_out, size_t cap, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (sr_in == 0 || sr_out == 0 || sr_in > 384000 || sr_out > 384000)
+        return fail(UCFP_E_MODALITY, "invalid sample rate %u -> %u", sr_in, sr_out);
+    const size_t m = ucfp::audio_resample_len(n, sr_in, sr_out);
+    if (m > cap) return fail(UCFP_E_INVALID, "resample output needs %zu samples, buffer holds %zu", m, cap);
+    if (m && (!d_in || !d_out)) return fail(UCFP_E_INVALID, "NULL buffer");
+    ucfp::launch_resample_linear(d_in, n, sr_in, sr_out, d_out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UCFP_OK;
+}
+
+static void haitsma_edges(float fmin, float fmax, uint32_t edges[34]) {
+    for (int b = 0; b <= 33; b++) {
+        const double f = (double)fmin * pow((double)fmax / (double)fmin, (double)b / 33);
+        const double bin = f * 2048 / 5000;
+        uint32_t e = (uint32_t)ceil(bin);
+        if (e > 1024) e = 1024;
+        edges[b] = e;
+    }
+}
+
+size_t ucfp_audio_haitsma_frames(size_t n_samples, uint32_t sample_rate) {
+    if (!sample_rate) return 0;
+    const size_t n5 = sample_rate == 5000 ? n_samples : ucfp::audio_resample_len(n_samples, sample_rate, 5000);
+    return ucfp::audio_stft_frames(n5, 2048, 64);
+}
+
+int ucfp_audio_haitsma_dev(ucfp_ctx* ctx, const float* d_pcm5k, size_t n, const ucfp_haitsma_config* cfg,
+                           uint32_t* d_out, size_t cap_frames, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    const float fmin = cfg ? cfg->fmin : 300.0f, fmax = cfg ? cfg->fmax : 2000.0f;
+    if (!(fmin >= 1.0f) || !(fmax > fmin) || !(fmax <= 2500.0f))
+        return fail(UCFP_E_MODALITY, "Haitsma band edges must satisfy 1 <= fmin < fmax <= 2500 Hz");
+    const size_t frames = ucfp::audio_stft_frames(n, 2048, 64);
+    if (frames > cap_frames) return fail(UCFP_E_INVALID, "output holds %zu frames, %zu produced", cap_frames, frames);
+    if (frames == 0) return UCFP_OK;
+    if (!d_pcm5k || !d_out) return fail(UCFP_E_INVALID, "NULL buffer");
+    uint32_t edges[34];
+    haitsma_edges(fmin, fmax, edges);
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = grow(&ctx->audio_ws, &ctx->audio_ws_cap, ucfp::haitsma_ws_bytes(n));
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, ctx->audio_done, 0));
+    // edges are copied with a pageable-memory async copy: keep them alive in the context
+    static thread_local uint32_t tl_edges[34];
+    memcpy(tl_edges, edges, sizeof edges);
+    ucfp::launch_haitsma(d_pcm5k, n, tl_edges, ctx->audio_ws, d_out, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->audio_done, st));
+    return UCFP_OK;
+}
+
+int ucfp_audio_haitsma(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate,
+                       const ucfp_haitsma_config* cfg, uint32_t* out, size_t cap_frames, size_t* n_frames) {
+    if (!ctx || !n_frames) return fail(UCFP_E_INVALID, "ctx/n_frames is NULL");
+    *n_frames = 0;
+    if (sample_rate == 0 || sample_rate > 384000) return fail(UCFP_E_MODALITY, "invalid sample rate %u", sample_rate);
+    if (n && !pcm) return fail(UCFP_E_INVALID, "pcm is NULL");
+    const size_t n5 = sample_rate == 5000 ? n : ucfp::audio_resample_len(n, sample_rate, 5000);
+    const size_t frames = ucfp::audio_stft_frames(n5, 2048, 64);
+    if (frames > cap_frames) return fail(UCFP_E_INVALID, "output holds %zu frames, %zu produced", cap_frames, frames);
+    if (frames == 0) return UCFP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d_in = nullptr, *d_5k = nullptr;
+    uint32_t* d_out = nullptr;
+    hipStream_t st = ctx->host_stream;
+    HIP_TRY(hipMalloc((void**)&d_in, n * 4));
+    hipError_t e = hipMalloc((void**)&d_out, frames * 4);
+    if (e == hipSuccess && sample_rate != 5000) e = hipMalloc((void**)&d_5k, n5 * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm, n * 4, hipMemcpyHostToDevice, st);
+    int rc = UCFP_OK;
+    if (e == hipSuccess) {
+        const float* src = d_in;
+        if (sample_rate != 5000) {
+            ucfp::launch_resample_linear(d_in, n, sample_rate, 5000, d_5k, st);
+            src = d_5k;
+        }
+        rc = ucfp_audio_haitsma_dev(ctx, src, n5, cfg, d_out, frames, st);
+        if (rc == UCFP_OK) e = hipMemcpyAsync(out, d_out, frames * 4, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_in);
+    if (d_5k) (void)hipFree(d_5k);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(UCFP_E_INDEX, "haitsma failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    *n_frames = frames;
     return UCFP_OK;
 }
 

@@ -40,9 +40,26 @@ def parse():
                          "100M; split evenly over the ranks = strong scaling). 0 skips the ANN leg")
     ap.add_argument("--ann-queries", type=int, default=4096)
     ap.add_argument("--ann-steps", type=int, default=5)
+    ap.add_argument("--text-docs", type=int, default=1_000_000, help="4 KiB docs per GPU (BASELINE configs[3]); 0 skips")
+    ap.add_argument("--audio-seconds", type=int, default=36_000, help="seconds of 44.1 kHz audio per GPU "
+                    "(BASELINE configs[2]: 10 h); 0 skips")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)")
     return ap.parse_args()
+
+
+def traffic_from_profiles(frames):
+    """HBM bytes per launch measured by rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 correction applied) and committed under profiles/; only valid for the profiled batch."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, rd, "image_multi_pmc_summary.json")
+        if os.path.exists(f):
+            d = json.load(open(f))["corrected_bytes_per_launch"]
+            if d.get("algorithmic") == ALGO_BYTES_PER_FRAME * frames:
+                best = d["total"]
+    return best
 
 
 def cpu_baseline(sample: int, gpu_records_head):
@@ -140,6 +157,121 @@ def bench_ann(args, rank, world, dev, ctx):
     }
 
 
+def bench_text(args, rank, world, dev, ctx):
+    """Secondary leg (BASELINE configs[3]): MinHash-128 over synthetic 4 KiB ASCII documents,
+    tokenisation + shingling + hashing all on the GPU. Documents shard by index, no collective."""
+    import numpy as np
+    import torch
+    from ucfp_amd import _lib
+    n_docs, doc_len, pool_n = args.text_docs, 4096, 4096
+    rng = np.random.default_rng(0xD0C5 + rank)
+    vocab = np.array(["".join(chr(97 + (i // 26 ** j) % 26) for j in range(1 + i % 7)) for i in range(50000)])
+    ranks = np.minimum(rng.zipf(1.1, size=(pool_n, 1200)) - 1, 49999)
+    pool = np.zeros((pool_n, doc_len), np.uint8)
+    for d in range(pool_n):
+        b = " ".join(vocab[ranks[d]]).encode()[:doc_len]
+        pool[d, :len(b)] = np.frombuffer(b, np.uint8)
+        pool[d, len(b):] = 32
+    reps = (n_docs + pool_n - 1) // pool_n
+    blob = torch.from_numpy(pool).to(dev).repeat(reps, 1)[:n_docs].contiguous()
+    offs = (torch.arange(n_docs + 1, dtype=torch.int64, device=dev) * doc_len).contiguous()
+    out = torch.empty((n_docs, 1032), dtype=torch.uint8, device=dev)
+    status = torch.empty((n_docs,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    lib = _lib.load()
+
+    def step():
+        _lib.check(lib.ucfp_text_minhash_batch_dev(ctx.handle, blob.data_ptr(), offs.data_ptr(), n_docs, 0, 5,
+                                                   out.data_ptr(), status.data_ptr(), stream))
+    step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    steps = 3
+    ev[0].record()
+    for _ in range(steps):
+        step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    assert int(status.abs().sum().item()) == 0
+    res = {"metric": "documents/s (MinHash-128, k=5 word shingles, tokenised on GPU)",
+           "value": n_docs / (ms / 1e3) * world, "unit": "docs/s", "docs_per_gpu": n_docs, "doc_bytes": doc_len,
+           "ms_per_pass": ms, "algorithmic_GBs": n_docs * (doc_len + 1032) / (ms / 1e3) / 1e9,
+           "note": "integer-VALU bound (DESIGN.md 5), HBM figure given as the common yardstick"}
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import oracle
+        docs = [bytes(pool[i]) for i in range(2048)]
+        t0 = time.perf_counter()
+        o, _ = oracle.text_minhash_batch(docs)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": 2048 / dt, "unit": "docs/s", "cores": oracle.num_threads(), "kind": "port",
+                               "gpu_matches_oracle_on_sample": bool(np.array_equal(o, out[:2048].cpu().numpy()))}
+    return res
+
+
+def bench_audio(args, rank, world, dev, ctx):
+    """Secondary leg (BASELINE configs[2]): Wang landmarks over synthetic 44.1 kHz mono PCM:
+    linear resample to 8 kHz, STFT, peaks, pairs -- one stream per GPU."""
+    import numpy as np
+    import torch
+    from ucfp_amd import _lib
+    sr, secs = 44100, args.audio_seconds
+    n = sr * secs
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xA0D10 + rank)
+    t = torch.arange(n, dtype=torch.float32, device=dev) / sr
+    x = torch.zeros(n, dtype=torch.float32, device=dev)
+    for i in range(8):
+        f0 = 110.0 * (1.6 ** i)
+        x += 0.06 * torch.sin(2 * np.pi * (f0 * t + 3.0 * torch.sin(0.05 * (i + 1) * t)))
+    del t
+    x += 0.0158 * torch.randn(n, dtype=torch.float32, device=dev, generator=g)
+    x.clamp_(-0.5, 0.5)
+    lib = _lib.load()
+    m = int(lib.ucfp_audio_resample_len(n, sr, 8000))
+    x8 = torch.empty(m, dtype=torch.float32, device=dev)
+    cap = int(lib.ucfp_audio_wang_max_hashes(m, None))
+    out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        _lib.check(lib.ucfp_audio_resample_linear_dev(ctx.handle, x.data_ptr(), n, sr, 8000, x8.data_ptr(), m, stream))
+        _lib.check(lib.ucfp_audio_wang_dev(ctx.handle, x8.data_ptr(), m, 8000, None, out.data_ptr(), cap,
+                                           cnt.data_ptr(), stream))
+    step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    steps = 3
+    ev[0].record()
+    for _ in range(steps):
+        step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    nh = int(cnt.item())
+    res = {"metric": "audio-seconds/s (Wang landmarks incl. 44.1k->8k linear resample)",
+           "value": secs / (ms / 1e3) * world, "unit": "x real time", "seconds_per_gpu": secs, "ms_per_pass": ms,
+           "hashes": nh, "algorithmic_GBs": (n * 4 + nh * 8) / (ms / 1e3) / 1e9,
+           "note": "spectrogram is spilled in 64 MiB chunks in round 1 (DESIGN.md 8)"}
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import oracle
+        s = 60 * sr
+        xs = x[:s].cpu().numpy()
+        t0 = time.perf_counter()
+        o = oracle.wang(oracle.resample_linear(xs, sr, 8000))
+        dt = time.perf_counter() - t0
+        d8 = torch.empty(int(lib.ucfp_audio_resample_len(s, sr, 8000)), dtype=torch.float32, device=dev)
+        _lib.check(lib.ucfp_audio_resample_linear_dev(ctx.handle, x.data_ptr(), s, sr, 8000, d8.data_ptr(), d8.numel(), stream))
+        _lib.check(lib.ucfp_audio_wang_dev(ctx.handle, d8.data_ptr(), d8.numel(), 8000, None, out.data_ptr(), cap,
+                                           cnt.data_ptr(), stream))
+        torch.cuda.synchronize()
+        gh = out[:int(cnt.item())].cpu().numpy().view(np.uint32)
+        res["cpu_baseline"] = {"value": 60.0 / dt, "unit": "x real time", "cores": oracle.num_threads(), "kind": "port",
+                               "sample": "first 60 s", "gpu_matches_oracle_on_sample": bool(np.array_equal(gh, o))}
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -234,7 +366,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * n,
                 "avg_launch_ms": avg_kernel_s * 1e3,
-                "traffic": args.traffic_bytes,
+                "traffic": traffic_from_profiles(n) if args.traffic_bytes is None else args.traffic_bytes,
             },
         }
         res["ann"] = None
@@ -252,6 +384,16 @@ def main():
         ann = bench_ann(args, rank, world, dev, ctx)
         if rank == 0:
             res["ann"] = ann
+    if args.text_docs > 0:
+        r = bench_text(args, rank, world, dev, ctx)
+        if rank == 0:
+            res["text"] = r
+        torch.cuda.empty_cache()
+    if args.audio_seconds > 0:
+        r = bench_audio(args, rank, world, dev, ctx)
+        if rank == 0:
+            res["audio"] = r
+        torch.cuda.empty_cache()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -37,6 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ImageLds {
     uint8_t s2[128 * 128];   // 16 KiB
     uint16_t v8[32 * 256];   // 16 KiB
+    uint16_t cs32[8 * 256];  // 4 KiB: column sums over 32 normalised rows (global 9x8 dHash image)
     uint16_t gsum[32 * 32];  // 2 KiB
     uint8_t g32[32 * 32];    // 1 KiB
     float pbuf[4][32 * 8];   // per-wave P = X*C8^T
@@ -149,43 +150,64 @@ __device__ __forceinline__ uint64_t ahash_region(const ImageLds& L, int r, int l
     return __ballot(px > mean);
 }
 
-// One 9x8 dHash pixel. Global: SRC = 256 columns, 4 v8 rows per output row, /8192.
-// Block: SRC = 64 columns starting at x0, 1 v8 row, /512.
-template <bool GLOBAL>
-__device__ __forceinline__ uint32_t dhash_px(const ImageLds& L, int vrow, int x0, int c) {
-    constexpr int SRC = GLOBAL ? 256 : 64;
-    const int d0 = SRC * c, d1 = d0 + SRC;          // dest cell on the 9*SRC lattice
-    const int xs = d0 / 9, xe = (d1 + 8) / 9;       // source cells touching it
-    uint32_t acc = 0;
-#pragma unroll 2
-    for (int x = xs; x < xe; x++) {
-        const int s0 = 9 * x, s1 = s0 + 9;
-        const int lo = s0 > d0 ? s0 : d0, hi = s1 < d1 ? s1 : d1;
-        const uint32_t w = (uint32_t)(hi - lo);
-        uint32_t cs;
-        if (GLOBAL) {
-            cs = (uint32_t)L.v8[(vrow + 0) * 256 + x] + L.v8[(vrow + 1) * 256 + x] +
-                 L.v8[(vrow + 2) * 256 + x] + L.v8[(vrow + 3) * 256 + x];
-        } else {
-            cs = L.v8[vrow * 256 + x0 + x];
-        }
-        acc += w * cs;
+// 9x8 dHash image of a region from vertical column sums `row` (u16, x = 0 at the region's left
+// edge; SRC = 256 columns for the global region, 64 for a block).  On the common lattice of
+// length 9*SRC a source column x covers [9x, 9x+9) and destination column c covers
+// [SRC*c, SRC*(c+1)): every touched column has weight 9 except the first and the last.
+template <int SRC>
+__device__ __forceinline__ uint32_t dhash_acc(const uint16_t* __restrict__ row, int c) {
+    constexpr int MAXCOLS = (SRC + 8) / 9 + 1;
+    const int d0 = SRC * c, d1 = d0 + SRC;
+    const int xs = d0 / 9, xe = (d1 + 8) / 9;
+    const int e0 = 9 * xs + 9;
+    const int w0 = (e0 < d1 ? e0 : d1) - d0;
+    const int s1 = 9 * (xe - 1);
+    const int w1 = d1 - (s1 > d0 ? s1 : d0);
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < MAXCOLS; i++) {
+        const int x = xs + i;
+        sum += x < xe ? (uint32_t)row[x] : 0u;
     }
-    return GLOBAL ? (acc + 4096u) >> 13 : (acc + 256u) >> 9;
+    return 9u * sum - (uint32_t)(9 - w0) * row[xs] - (uint32_t)(9 - w1) * row[xe - 1];
+}
+
+// Destination column 8 (the right neighbour of column 7) is spread over the 8 lanes of a row
+// group instead of costing a second pass: lane j adds its share, a 3-step butterfly sums them.
+template <int SRC>
+__device__ __forceinline__ uint32_t dhash_acc_col8(const uint16_t* __restrict__ row, int j) {
+    constexpr int XS = (8 * SRC) / 9;                 // first source column touching [8*SRC, 9*SRC)
+    constexpr int W0 = 9 * XS + 9 - 8 * SRC;          // its overlap
+    constexpr int N = SRC - XS;                       // 8 (block) or 29 (global) columns
+    uint32_t part = 0;
+#pragma unroll
+    for (int i = 0; i < (N + 7) / 8; i++) {
+        const int x = XS + j + 8 * i;
+        const uint32_t w = x == XS ? (uint32_t)W0 : 9u;
+        part += x < SRC ? w * row[x] : 0u;
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    return part;
 }
 
 __device__ __forceinline__ uint64_t dhash_region(const ImageLds& L, int r, int lane) {
     const int a = lane >> 3, c = lane & 7;
-    uint32_t left, right;
+    uint32_t px, px8;
     if (r == 0) {
-        left = dhash_px<true>(L, 4 * a, 0, c);
-        right = dhash_px<true>(L, 4 * a, 0, c + 1);
+        const uint16_t* row = &L.cs32[a * 256];
+        px = (dhash_acc<256>(row, c) + 4096u) >> 13;
+        px8 = (dhash_acc_col8<256>(row, c) + 4096u) >> 13;
     } else {
         const int by = (r - 1) >> 2, bx = (r - 1) & 3;
-        left = dhash_px<false>(L, 8 * by + a, 64 * bx, c);
-        right = dhash_px<false>(L, 8 * by + a, 64 * bx, c + 1);
+        const uint16_t* row = &L.v8[(8 * by + a) * 256 + 64 * bx];
+        px = (dhash_acc<64>(row, c) + 256u) >> 9;
+        px8 = (dhash_acc_col8<64>(row, c) + 256u) >> 9;
     }
-    return __ballot(left > right);
+    const uint32_t nxt = __shfl_down(px, 1, 64);
+    const uint32_t right = c == 7 ? px8 : nxt;
+    return __ballot(px > right);
 }
 
 // pHash of region r. creg[s] = C[lane&15][4s + (lane>>4)] (0 for lane&15 >= 8).
@@ -243,17 +265,21 @@ __device__ __forceinline__ uint64_t phash_region(ImageLds& L, int r, int lane, i
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-    // ---- median of the 63 AC coefficients by rank counting; lane = coefficient index ----
+    // ---- median of the 63 AC coefficients: bitonic sort across the wave (DC parked at +inf),
+    //      the 32nd smallest lands on lane 31 ----
     const float mine = CO[lane];
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 1; j < 64; j++) {
-        const float o = CO[j];
-        rank += (o < mine || (o == mine && j < lane)) ? 1 : 0;
+    float v = lane == 0 ? __builtin_inff() : mine;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float o = __shfl_xor(v, j, 64);
+            const bool up = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+        }
     }
-    const uint64_t is_med = __ballot(lane >= 1 && rank == 31);
-    const int med_lane = __ffsll((unsigned long long)is_med) - 1;
-    const float med = __shfl(mine, med_lane, 64);
+    const float med = __shfl(v, 31, 64);
     const uint64_t h = __ballot(mine > med);
     __builtin_amdgcn_wave_barrier();
     return h;
@@ -268,6 +294,19 @@ __device__ __forceinline__ void hash_phase_and_store(ImageLds& L, uint32_t algo,
         const int m = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int s = 0; s < 8; s++) creg[s] = (m < 8) ? c_dct_lo[m][4 * s + q] : 0.f;
+    }
+    if (algo & 4u) {
+        // column sums over 32 normalised rows = 4 v8 rows, two u16 per dword (no carry: <= 8160)
+        const uint32_t* v8w = reinterpret_cast<const uint32_t*>(L.v8);
+        uint32_t* csw = reinterpret_cast<uint32_t*>(L.cs32);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int w = tid + 256 * i;            // dword index in cs32: row = w / 128
+            const int rr = w >> 7, xw = w & 127;
+            csw[w] = v8w[(4 * rr + 0) * 128 + xw] + v8w[(4 * rr + 1) * 128 + xw] +
+                     v8w[(4 * rr + 2) * 128 + xw] + v8w[(4 * rr + 3) * 128 + xw];
+        }
+        __syncthreads();
     }
 #pragma unroll 1
     for (int r = wave; r < 17; r += 4) {

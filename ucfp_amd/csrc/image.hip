@@ -33,6 +33,13 @@ namespace ucfp {
 __constant__ float c_dct_lo[8][32] = UCFP_DCT32_LO_INIT;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// frames are read exactly once: non-temporal loads keep them from displacing L2/MALL contents
+__device__ __forceinline__ uint4 load_frame16(const uint8_t* p) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 struct ImageLds {
     uint8_t s2[128 * 128];   // 16 KiB
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256) void image_hash_gray_kernel(
             uint4 rows[16];
 #pragma unroll
             for (int y = 0; y < 16; y++)
-                rows[y] = *reinterpret_cast<const uint4*>(base + (size_t)y * row_stride);
+                rows[y] = load_frame16(base + (size_t)y * row_stride);
 #pragma unroll
             for (int j2 = 0; j2 < 4; j2++) {
                 uint32_t nA[8], nB[8];

@@ -7,7 +7,7 @@
 // canonicalised and tokenised (PRETOKENIZED: tokens separated by single spaces).  Spec: DESIGN.md
 // "Text spec" T1..T6; CPU statement: oracle/ (text).
 //
-// One 256-thread workgroup per document, tiles of <= 4095 bytes:
+// One 256-thread workgroup per document, tiles of <= 2047 bytes:
 //   A  load the tile (16 B/lane, coalesced) into LDS, classify bytes; "byte is inside a word" is a
 //      function of (prev, cur, next) only (WB5-13 on ASCII), so it is embarrassingly parallel
 //   B  two block-wide exclusive scans (word bytes, token starts) give every word byte its place in
@@ -32,8 +32,9 @@ namespace ucfp {
 
 namespace {
 
-constexpr int kTile = 4096;           // LDS bytes per tile (last byte is look-ahead)
+constexpr int kTile = 2048;           // LDS bytes per tile (last byte is look-ahead)
 constexpr int kMaxTok = kTile / 2 + 8;
+constexpr int kPer = kTile / 256;      // bytes per thread per tile
 
 struct TextLds {
     uint8_t raw[kTile + 16];
@@ -123,7 +124,7 @@ __device__ __forceinline__ void block_scan2(TextLds& L, uint32_t a, uint32_t b, 
 
 // MODE_SIM = false: MinHash (out 1032 B/doc); true: SimHash (out 8 B/doc)
 template <bool MODE_SIM>
-__global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restrict__ utf8,
+__global__ __launch_bounds__(256, 4) void text_hash_kernel(const uint8_t* __restrict__ utf8,
                                                         const uint64_t* __restrict__ offsets, size_t n,
                                                         int pretok_i, uint32_t k,
                                                         uint8_t* __restrict__ out, int32_t* __restrict__ status) {
@@ -151,12 +152,12 @@ __global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restric
         {
             const int nload = last ? tl : tl + 1;
             const uint8_t* src = text + pos;
-            const int b0 = tid * 16;
-            if (((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && b0 + 16 <= nload) {
-                *reinterpret_cast<uint4*>(&L.raw[b0]) = *reinterpret_cast<const uint4*>(src + b0);
+            const int b0 = tid * kPer;
+            if (((reinterpret_cast<uintptr_t>(src) & 7u) == 0) && b0 + kPer <= nload) {
+                *reinterpret_cast<uint2*>(&L.raw[b0]) = *reinterpret_cast<const uint2*>(src + b0);
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; j++) L.raw[b0 + j] = (b0 + j < nload) ? src[b0 + j] : 0;
+                for (int j = 0; j < kPer; j++) L.raw[b0 + j] = (b0 + j < nload) ? src[b0 + j] : 0;
             }
             if (tid == 0) {
                 L.cut = -1;
@@ -164,19 +165,19 @@ __global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restric
             }
         }
         __syncthreads();
-        uint8_t c[18];  // c[0] = byte before my 16, c[17] = byte after
+        uint8_t c[kPer + 2];  // c[0] = byte before my kPer, c[kPer + 1] = byte after
         {
-            const int b0 = tid * 16;
+            const int b0 = tid * kPer;
             c[0] = b0 > 0 ? L.raw[b0 - 1] : 0;
 #pragma unroll
-            for (int j = 0; j < 16; j++) c[j + 1] = L.raw[b0 + j];
-            c[17] = (b0 + 16 < kTile) ? L.raw[b0 + 16] : 0;
+            for (int j = 0; j < kPer; j++) c[j + 1] = L.raw[b0 + j];
+            c[kPer + 1] = (b0 + kPer < kTile) ? L.raw[b0 + kPer] : 0;
         }
         uint32_t inw = 0;  // bit j: byte b0 + j is a word byte
         bool nonascii = false;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int i = tid * 16 + j;
+        for (int j = 0; j < kPer; j++) {
+            const int i = tid * kPer + j;
             if (i < tl) {
                 if (!pretok && c[j + 1] >= 0x80) nonascii = true;
                 if (inword(c[j], c[j + 1], c[j + 2], pretok)) inw |= 1u << j;
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restric
         if (!last) {
             int mycut = -1;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int i = tid * 16 + j;
+            for (int j = 0; j < kPer; j++) {
+                const int i = tid * kPer + j;
                 if (i < tl && !((inw >> j) & 1u)) mycut = i;
             }
             if (mycut >= 0) atomicMax(&L.cut, mycut);
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restric
         uint32_t nin = 0, nst = 0;
         bool prev_in = false;
         {
-            const int b0 = tid * 16;
+            const int b0 = tid * kPer;
             // previous byte's status (recomputed: needs the byte before it)
             if (b0 > 0 && b0 - 1 < limit) {
                 const uint8_t pp = b0 > 1 ? L.raw[b0 - 2] : 0;
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restric
             }
         }
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int i = tid * 16 + j;
+        for (int j = 0; j < kPer; j++) {
+            const int i = tid * kPer + j;
             bool w = ((inw >> j) & 1u) && i < limit;
             if (!w) inw &= ~(1u << j);
             if (w) {
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restric
         {
             uint32_t li = 0, ls = 0;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
+            for (int j = 0; j < kPer; j++) {
                 if (!((inw >> j) & 1u)) continue;
-                const int i = tid * 16 + j;
+                const int i = tid * kPer + j;
                 if ((st >> j) & 1u) ls++;
                 const uint32_t tok = base_st + ls - 1;
                 const uint32_t cpos = base_in + li + tok;
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(256) void text_hash_kernel(const uint8_t* __restric
                 }
                 // token ends here if the next byte is not a word byte (or lies beyond the limit)
                 bool next_in;
-                if (j < 15) next_in = (inw >> (j + 1)) & 1u;
-                else next_in = (i + 1 < limit) && inword(c[16], c[17], (i + 2 < kTile) ? L.raw[i + 2] : 0, pretok);
+                if (j < kPer - 1) next_in = (inw >> (j + 1)) & 1u;
+                else next_in = (i + 1 < limit) && inword(c[kPer], c[kPer + 1], (i + 2 < kTile) ? L.raw[i + 2] : 0, pretok);
                 if (!next_in) L.cend[tok] = (uint16_t)(cpos + 1);
                 li++;
             }

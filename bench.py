@@ -40,6 +40,7 @@ def parse():
                          "100M; split evenly over the ranks = strong scaling). 0 skips the ANN leg")
     ap.add_argument("--ann-queries", type=int, default=4096)
     ap.add_argument("--ann-steps", type=int, default=5)
+    ap.add_argument("--cosine-rows", type=int, default=1_000_000, help="768-d f32 rows per GPU for the cosine leg; 0 skips")
     ap.add_argument("--text-docs", type=int, default=1_000_000, help="4 KiB docs per GPU (BASELINE configs[3]); 0 skips")
     ap.add_argument("--audio-seconds", type=int, default=36_000, help="seconds of 44.1 kHz audio per GPU "
                     "(BASELINE configs[2]: 10 h); 0 skips")
@@ -128,7 +129,7 @@ def bench_ann(args, rank, world, dev, ctx):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     out_ids, _, out_keys, out_cnt = out
@@ -207,6 +208,50 @@ def bench_text(args, rank, world, dev, ctx):
         res["cpu_baseline"] = {"value": 2048 / dt, "unit": "docs/s", "cores": oracle.num_threads(), "kind": "port",
                                "gpu_matches_oracle_on_sample": bool(np.array_equal(o, out[:2048].cpu().numpy()))}
     return res
+
+
+def bench_cosine(args, rank, world, dev, ctx):
+    """Secondary leg: IndexBackend::knn as the reference ships it (cosine over f32 embeddings,
+    src/index/embedded/mod.rs:268-360), 1 M x 768-d per GPU, k = 10; checked against torch on query 0."""
+    import torch
+    from ucfp_amd import index
+    n, dim, k = args.cosine_rows, 768, 10
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC05 + rank)
+    rows = torch.randn((n, dim), dtype=torch.float32, device=dev, generator=g)
+    ids = torch.arange(n, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ix = index.DeviceIndex(index.COSINE_F32, dim, index.APPEND_ONLY, ctx)
+    ix.append_dev(0, ids.data_ptr(), rows.data_ptr(), n, stream)
+    out = {}
+    for nq in (1, 256):
+        q = torch.randn((nq, dim), dtype=torch.float32, device=dev, generator=g)
+        o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        o_sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        o_key = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+
+        def step():
+            ix.search_dev(0, q.data_ptr(), nq, k, o_ids.data_ptr(), o_sc.data_ptr(), o_key.data_ptr(),
+                          o_cnt.data_ptr(), stream)
+        step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        ref = torch.nn.functional.normalize(rows, dim=1) @ torch.nn.functional.normalize(q[0], dim=0)
+        top = torch.topk(ref, k)
+        ok = bool(torch.equal(top.indices, o_ids[0])) and float((top.values - o_sc[0]).abs().max()) < 1e-5
+        out[f"batch{nq}"] = {"ms": ms, "qps": nq / ms * 1e3, "top10_matches_torch_within_1e-5": ok}
+    ix.close()
+    return {"metric": "cosine kNN queries/s (exact, k=10)", "rows_per_gpu": n, "dim": dim,
+            "value": out["batch256"]["qps"] * world, "unit": "queries/s", **out,
+            "single_query_row_GBs": n * dim * 4 / out["batch1"]["ms"] / 1e6,
+            "reference_claim": "~8 ms per query at 1M x 768 on 16 cores (REPORT.md:1233, unmeasured)"}
 
 
 def bench_audio(args, rank, world, dev, ctx):
@@ -288,10 +333,18 @@ def main():
     from ucfp_amd import _lib, image
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    # UCFP_BENCH_REHEARSAL=1: every rank uses GPU 0 and the collectives run over gloo -- lets the
+    # N > 1 code path be exercised on a one-GPU box. Never used for reported numbers.
+    rehearsal = os.environ.get("UCFP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = _lib.Context(local_rank)
     lib = _lib.load()
     n = args.frames
@@ -329,7 +382,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert int(status.abs().sum().item()) == 0, "some frames were rejected"
@@ -351,7 +404,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU, not a result)",
             "config": {
                 "workload": f"image multi (pHash+dHash+aHash bundle, 536 B/frame), {n} synthetic "
                             f"{FRAME_SIDE}x{FRAME_SIDE} GRAY8 frames per GPU resident in HBM "
@@ -384,6 +437,11 @@ def main():
         ann = bench_ann(args, rank, world, dev, ctx)
         if rank == 0:
             res["ann"] = ann
+    if args.cosine_rows > 0:
+        r = bench_cosine(args, rank, world, dev, ctx)
+        if rank == 0:
+            res["cosine"] = r
+        torch.cuda.empty_cache()
     if args.text_docs > 0:
         r = bench_text(args, rank, world, dev, ctx)
         if rank == 0:

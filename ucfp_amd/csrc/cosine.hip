@@ -7,6 +7,7 @@
 // NaN case, which the reference leaves to rayon's split order, are fixed here as "ascending
 // record_id" and "NaN scores are dropped".
 //
+// (cosine_keys has two forms: an f32 MFMA tile kernel for dim % 4 == 0, and a VALU kernel for the rest.)
 // Three steps, all streaming:
 //   cosine_norms     |v| per row, once at upsert time (rows are immutable until overwritten)
 //   cosine_keys      one pass over the rows per group of QT queries: 8 lanes share a row
@@ -124,6 +125,97 @@ __global__ __launch_bounds__(256) void cosine_keys(const float* __restrict__ row
     }
 }
 
+// ---- MFMA variant: 16 rows x (16*G queries) per wave step ---------------------------------------
+// v_mfma_f32_16x16x4_f32: A = queries (M = query, lane l: Q[l&15][k]), B = rows (N = row, lane l:
+// R[l&15][k]), k = 4 consecutive dims per lane taken from ONE float4 (global for rows, LDS for
+// queries): lane (n, q) loads R[n][16s+4q .. 16s+4q+3] and feeds element j to MFMA j, while A
+// feeds Q[m][16s+4q+j] -- the same permutation of k on both operands, so the sum is complete.
+// All 16*G query rows stay in LDS (row stride dim16 + 4 floats: ds_read_b128 conflict-free);
+// rows stream from HBM exactly once per pass, 64 B per row per instruction.  HBM-bound up to
+// G = 3 (48 queries per pass) at dim 768.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int G>
+__global__ __launch_bounds__(512) void cosine_keys_mfma(const float* __restrict__ rows,
+                                                        const float* __restrict__ norms, size_t n, uint32_t dim,
+                                                        const float* __restrict__ queries,
+                                                        const float* __restrict__ qnorm, uint32_t nq_pass,
+                                                        uint32_t* __restrict__ keys) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [16*G][dim16 + 4]
+    const uint32_t dim16 = (dim + 15) & ~15u;
+    const uint32_t qstride = dim16 + 4;
+    for (uint32_t i = threadIdx.x; i < 16u * G * qstride; i += 512) {
+        const uint32_t qt = i / qstride, c = i - qt * qstride;
+        qs[i] = (qt < nq_pass && c < dim) ? queries[(size_t)qt * dim + c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nn = lane & 15, q4 = lane >> 4;
+    const size_t tiles = (n + 15) / 16;
+    for (size_t tile = (size_t)blockIdx.x * 8 + wave; tile < tiles; tile += (size_t)gridDim.x * 8) {
+        const size_t row = tile * 16 + nn;
+        const bool live = row < n;
+        const float* __restrict__ v = rows + (live ? row : 0) * (size_t)dim;
+        f32x4v acc[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        // U row chunks (16 floats per row each) are in flight while the previous U are consumed:
+        // one block per CU (LDS holds the queries), so latency must be hidden inside the wave.
+        constexpr int U = 8;
+        float4 xa[U], xb[U];
+        auto load_chunks = [&](float4 (&x)[U], uint32_t c0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = c0 + 16 * u + 4 * q4;
+                x[u] = (live && c < dim) ? *reinterpret_cast<const float4*>(v + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto consume = [&](const float4 (&x)[U], uint32_t c0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = c0 + 16 * u + 4 * q4;
+                if (c0 + 16 * u < dim16) {  // wave-uniform
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        const float4 qa = *reinterpret_cast<const float4*>(&qs[(g * 16 + nn) * qstride + c]);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, x[u].x, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, x[u].y, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, x[u].z, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, x[u].w, acc[g], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        load_chunks(xa, 0);
+        for (uint32_t c0 = 0; c0 < dim16; c0 += 32 * U) {
+            load_chunks(xb, c0 + 16 * U);
+            consume(xa, c0);
+            load_chunks(xa, c0 + 32 * U);
+            consume(xb, c0 + 16 * U);
+        }
+        // D: col = lane&15 = row in tile, row = 4*(lane>>4) + reg = query in group
+        if (live) {
+            const float vn = norms[row];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t qt = g * 16 + 4 * q4 + r;
+                    if (qt < nq_pass) {
+                        const float qn = qnorm[qt];
+                        uint32_t key = 0xffffffffu;
+                        if (vn != 0.f && qn != 0.f) {
+                            const float sc = acc[g][r] / (qn * vn);
+                            if (sc == sc) key = score_to_key(sc);
+                        }
+                        keys[(size_t)qt * n + row] = key;
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ void cosine_scores_from_keys(const uint32_t* __restrict__ keys, size_t total, float* __restrict__ scores) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) scores[i] = keys[i] == 0xffffffffu ? -2.0f : key_to_score(keys[i]);
@@ -135,8 +227,23 @@ int launch_cosine_norms(const float* rows, size_t n, uint32_t dim, float* norms,
     return 0;
 }
 
-// queries per corpus pass: kQT, or fewer when kQT query rows do not fit 144 KiB of LDS
+namespace {
+// groups of 16 queries whose rows (stride dim16 + 4 floats) fit 156 KiB of LDS, at most 3
+int mfma_groups(uint32_t dim) {
+    const uint32_t dim16 = (dim + 15) & ~15u;
+    const size_t per_group = 16 * (size_t)(dim16 + 4) * sizeof(float);
+    const size_t g = (156u * 1024u) / per_group;
+    return (int)(g > 3 ? 3 : g);
+}
+bool mfma_ok(const float* rows, uint32_t dim) {
+    return dim % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15u) == 0 && mfma_groups(dim) >= 1;
+}
+}  // namespace
+
+// queries per corpus pass. MFMA path (dim % 4 == 0): 16 per LDS-resident group, up to 48;
+// VALU path: kQT, or fewer when kQT query rows do not fit 144 KiB of LDS
 int cosine_queries_per_pass(uint32_t dim) {
+    if (dim % 4 == 0 && mfma_groups(dim) >= 1) return 16 * mfma_groups(dim);
     const uint32_t dim4 = (dim + 3) & ~3u;
     const size_t fit = (144u * 1024u) / ((size_t)dim4 * sizeof(float));
     return (int)(fit < (size_t)kQT ? fit : (size_t)kQT);
@@ -145,6 +252,25 @@ int cosine_queries_per_pass(uint32_t dim) {
 int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                        const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream) {
     if (n == 0 || nq_pass == 0) return 0;
+    if (mfma_ok(rows, dim)) {
+        const int G = (int)((nq_pass + 15) / 16);  // <= mfma_groups(dim) by construction of the pass size
+        const uint32_t dim16 = (dim + 15) & ~15u;
+        const size_t lds = (size_t)16 * G * (dim16 + 4) * sizeof(float);
+        const size_t tiles = (n + 15) / 16;
+        unsigned grid = (unsigned)((tiles + 7) / 8);
+        if (grid > 256 * 4) grid = 256 * 4;
+        auto go = [&](auto kern) {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass,
+                               keys);
+        };
+        if (G == 1) go(cosine_keys_mfma<1>);
+        else if (G == 2) go(cosine_keys_mfma<2>);
+        else go(cosine_keys_mfma<3>);
+        return 0;
+    }
     const uint32_t dim4 = (dim + 3) & ~3u;
     const size_t lds = (size_t)nq_pass * dim4 * sizeof(float);
     if (lds > 48 * 1024)

@@ -32,6 +32,10 @@ def all_gather_topk(ids: torch.Tensor, keys: torch.Tensor, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return ids.unsqueeze(0).contiguous(), keys.unsqueeze(0).contiguous()
+    if ids.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal mode (several ranks sharing one GPU over gloo): stage through the host
+        g_ids, g_keys = all_gather_topk(ids.cpu(), keys.cpu(), group)
+        return g_ids.to(ids.device), g_keys.to(keys.device)
     nq = ids.shape[0]
     # concatenation along dim 0 in rank order == [world][nq][k] row-major
     g_ids = torch.empty((world * nq,) + tuple(ids.shape[1:]), dtype=ids.dtype, device=ids.device)

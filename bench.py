@@ -40,6 +40,7 @@ def parse():
                          "100M; split evenly over the ranks = strong scaling). 0 skips the ANN leg")
     ap.add_argument("--ann-queries", type=int, default=4096)
     ap.add_argument("--ann-steps", type=int, default=5)
+    ap.add_argument("--rgb-frames", type=int, default=30_000, help="RGB8 512x512 frames for the RGB variant; 0 skips")
     ap.add_argument("--cosine-rows", type=int, default=1_000_000, help="768-d f32 rows per GPU for the cosine leg; 0 skips")
     ap.add_argument("--text-docs", type=int, default=1_000_000, help="4 KiB docs per GPU (BASELINE configs[3]); 0 skips")
     ap.add_argument("--audio-seconds", type=int, default=36_000, help="seconds of 44.1 kHz audio per GPU "
@@ -387,6 +388,30 @@ def main():
         elapsed = float(t.item())
     assert int(status.abs().sum().item()) == 0, "some frames were rejected"
 
+    # ---- RGB8 variant of the same workload ("also report RGB8"): 786 432 B/frame ----
+    rgb = None
+    if args.rgb_frames > 0:
+        nr = args.rgb_frames
+        rgbf = torch.empty((nr, FRAME_SIDE, FRAME_SIDE * 3), dtype=torch.uint8, device=dev)
+        _lib.check(lib.ucfp_image_synth_dev(ctx.handle, rgbf.data_ptr(), nr, FRAME_SIDE * 3, FRAME_SIDE, 0, stream))
+        rout = torch.empty((nr, REC_BYTES), dtype=torch.uint8, device=dev)
+
+        def rstep():
+            image.fingerprint_frames_dev(rgbf.data_ptr(), nr, FRAME_SIDE, FRAME_SIDE, algo=image.MULTI,
+                                         pixfmt=image.PIX_RGB8, out_ptr=rout.data_ptr(), stream=stream, ctx=ctx)
+        rstep()
+        torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        for _ in range(5):
+            rstep()
+        r1.record()
+        torch.cuda.synchronize()
+        rms = r0.elapsed_time(r1) / 5
+        rgb = {"frames": nr, "ms_per_launch": rms, "fingerprints_per_s": nr / rms * 1e3,
+               "achieved_GBs": nr * (FRAME_SIDE * FRAME_SIDE * 3 + REC_BYTES) / rms / 1e6,
+               "frac_of_hbm_peak": nr * (FRAME_SIDE * FRAME_SIDE * 3 + REC_BYTES) / rms / 1e6 / HBM_PEAK_GBS}
+        del rgbf, rout
     if rank == 0:
         total_frames = n * world * args.steps
         value = total_frames / elapsed
@@ -422,6 +447,7 @@ def main():
                 "traffic": traffic_from_profiles(n) if args.traffic_bytes is None else args.traffic_bytes,
             },
         }
+        res["rgb8_variant"] = rgb
         res["ann"] = None
         if args.cpu_sample > 0 and world == 1:
             head = out[:min(args.cpu_sample, n)].cpu().numpy()

@@ -19,6 +19,14 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t s0, uint32_t s1
                 acc[j] += __builtin_popcount(a) + __builtin_popcount(b);
             } else if (MODE == 1) {  // xor only (2 ops + add)
                 acc[j] += (q0 ^ (sa + j)) ^ (q1 ^ (sb + j));
+            } else if (MODE == 3) {  // v_dot4_u32_u8, 8 independent accumulators
+                acc[j] = __builtin_amdgcn_udot4(q0 + j, q1, acc[j], false);
+            } else if (MODE == 4) {  // v_alignbyte_b32
+                acc[j] += __builtin_amdgcn_alignbyte(q0, acc[j], (uint32_t)(j & 3));
+            } else if (MODE == 5) {  // v_mad_u64_u32 (64-bit accumulate)
+                unsigned long long t = ((unsigned long long)acc[(j + 1) & 7] << 32) | acc[j];
+                t = (unsigned long long)(q0 + j) * q1 + t;
+                acc[j] = (uint32_t)t ^ (uint32_t)(t >> 32);
             } else {  // fma f32 reference: 1 op
                 float f = __uint_as_float(acc[j]);
                 f = fmaf(f, 1.0001f, 0.5f);
@@ -61,5 +69,8 @@ int main() {
     run<0>("xor,xor,bcnt,bcnt(+acc)", 4, 4000);
     run<1>("xor,xor,xor,add", 4, 4000);
     run<2>("fma_f32", 1, 16000);
+    run<3>("dot4_u32_u8 (acc chain x8)", 1, 16000);
+    run<4>("alignbyte + add", 2, 8000);
+    run<5>("mad_u64_u32 + xor", 2, 8000);
     return 0;
 }

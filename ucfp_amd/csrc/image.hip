@@ -429,6 +429,110 @@ __global__ __launch_bounds__(256) void image_hash_gray_kernel(
                          out + img * (algo == 7u ? 536 : 168));
 }
 
+// ---- fused kernel: RGB8 / RGBA8 frames of 512 x 512 (S = 2) ------------------------------------
+// Colour pixels are 3 or 4 bytes, so the 16-pixel-per-lane tiling of the GRAY8 kernel would make
+// every load instruction touch 64 scattered 16-byte pieces.  Here a LANE OWNS A STRIP of 4 source
+// pixels (= 2 normalised pixels) and walks down the rows: one load instruction reads 64 lanes x
+// 12 (RGB, global_load_dwordx3) or 16 bytes = 768 / 1024 CONTIGUOUS bytes of one row.
+// Waves 0,1 cover strips 0..127 of rows 0..255, waves 2,3 rows 256..511.  Per 16-row band a lane
+// produces its 4 s2 values, 2 v8 column sums, and (4 lanes together) one 8x8 tile total.
+// Luma (spec I1) is v_dot4_u32_u8 with the weights {77,150,29} shifted to where a pixel's bytes
+// sit inside the dword(s) -- no byte gathering.
+template <int BPP>
+struct StripRow {
+    uint32_t w[BPP];  // 4 pixels = 12 or 16 bytes
+};
+
+template <int BPP>
+__device__ __forceinline__ StripRow<BPP> load_strip(const uint8_t* __restrict__ p) {
+    StripRow<BPP> r;
+    if (BPP == 3) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const u32x3*>(p));
+        r.w[0] = v.x;
+        r.w[1] = v.y;
+        r.w[2] = v.z;
+    } else {
+        const uint4 v = load_frame16(p);
+        r.w[0] = v.x;
+        r.w[1] = v.y;
+        r.w[2] = v.z;
+        r.w[BPP - 1] = v.w;
+    }
+    return r;
+}
+
+// sum of the lumas of pixels {0,1} and of pixels {2,3} of one strip row
+template <int BPP>
+__device__ __forceinline__ void strip_luma_pairs(const StripRow<BPP>& r, uint32_t& p01, uint32_t& p23) {
+    constexpr uint32_t W = 0x001D964Du;  // bytes: R*77, G*150, B*29, (4th)*0
+    uint32_t l0, l1, l2, l3;
+    if (BPP == 4) {
+        l0 = __builtin_amdgcn_udot4(r.w[0], W, 128u, false) >> 8;
+        l1 = __builtin_amdgcn_udot4(r.w[1], W, 128u, false) >> 8;
+        l2 = __builtin_amdgcn_udot4(r.w[2], W, 128u, false) >> 8;
+        l3 = __builtin_amdgcn_udot4(r.w[BPP - 1], W, 128u, false) >> 8;
+    } else {
+        // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+        l0 = __builtin_amdgcn_udot4(r.w[0], W, 128u, false) >> 8;
+        l1 = __builtin_amdgcn_udot4(r.w[1], W >> 8, __builtin_amdgcn_udot4(r.w[0], W << 24, 128u, false), false) >> 8;
+        l2 = __builtin_amdgcn_udot4(r.w[2], W >> 16, __builtin_amdgcn_udot4(r.w[1], W << 16, 128u, false), false) >> 8;
+        l3 = __builtin_amdgcn_udot4(r.w[2], W << 8, 128u, false) >> 8;
+    }
+    p01 = l0 + l1;
+    p23 = l2 + l3;
+}
+
+template <int BPP>
+__global__ __launch_bounds__(256) void image_hash_color512_kernel(
+    const uint8_t* __restrict__ frames, size_t n, size_t row_stride, size_t frame_stride,
+    uint32_t algo, const uint8_t* __restrict__ exact, uint8_t* __restrict__ out,
+    int32_t* __restrict__ status) {
+    __shared__ ImageLds L;
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sx = 64 * (wave & 1) + lane;           // strip 0..127
+    const int band0 = 16 * (wave >> 1);              // first 16-row band (tile row) of this wave
+    const uint8_t* __restrict__ col = frames + img * frame_stride + (size_t)(4 * BPP * sx);
+#pragma unroll 1
+    for (int b = 0; b < 16; b++) {
+        const int ty = band0 + b;
+        const uint8_t* p = col + (size_t)(16 * ty) * row_stride;
+        StripRow<BPP> rows[16];
+#pragma unroll
+        for (int y = 0; y < 16; y++) rows[y] = load_strip<BPP>(p + (size_t)y * row_stride);
+        uint32_t c0 = 0, c1 = 0;  // column sums of the two normalised columns over the band
+#pragma unroll
+        for (int j2 = 0; j2 < 4; j2++) {
+            uint32_t n0[2], n1[2];  // normalised pixels of rows 2*j2, 2*j2+1
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t a01, a23, b01, b23;
+                strip_luma_pairs<BPP>(rows[4 * j2 + 2 * h], a01, a23);
+                strip_luma_pairs<BPP>(rows[4 * j2 + 2 * h + 1], b01, b23);
+                n0[h] = (a01 + b01 + 2u) >> 2;
+                n1[h] = (a23 + b23 + 2u) >> 2;
+            }
+            c0 += n0[0] + n0[1];
+            c1 += n1[0] + n1[1];
+            L.s2[(4 * ty + j2) * 128 + sx] = (uint8_t)((n0[0] + n0[1] + n1[0] + n1[1] + 2u) >> 2);
+        }
+        reinterpret_cast<uint32_t*>(L.v8)[ty * 128 + sx] = c0 | (c1 << 16);
+        uint32_t tot = c0 + c1;
+        tot += __shfl_xor(tot, 1, 64);
+        tot += __shfl_xor(tot, 2, 64);
+        if ((lane & 3) == 0) {
+            L.gsum[ty * 32 + (sx >> 2)] = (uint16_t)tot;
+            L.g32[ty * 32 + (sx >> 2)] = (uint8_t)((tot + 32u) >> 6);
+        }
+    }
+    __syncthreads();
+    if (status && tid == 0) status[img] = 0;
+    hash_phase_and_store(L, algo, exact ? exact + 32 * img : nullptr,
+                         out + img * (algo == 7u ? 536 : 168));
+}
+
 // ---- generic path, step 1: any geometry / pixel format -> 256x256 normalised plane ----------
 // grid (256, n): block = one normalised row, thread = one normalised pixel (spec I1 + I3).
 __global__ __launch_bounds__(256) void image_normalize_kernel(
@@ -533,6 +637,17 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
         else
             hipLaunchKernelGGL(image_hash_gray_kernel<4>, grid, block, 0, stream, frames, n,
                                row_stride, frame_stride, algo, exact, out, status);
+        return 0;
+    }
+    if (S == 2 && ((pixfmt == 2 && aligned16(frames, row_stride, frame_stride)) ||
+                   (pixfmt == 1 && (((uintptr_t)frames | row_stride | frame_stride) & 3u) == 0))) {
+        dim3 grid((unsigned)n), block(256);
+        if (pixfmt == 1)
+            hipLaunchKernelGGL(image_hash_color512_kernel<3>, grid, block, 0, stream, frames, n, row_stride,
+                               frame_stride, algo, exact, out, status);
+        else
+            hipLaunchKernelGGL(image_hash_color512_kernel<4>, grid, block, 0, stream, frames, n, row_stride,
+                               frame_stride, algo, exact, out, status);
         return 0;
     }
     // generic: normalise into the workspace in chunks, then hash the 256x256 planes (S = 1).

@@ -7,9 +7,8 @@
 // library is built with -ffp-contract=off), so the integer outputs are bit-identical.
 //
 //   resample_linear   A1   one thread per output sample
-//   stft_power<N>     A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT held in
-//                          LDS (8/16 KiB per wave, twiddles in LDS), butterflies of a stage are
-//                          independent so the wave runs them 64 at a time with no block barrier;
+//   stft_power<N>     A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT, 16/32 points
+//                          per lane in registers, two LDS transposes, no block barrier;
 //                          Wang: power spectrum to HBM; Haitsma: 33 band energies per frame
 //   (stft epilogue)/cand A5 separable neighbourhood maximum, then the exact tie rule only on the
 //                          (rare) cells that equal their window maximum
@@ -50,22 +49,132 @@ __global__ void resample_linear_kernel(const float* __restrict__ in, size_t n, u
     out[i] = x0 + mm;
 }
 
-// ---- A2/A3: one wave per frame ---------------------------------------------------------------
+// ---- A2/A3: one wave per frame, FFT register-tiled ------------------------------------------------
+// N = 64 * E points, E = 16 (Wang, N = 1024) or 32 (Haitsma, N = 2048) complex values per lane.
+// The radix-2 DIT butterflies are EXACTLY those of the oracle (same operands, same f32 ops), only
+// their placement changes: a lane keeps E points in registers and runs every stage whose partner
+// distance stays inside its E points, then the wave transposes through LDS:
+//   phase 1  lane L holds p = E*L + i           -> stages 1..B        (B = log2 E), twiddles constant
+//   phase 2  lane (hi, lo) holds p = hi*E*E + m*E + lo  -> stages B+1..2B
+//   phase 3  lane l holds p = e*64 + l          -> stages 2B+1..log2 N
+// Two LDS transposes (padded: p + p/E) replace the ten LDS round trips of a stage-by-stage FFT.
 template <int N>
 struct FftLds {
     float tw[1024][2];
-    float re[4][N];
-    float im[4][N];
-    float band[4][64];
+    float2 buf[4][N + 64];   // per wave; reused as the power spectrum (float[N/2]) afterwards
 };
+
+__device__ __forceinline__ void bfly(float& ur, float& ui, float& xr, float& xi, float c, float sn) {
+    const float t1 = xr * c, t2 = xi * sn, t3 = xr * sn, t4 = xi * c;
+    const float vr = t1 - t2, vi = t3 + t4;
+    const float ar = ur, ai = ui;
+    ur = ar + vr;
+    ui = ai + vi;
+    xr = ar - vr;
+    xi = ai - vi;
+}
+
+template <int N>
+__device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, int lane, float (*tw)[2],
+                                               float2* __restrict__ buf) {
+    constexpr int E = N / 64;
+    constexpr int B = E == 16 ? 4 : 5;
+    constexpr int BITS = N == 1024 ? 10 : 11;
+    constexpr int TWS = 2048 / N;
+    float xr[E], xi[E];
+    // ---- load + window, element i of lane L is p = E*L + i = bit-reversed sample index ----
+    const uint32_t rl = __brev((uint32_t)lane) >> 26;  // 6-bit reversal of the lane
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const uint32_t ri = __brev((uint32_t)i) >> (32 - B);   // compile-time after unrolling
+        const uint32_t n = (ri << 6) | rl;
+        float c = tw[(n * TWS) & 1023][0];
+        if (n * TWS >= 1024) c = -c;
+        const float w = 0.5f - 0.5f * c;
+        xr[i] = src[n] * w;
+        xi[i] = 0.0f;
+    }
+    // ---- phase 1: stages 1..B on bits 0..B-1 (register index), twiddles are table constants ----
+#pragma unroll
+    for (int st = 1; st <= B; st++) {
+        const int half = 1 << (st - 1), tstep = 2048 >> st;
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0++) {
+            if (i0 & half) continue;
+            const int jj = i0 & (half - 1);
+            bfly(xr[i0], xi[i0], xr[i0 + half], xi[i0 + half], c_tw[jj * tstep][0], c_tw[jj * tstep][1]);
+        }
+    }
+    // ---- transpose 1 ----
+#pragma unroll
+    for (int i = 0; i < E; i++) buf[(E + 1) * lane + i] = make_float2(xr[i], xi[i]);   // p + p/E, p = E*lane + i
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int lo = lane & (E - 1), hi = lane >> B;
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int pp = hi * E * E + m * E + lo;
+        const float2 v = buf[pp + (pp >> B)];
+        xr[m] = v.x;
+        xi[m] = v.y;
+    }
+    // ---- phase 2: stages B+1..2B on bits B..2B-1 (register index m) ----
+#pragma unroll
+    for (int st = B + 1; st <= 2 * B; st++) {
+        const int halfm = 1 << (st - B - 1), tstep = 2048 >> st;
+#pragma unroll
+        for (int m0 = 0; m0 < E; m0++) {
+            if (m0 & halfm) continue;
+            const int jj = ((m0 & (halfm - 1)) << B) | lo;
+            bfly(xr[m0], xi[m0], xr[m0 + halfm], xi[m0 + halfm], tw[jj * tstep][0], tw[jj * tstep][1]);
+        }
+    }
+    // ---- transpose 2 (own slots back, then gather p = e*64 + lane) ----
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int pp = hi * E * E + m * E + lo;
+        buf[pp + (pp >> B)] = make_float2(xr[m], xi[m]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int pp = e * 64 + lane;
+        const float2 v = buf[pp + (pp >> B)];
+        xr[e] = v.x;
+        xi[e] = v.y;
+    }
+    // ---- phase 3: stages 2B+1..BITS on bits 2B.. (register index e, bit st-1-6) ----
+#pragma unroll
+    for (int st = 2 * B + 1; st <= BITS; st++) {
+        const int halfe = 1 << (st - 1 - 6), tstep = 2048 >> st;
+#pragma unroll
+        for (int e0 = 0; e0 < E; e0++) {
+            if (e0 & halfe) continue;
+            const int jj = ((e0 & (halfe - 1)) << 6) | lane;
+            bfly(xr[e0], xi[e0], xr[e0 + halfe], xi[e0 + halfe], tw[jj * tstep][0], tw[jj * tstep][1]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- power spectrum, bins k = e*64 + lane < N/2, into the (now free) buffer as float[N/2] ----
+    float* pw = reinterpret_cast<float*>(buf);
+#pragma unroll
+    for (int e = 0; e < E / 2; e++) {
+        const float a = xr[e] * xr[e], b = xi[e] * xi[e];
+        pw[e * 64 + lane] = a + b;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <int N, bool HAITSMA>
 __global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict__ x, size_t first_frame,
                                                          size_t n_frames, int hop, float* __restrict__ out,
                                                          const uint32_t* __restrict__ edges,
                                                          float* __restrict__ rowmax_out) {
-    constexpr int BITS = N == 1024 ? 10 : 11;
-    constexpr int TWS = 2048 / N;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     FftLds<N>& L = *reinterpret_cast<FftLds<N>*>(lds_raw);
     for (int i = threadIdx.x; i < 1024; i += 256) {
@@ -74,79 +183,35 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* re = L.re[wave];
-    float* im = L.im[wave];
+    float2* buf = L.buf[wave];
+    const float* pw = reinterpret_cast<const float*>(buf);
     // frames are dealt to waves round-robin over the whole grid
     for (size_t f = (size_t)blockIdx.x * 4 + wave; f < n_frames; f += (size_t)gridDim.x * 4) {
-        const float* src = x + (first_frame + f) * (size_t)hop;
-#pragma unroll 4
-        for (int n = lane; n < N; n += 64) {
-            float c = L.tw[(n * TWS) & 1023][0];
-            if (n * TWS >= 1024) c = -c;
-            const float w = 0.5f - 0.5f * c;
-            const uint32_t r = __brev((uint32_t)n) >> (32 - BITS);
-            re[r] = src[n] * w;
-            im[r] = 0.0f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int s = 1; s <= BITS; s++) {
-            const int half = 1 << (s - 1), tstep = 2048 >> s;
-#pragma unroll 4
-            for (int bf = lane; bf < N / 2; bf += 64) {
-                const int j = bf & (half - 1);
-                const int i0 = ((bf >> (s - 1)) << s) + j, i1 = i0 + half;
-                const float c = L.tw[j * tstep][0], sn = L.tw[j * tstep][1];
-                const float xr = re[i1], xi = im[i1];
-                const float t1 = xr * c, t2 = xi * sn, t3 = xr * sn, t4 = xi * c;
-                const float vr = t1 - t2, vi = t3 + t4;
-                const float ur = re[i0], ui = im[i0];
-                re[i0] = ur + vr;
-                im[i0] = ui + vi;
-                re[i1] = ur - vr;
-                im[i1] = ui - vi;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
+        wave_fft_power<N>(x + (first_frame + f) * (size_t)hop, lane, L.tw, buf);
         if (!HAITSMA) {
             // power spectrum to HBM and, while the frame is still in LDS, its +-kRK-bin running
             // maximum (the row half of the separable peak neighbourhood)
             float* o = out + f * (size_t)(N / 2);
-#pragma unroll 4
-            for (int k = lane; k < N / 2; k += 64) {
-                const float a = re[k] * re[k], b = im[k] * im[k];
-                const float pw = a + b;
-                o[k] = pw;
-                im[k] = pw;   // im[0..N/2) is dead after this read (same lane, same k)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
             float* ro = rowmax_out + f * (size_t)(N / 2);
+#pragma unroll 2
             for (int k = lane; k < N / 2; k += 64) {
                 // fixed 31 taps with clamped indices (duplicates do not change a maximum): the LDS
                 // reads are independent, so their latency overlaps instead of adding up
-                float m = im[k];
+                const float pk = pw[k];
+                float m = pk;
 #pragma unroll
                 for (int d = 1; d <= kRK; d++) {
                     const int lo = k - d < 0 ? 0 : k - d, hi = k + d > N / 2 - 1 ? N / 2 - 1 : k + d;
-                    m = fmaxf(m, fmaxf(im[lo], im[hi]));
+                    m = fmaxf(m, fmaxf(pw[lo], pw[hi]));
                 }
+                o[k] = pk;
                 ro[k] = m;
             }
         } else {
-            // power into re[] (in place), then lane b sums band b sequentially (same order as the oracle)
-#pragma unroll 4
-            for (int k = lane; k < N / 2; k += 64) {
-                const float a = re[k] * re[k], b = im[k] * im[k];
-                re[k] = a + b;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            // lane b sums band b sequentially (same order as the oracle)
             if (lane < kHkBands) {
                 float e = 0.0f;
-                for (uint32_t k = edges[lane]; k < edges[lane + 1]; k++) e = e + re[k];
+                for (uint32_t k = edges[lane]; k < edges[lane + 1]; k++) e = e + pw[k];
                 out[f * (size_t)kHkBands + lane] = e;
             }
         }

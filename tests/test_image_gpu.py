@@ -204,3 +204,74 @@ def test_properties_at_batch_geometry(gpu_ctx, torch_cuda):
     # hashes are not degenerate on this workload
     glob = a[:, 32 + 168 + 32:32 + 168 + 40]
     assert len({bytes(g) for g in glob}) > 8
+
+
+def test_strided_and_unaligned_frames_dev(gpu_ctx, oracle, torch_cuda):
+    """Row/frame strides with padding, and a base pointer that is not 16-byte aligned (falls back
+    to the generic normalise path): same records as the dense layout."""
+    torch = torch_cuda
+    from ucfp_amd import image
+    rng = np.random.default_rng(21)
+    n, side = 6, 512
+    fr = _frames(rng, n, side, side, kind="smooth")
+    ref, _ = oracle.image_hash_batch(fr, 7)
+    stream = torch.cuda.current_stream().cuda_stream
+    # (a) padded rows and frames, still 16-byte aligned -> fused path
+    rs, fs = side + 64, (side + 64) * (side + 3)
+    buf = torch.zeros(n * fs + 64, dtype=torch.uint8, device="cuda")
+    view = buf[: n * fs].view(n, fs)[:, : side * rs].view(n, side, rs)
+    view[:, :, :side] = torch.from_numpy(fr).cuda()
+    out = torch.zeros((n, 536), dtype=torch.uint8, device="cuda")
+    image.fingerprint_frames_dev(buf.data_ptr(), n, side, side, row_stride=rs, frame_stride=fs, out_ptr=out.data_ptr(),
+                                 stream=stream, ctx=gpu_ctx)
+    torch.cuda.synchronize()
+    _assert_same(out.cpu().numpy(), ref, "padded strides")
+    # (b) base pointer offset by 5 bytes, odd row stride -> generic path
+    rs2, fs2 = side + 7, (side + 7) * side + 11
+    buf2 = torch.zeros(n * fs2 + 64, dtype=torch.uint8, device="cuda")
+    v2 = buf2[5: 5 + n * fs2].view(n, fs2)[:, : side * rs2].view(n, side, rs2)
+    v2[:, :, :side] = torch.from_numpy(fr).cuda()
+    out2 = torch.zeros((n, 536), dtype=torch.uint8, device="cuda")
+    image.fingerprint_frames_dev(buf2.data_ptr() + 5, n, side, side, row_stride=rs2, frame_stride=fs2,
+                                 out_ptr=out2.data_ptr(), stream=stream, ctx=gpu_ctx)
+    torch.cuda.synchronize()
+    _assert_same(out2.cpu().numpy(), ref, "unaligned base")
+
+
+def test_large_generic_batch_crosses_workspace_chunks(gpu_ctx, oracle):
+    """More frames than the 256-plane normalise workspace holds (generic path chunks the batch)."""
+    rng = np.random.default_rng(22)
+    fr = _frames(rng, 300, 96, 80)
+    gpu, st = _gpu_host(fr, 7)
+    ref, _ = oracle.image_hash_batch(fr, 7)
+    assert not st.any()
+    _assert_same(gpu, ref, "generic 300 frames")
+
+
+def test_encoded_image_adapters(gpu_ctx, oracle):
+    """The reference's call shape: encoded bytes in, Record out (src/modality/image.rs:56-194), with
+    `exact` = BLAKE3 of the upload and Error::Modality on undecodable input."""
+    import io
+    from PIL import Image
+    from ucfp_amd import image
+    from ucfp_amd.blake3 import blake3_digest
+    from ucfp_amd.errors import ModalityError
+    yy, xx = np.mgrid[0:256, 0:256]
+    px = np.stack([xx % 256, yy % 256, np.full_like(xx, 128)], axis=-1).astype(np.uint8)   # benches/end_to_end.rs:77-85
+    bio = io.BytesIO()
+    Image.fromarray(px, "RGB").save(bio, format="PNG")
+    png = bio.getvalue()
+    rec = image.fingerprint(png, 7, 42)
+    assert rec.algorithm == "imgfprint-multihash-v1" and rec.tenant_id == 7 and rec.record_id == 42
+    assert rec.config_hash == 0 and rec.format_version == 1 and len(rec.fingerprint) == 536
+    ex = np.frombuffer(blake3_digest(png), np.uint8)[None]
+    ref, _ = oracle.image_hash_batch(px[None], 7, pixfmt=1, exact=ex)
+    assert rec.fingerprint == ref[0].tobytes()
+    ph = image.fingerprint_phash(png, image.PreprocessConfig(), 7, 42)
+    assert ph.algorithm == "imgfprint-phash-v1" and ph.fingerprint == ref[0, 200:368].tobytes()
+    with pytest.raises(ModalityError):
+        image.fingerprint(b"not an image", 0, 0)
+    with pytest.raises(ModalityError):
+        image.fingerprint_with(png, 0, 0, image.PreprocessConfig(min_dimension=512))
+    with pytest.raises(ModalityError):
+        image.fingerprint_with(png, 0, 0, image.PreprocessConfig(max_input_bytes=10))

@@ -88,7 +88,7 @@ def cpu_baseline(sample: int, gpu_records_head):
     }
 
 
-def bench_ann(args, rank, world, dev, ctx):
+def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
     """Secondary leg (BASELINE configs[4]): /v1/query Hamming k=10 over a corpus sharded across
     the ranks, one all-gather of per-shard top-k, merge on every rank. Returns a dict (rank 0)."""
     import torch
@@ -96,7 +96,8 @@ def bench_ann(args, rank, world, dev, ctx):
     from ucfp_amd import index, sharded
 
     k, nq = 10, args.ann_queries
-    start, end = sharded.shard_range(args.ann_corpus, rank, world)
+    corpus_total = corpus_total or args.ann_corpus
+    start, end = sharded.shard_range(corpus_total, rank, world)
     n_local = end - start
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED + rank)
@@ -138,7 +139,7 @@ def bench_ann(args, rank, world, dev, ctx):
     if rank != 0:
         return None
     qps = nq * args.ann_steps / dt
-    pairs_per_s = qps * args.ann_corpus
+    pairs_per_s = qps * corpus_total
     # un-packed 32-bit VALU: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-op/s (the 157.3 TF
     # datasheet figure counts packed FMA); tools/ubench_valu.hip measures 35-41 T on this chip
     # (profiles/r01/ubench_valu.txt). The scan issues 73 VALU ops per 16 code-query pairs per lane.
@@ -146,7 +147,7 @@ def bench_ann(args, rank, world, dev, ctx):
     ops_per_pair = 73.0 / 16.0
     return {
         "metric": "ANN queries/sec (Hamming k=10, brute force, exact)", "value": qps, "unit": "queries/s",
-        "corpus_total": args.ann_corpus, "corpus_per_gpu": n_local, "queries_per_batch": nq, "k": k,
+        "corpus_total": corpus_total, "corpus_per_gpu": n_local, "queries_per_batch": nq, "k": k,
         "ms_per_batch": dt / args.ann_steps * 1e3, "scaling": "strong",
         "exchange": "one all-gather of nq*k*(8+4) B per rank + merge on every rank" if world > 1 else "none",
         "pairs_per_s": pairs_per_s,
@@ -463,6 +464,11 @@ def main():
         ann = bench_ann(args, rank, world, dev, ctx)
         if rank == 0:
             res["ann"] = ann
+        torch.cuda.empty_cache()
+        # the size BASELINE.json's metric string quotes ("ANN queries/sec @10M corpus")
+        ann10 = bench_ann(args, rank, world, dev, ctx, corpus_total=10_000_000)
+        if rank == 0:
+            res["ann_10m"] = ann10
     if args.cosine_rows > 0:
         r = bench_cosine(args, rank, world, dev, ctx)
         if rank == 0:

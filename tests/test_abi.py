@@ -82,3 +82,26 @@ def test_product_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), (dp, fn)
                 assert not re.search(r'#include\s*"[^"]*oracle', txt), (dp, fn)
                 assert "libucfp_oracle" not in txt, (dp, fn)
+
+
+def test_host_only_entry_points_need_no_gpu():
+    """Sizing helpers and argument validation run on the host: usable (and testable) without a device."""
+    lib = _lib.load()
+    cfg = _lib.WangConfig(10, 63, 64, 30, -50.0)
+    # 10 s at 8 kHz: 618 frames -> 10 one-second buckets -> 10 * 30 peaks * 10 targets
+    assert lib.ucfp_audio_wang_max_hashes(80000, C.byref(cfg)) == 10 * 30 * 10
+    assert lib.ucfp_audio_wang_max_hashes(1000, C.byref(cfg)) == 0          # shorter than one frame
+    assert lib.ucfp_audio_resample_len(44100, 44100, 8000) == 8000
+    assert lib.ucfp_audio_resample_len(44101, 44100, 5000) == 5000
+    assert lib.ucfp_audio_haitsma_frames(5000 * 10, 5000) == 1 + (50000 - 2048) // 64
+    assert lib.ucfp_audio_haitsma_frames(8000 * 10, 8000) == 1 + (50000 - 2048) // 64   # resampled to 5 kHz
+    assert lib.ucfp_audio_haitsma_frames(100, 5000) == 0
+    # NULL context / bad enums are rejected before any device call
+    out = (C.c_uint8 * 536)()
+    assert lib.ucfp_image_hash_batch(None, 7, out, 1, 64, 64, 64, 4096, 0, None, None, out, None) == -4
+    assert b"ctx" in lib.ucfp_last_error()
+    assert lib.ucfp_text_minhash_batch(None, None, None, 0, 0, 5, None, None) == -4
+    n = C.c_size_t(0)
+    assert lib.ucfp_audio_wang(None, None, 0, 8000, None, None, 0, C.byref(n)) == -4
+    assert lib.ucfp_index_create(None, 1, 0, 0, C.byref(C.c_void_p())) == -4
+    assert lib.ucfp_blake3(None, 5, out) == -4

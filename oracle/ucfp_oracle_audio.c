@@ -138,8 +138,10 @@ float ucfp_oracle_wang_floor_power(float db) { return (float)(65536.0 * pow(10.0
 /* A5: peaks (time-sorted). Returns count; out may be NULL to count only. */
 size_t ucfp_oracle_wang_peaks(const float* P, size_t T, uint32_t peaks_per_sec, uint32_t* out_t, uint32_t* out_k,
                               float* out_p) {
-    peak_t* cand = (peak_t*)malloc(sizeof(peak_t) * (T * 40 + 64));
-    size_t nc = 0;
+    /* candidate flags in parallel over frames (the test of a cell is independent of the others),
+     * then a sequential gather in (t, k) order */
+    uint8_t* flag = (uint8_t*)calloc(T * WANG_BINS + 1, 1);
+#pragma omp parallel for schedule(dynamic, 16)
     for (size_t t = 0; t < T; t++)
         for (int k = 0; k < WANG_BINS; k++) {
             const float v = P[t * WANG_BINS + k];
@@ -158,13 +160,19 @@ size_t ucfp_oracle_wang_peaks(const float* P, size_t T, uint32_t peaks_per_sec, 
                         break;
                     }
                 }
-            if (ok) {
+            flag[t * WANG_BINS + k] = (uint8_t)ok;
+        }
+    peak_t* cand = (peak_t*)malloc(sizeof(peak_t) * (T * 40 + 64));
+    size_t nc = 0;
+    for (size_t t = 0; t < T; t++)
+        for (int k = 0; k < WANG_BINS; k++)
+            if (flag[t * WANG_BINS + k]) {
                 cand[nc].t = (uint32_t)t;
                 cand[nc].k = (uint32_t)k;
-                cand[nc].p = v;
+                cand[nc].p = P[t * WANG_BINS + k];
                 nc++;
             }
-        }
+    free(flag);
     /* per-second cap: second = floor(t * hop / sr) */
     size_t np = 0, i = 0;
     peak_t* sel = (peak_t*)malloc(sizeof(peak_t) * (nc + 1));

@@ -58,14 +58,24 @@ def test_wang_config_variants(gpu_ctx, oracle):
         assert np.array_equal(g, o)
 
 
-def test_wang_long_stream_crosses_chunks(gpu_ctx, oracle):
-    """> 32768 frames (~70 min) would be slow on the oracle; instead check chunk-invariance with the
-    stage probes: a 75 s signal through the product path vs the oracle."""
+@pytest.mark.parametrize("seconds", [75.0, 530.0, 1100.0])
+def test_wang_long_stream_crosses_chunks(gpu_ctx, oracle, seconds):
+    """The spilled spectrogram is processed in chunks of 32 768 frames (524 s) with a +-7-frame halo;
+    530 s crosses one chunk boundary, 1100 s two. Bit-exact against the (unchunked) oracle."""
     from ucfp_amd import audio
-    x = _signal("chirps", 75.0, 8000, seed=9)
+    x = _signal("chirps", seconds, 8000, seed=9)
     g = audio.wang_hashes(x, 8000, ctx=gpu_ctx)
     o = oracle.wang(x)
-    assert np.array_equal(g, o)
+    assert g.shape == o.shape and np.array_equal(g, o)
+
+
+def test_haitsma_long_stream_crosses_chunks(gpu_ctx, oracle):
+    """Haitsma chunks hold 131 072 frames (1678 s at 5 kHz) plus one frame of history."""
+    from ucfp_amd import audio
+    x = _signal("noise", 1750.0, 5000, seed=4)
+    g = audio.haitsma_frames(x, 5000, ctx=gpu_ctx)
+    o = oracle.haitsma(x, 5000)
+    assert g.shape == o.shape and g.shape[0] > 131072 and np.array_equal(g, o)
 
 
 def test_wang_rejects_other_rates(gpu_ctx):

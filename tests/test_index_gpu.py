@@ -260,3 +260,44 @@ def test_topk_merge_dev_matches_global(gpu_ctx, oracle, torch_cuda):
     o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
     assert np.array_equal(out_ids.cpu().numpy().astype(np.uint64), o_ids)
     assert np.array_equal(out_keys.cpu().numpy().astype(np.uint32), o_d)
+
+
+def test_hamming_properties_at_scale(gpu_ctx, torch_cuda):
+    """BASELINE-scale shard (12.5 M codes, the per-GPU share of configs[4]) without the oracle:
+    planted neighbours come back first with their exact distance, distances are sorted, ids are
+    ascending inside a distance, the search is idempotent, and a query equal to a stored code
+    returns that code's id at distance 0."""
+    torch = torch_cuda
+    from ucfp_amd import index
+    n, nq, k = 12_500_000, 512, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    codes = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda", generator=g)
+    ids = torch.arange(n, dtype=torch.int64, device="cuda") * 3 + 1
+    q = torch.randint(-2**63, 2**63 - 1, (nq,), dtype=torch.int64, device="cuda", generator=g)
+    pos = (torch.arange(nq, device="cuda") * 24_391 + 17) % n
+    flips = torch.ones(nq, dtype=torch.int64, device="cuda") << (torch.arange(nq, device="cuda") % 60)
+    codes[pos] = q ^ flips                      # one neighbour at distance exactly 1 per query
+    q[0] = codes[123]                           # and an exact hit
+    ix = index.DeviceIndex(index.HAMMING64, 0, index.APPEND_ONLY, gpu_ctx)
+    stream = torch.cuda.current_stream().cuda_stream
+    ix.append_dev(0, ids.data_ptr(), codes.data_ptr(), n, stream)
+    outs = []
+    for _ in range(2):
+        o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        o_sc = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        o_d = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        o_c = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        ix.search_dev(0, q.data_ptr(), nq, k, o_ids.data_ptr(), o_sc.data_ptr(), o_d.data_ptr(), o_c.data_ptr(), stream)
+        torch.cuda.synchronize()
+        outs.append((o_ids.cpu().numpy(), o_d.cpu().numpy(), o_c.cpu().numpy()))
+    (i1, d1, c1), (i2, d2, c2) = outs
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2) and (c1 == k).all()
+    assert (np.diff(d1, axis=1) >= 0).all()
+    same = np.diff(d1, axis=1) == 0
+    assert (np.diff(i1, axis=1)[same] > 0).all()
+    assert d1[0, 0] == 0 and i1[0, 0] == 123 * 3 + 1
+    exp_ids = (pos.cpu().numpy() * 3 + 1)[1:]
+    assert (d1[1:, 0] <= 1).all()
+    assert (i1[1:, 0] == exp_ids).mean() > 0.99     # a random code at distance <= 1 is essentially impossible
+    ix.close()

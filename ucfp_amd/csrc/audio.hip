@@ -86,8 +86,6 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
     const uint32_t rl = __brev((uint32_t)lane) >> 26;  // 6-bit reversal of the lane
 #pragma unroll
     for (int i = 0; i < E; i++) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const uint32_t ri = __brev((uint32_t)i) >> (32 - B);   // compile-time after unrolling
         const uint32_t n = (ri << 6) | rl;
         float c = tw[(n * TWS) & 1023][0];

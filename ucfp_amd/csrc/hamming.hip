@@ -401,18 +401,18 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     p.qgroups = (nq + kWave - 1) / kWave;
     p.cap = k <= 16 ? 24 : k <= 40 ? 64 : 160;
     if (n == 0) return p;  // empty shard: nothing to launch
-    // sample: the first 128k codes. A lane then accepts ~k*n/sample items over the robust range,
-    // i.e. a wave leaves its fast path on ~64*k/sample = 0.5 % of the codes.
-    size_t s = 131072;
+    // sample: the first 32k codes. A lane then accepts ~k*n/sample items over the robust range,
+    // i.e. a wave leaves its fast path on ~64*k/sample = 2 % of the codes (k = 10).
+    size_t s = 32768;
     if (s > n) s = n;
     p.sample_n = s;
-    p.sample_parts = (uint32_t)((s + 4095) / 4096);
+    p.sample_parts = (uint32_t)((s + 1023) / 1024);  // short parts: the pre-pass is latency-bound per wave
     p.per_part = (s + p.sample_parts - 1) / p.sample_parts;
     // two tiers once the corpus is big enough for the prefix to be a small fraction of it
     p.fast = n >= (size_t)1 << 20;
     p.robust_n = n;
     if (p.fast) {
-        size_t pre = n / 16;
+        size_t pre = n / 32;
         if (pre < 131072) pre = 131072;
         if (pre > ((size_t)4 << 20)) pre = (size_t)4 << 20;
         p.robust_n = (pre + 31) & ~(size_t)31;

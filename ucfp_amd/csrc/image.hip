@@ -5,7 +5,7 @@
 // every step follows is DESIGN.md "Image spec" (I1..I8); oracle/ucfp_oracle_image.c is the
 // independent CPU statement of the same spec.
 //
-// One 256-thread workgroup hashes one frame:
+// One workgroup (kNW waves) hashes one frame:
 //   phase A  stream the frame once from HBM (16 B/lane, every 128-B line fully used); each
 //            thread owns tiles of 8x8 NORMALISED pixels and reduces them in registers to
 //            exact integer partial sums, which is all phase B needs:
@@ -32,6 +32,13 @@ namespace ucfp {
 
 __constant__ float c_dct_lo[8][32] = UCFP_DCT32_LO_INIT;
 
+// waves per workgroup (one workgroup hashes one frame)
+#ifndef UCFP_IMG_WAVES
+#define UCFP_IMG_WAVES 8
+#endif
+constexpr int kNW = UCFP_IMG_WAVES;
+constexpr int kNT = 64 * kNW;
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -47,8 +54,8 @@ struct ImageLds {
     uint16_t cs32[8 * 256];  // 4 KiB: column sums over 32 normalised rows (global 9x8 dHash image)
     uint16_t gsum[32 * 32];  // 2 KiB
     uint8_t g32[32 * 32];    // 1 KiB
-    float pbuf[4][32 * 8];   // per-wave P = X*C8^T
-    float coef[4][64];       // per-wave DCT low block
+    float pbuf[kNW][32 * 8]; // per-wave P = X*C8^T
+    float coef[kNW][64];     // per-wave DCT low block
     uint64_t hashes[3][17];  // [ahash, phash, dhash][region]
 };
 
@@ -307,8 +314,8 @@ __device__ __forceinline__ void hash_phase_and_store(ImageLds& L, uint32_t algo,
         const uint32_t* v8w = reinterpret_cast<const uint32_t*>(L.v8);
         uint32_t* csw = reinterpret_cast<uint32_t*>(L.cs32);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int w = tid + 256 * i;            // dword index in cs32: row = w / 128
+        for (int i = 0; i < 1024 / kNT; i++) {
+            const int w = tid + kNT * i;            // dword index in cs32: row = w / 128
             const int rr = w >> 7, xw = w & 127;
             csw[w] = v8w[(4 * rr + 0) * 128 + xw] + v8w[(4 * rr + 1) * 128 + xw] +
                      v8w[(4 * rr + 2) * 128 + xw] + v8w[(4 * rr + 3) * 128 + xw];
@@ -316,7 +323,7 @@ __device__ __forceinline__ void hash_phase_and_store(ImageLds& L, uint32_t algo,
         __syncthreads();
     }
 #pragma unroll 1
-    for (int r = wave; r < 17; r += 4) {
+    for (int r = wave; r < 17; r += kNW) {
         if (algo & 1u) {
             const uint64_t h = ahash_region(L, r, lane);
             if (lane == 0) L.hashes[0][r] = h;
@@ -366,7 +373,7 @@ __device__ __forceinline__ void hash_phase_and_store(ImageLds& L, uint32_t algo,
 // ---- fused kernel: GRAY8 frames with width = height = 256*S ---------------------------------
 // tile = 8x8 normalised px = (8S)x(8S) source px; thread t handles tiles t + 256k, k = 0..3.
 template <int S>
-__global__ __launch_bounds__(256) void image_hash_gray_kernel(
+__global__ __launch_bounds__(kNT) void image_hash_gray_kernel(
     const uint8_t* __restrict__ frames, size_t n, size_t row_stride, size_t frame_stride,
     uint32_t algo, const uint8_t* __restrict__ exact, uint8_t* __restrict__ out,
     int32_t* __restrict__ status) {
@@ -377,8 +384,8 @@ __global__ __launch_bounds__(256) void image_hash_gray_kernel(
     const int tid = threadIdx.x;
     const int tx = tid & 31;
 
-    for (int k = 0; k < 4; k++) {
-        const int ty = (tid >> 5) + 8 * k;
+    for (int k = 0; k < 1024 / kNT; k++) {
+        const int ty = (tid >> 5) + 2 * kNW * k;
         const uint8_t* base = f + (size_t)(8 * S * ty) * row_stride + (size_t)(8 * S * tx);
         TileAcc acc;
         acc.init();
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(256) void image_hash_gray_kernel(
 // every load instruction touch 64 scattered 16-byte pieces.  Here a LANE OWNS A STRIP of 4 source
 // pixels (= 2 normalised pixels) and walks down the rows: one load instruction reads 64 lanes x
 // 12 (RGB, global_load_dwordx3) or 16 bytes = 768 / 1024 CONTIGUOUS bytes of one row.
-// Waves 0,1 cover strips 0..127 of rows 0..255, waves 2,3 rows 256..511.  Per 16-row band a lane
+// Wave pairs (2w, 2w+1) cover strips 0..127 of a horizontal slab of 512 / (kNW/2) rows.  Per 16-row band a lane
 // produces its 4 s2 values, 2 v8 column sums, and (4 lanes together) one 8x8 tile total.
 // Luma (spec I1) is v_dot4_u32_u8 with the weights {77,150,29} shifted to where a pixel's bytes
 // sit inside the dword(s) -- no byte gathering.
@@ -484,7 +491,7 @@ __device__ __forceinline__ void strip_luma_pairs(const StripRow<BPP>& r, uint32_
 }
 
 template <int BPP>
-__global__ __launch_bounds__(256) void image_hash_color512_kernel(
+__global__ __launch_bounds__(kNT) void image_hash_color512_kernel(
     const uint8_t* __restrict__ frames, size_t n, size_t row_stride, size_t frame_stride,
     uint32_t algo, const uint8_t* __restrict__ exact, uint8_t* __restrict__ out,
     int32_t* __restrict__ status) {
@@ -493,10 +500,11 @@ __global__ __launch_bounds__(256) void image_hash_color512_kernel(
     if (img >= n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sx = 64 * (wave & 1) + lane;           // strip 0..127
-    const int band0 = 16 * (wave >> 1);              // first 16-row band (tile row) of this wave
+    constexpr int kBands = 64 / kNW;                 // 16-row bands (tile rows) per wave
+    const int band0 = kBands * (wave >> 1);          // first band of this wave
     const uint8_t* __restrict__ col = frames + img * frame_stride + (size_t)(4 * BPP * sx);
 #pragma unroll 1
-    for (int b = 0; b < 16; b++) {
+    for (int b = 0; b < kBands; b++) {
         const int ty = band0 + b;
         const uint8_t* p = col + (size_t)(16 * ty) * row_stride;
         StripRow<BPP> rows[16];
@@ -627,7 +635,7 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
     const bool square = (w == h) && (w % 256 == 0);
     const uint32_t S = square ? w / 256 : 0;
     if (pixfmt == 0 && aligned16(frames, row_stride, frame_stride) && (S == 1 || S == 2 || S == 4)) {
-        dim3 grid((unsigned)n), block(256);
+        dim3 grid((unsigned)n), block(kNT);
         if (S == 2)
             hipLaunchKernelGGL(image_hash_gray_kernel<2>, grid, block, 0, stream, frames, n,
                                row_stride, frame_stride, algo, exact, out, status);
@@ -641,7 +649,7 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
     }
     if (S == 2 && ((pixfmt == 2 && aligned16(frames, row_stride, frame_stride)) ||
                    (pixfmt == 1 && (((uintptr_t)frames | row_stride | frame_stride) & 3u) == 0))) {
-        dim3 grid((unsigned)n), block(256);
+        dim3 grid((unsigned)n), block(kNT);
         if (pixfmt == 1)
             hipLaunchKernelGGL(image_hash_color512_kernel<3>, grid, block, 0, stream, frames, n, row_stride,
                                frame_stride, algo, exact, out, status);
@@ -656,7 +664,7 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
         hipLaunchKernelGGL(image_normalize_kernel, dim3(256, (unsigned)chunk), dim3(256), 0, stream,
                            frames + done * frame_stride, w, h, row_stride, frame_stride, pixfmt,
                            norm_ws);
-        hipLaunchKernelGGL(image_hash_gray_kernel<1>, dim3((unsigned)chunk), dim3(256), 0, stream,
+        hipLaunchKernelGGL(image_hash_gray_kernel<1>, dim3((unsigned)chunk), dim3(kNT), 0, stream,
                            norm_ws, chunk, (size_t)256, (size_t)65536, algo,
                            exact ? exact + 32 * done : nullptr, out + done * rec,
                            status ? status + done : nullptr);

@@ -114,6 +114,20 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
                           size_t frame_stride, int pixfmt, const ucfp_image_preprocess* pre,
                           const uint8_t* exact, uint8_t* out, int32_t* status);
 
+/* Host micro-batcher: the caller side of handlers::ingest_image
+ * (src/server/handlers.rs:232-302) hashes one image per request thread, up to 512 in flight
+ * (src/bin/ucfp.rs:267).  submit() is BLOCKING and thread-safe: concurrent calls are coalesced
+ * into one pinned-memory copy + one launch of at most max_batch frames, flushed no later than
+ * max_delay_us after the first pending frame arrived.  One geometry per batcher. */
+typedef struct ucfp_image_batcher ucfp_image_batcher;
+int ucfp_image_batcher_create(ucfp_ctx* ctx, uint32_t algo, uint32_t width, uint32_t height, int pixfmt,
+                              const ucfp_image_preprocess* pre, size_t max_batch, uint32_t max_delay_us,
+                              ucfp_image_batcher** out);
+void ucfp_image_batcher_destroy(ucfp_image_batcher* b);
+int ucfp_image_batcher_submit(ucfp_image_batcher* b, const uint8_t* frame, size_t row_stride,
+                              const uint8_t* exact, uint8_t* out, int32_t* status);
+int ucfp_image_batcher_stats(ucfp_image_batcher* b, uint64_t* batches, uint64_t* items);
+
 /* Synthetic workload of SURVEY 8(d) config 2, generated on device: frame i, pixel (x,y) =
  * ((x + y + 17*i) & 255) ^ (splitmix64((i*h + y)*w + x) >> 60): a ramp with 4 bits of seeded
  * noise. Deterministic; the oracle has the same generator. Bench/test support only. */

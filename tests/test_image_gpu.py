@@ -275,3 +275,28 @@ def test_encoded_image_adapters(gpu_ctx, oracle):
         image.fingerprint_with(png, 0, 0, image.PreprocessConfig(min_dimension=512))
     with pytest.raises(ModalityError):
         image.fingerprint_with(png, 0, 0, image.PreprocessConfig(max_input_bytes=10))
+
+
+def test_micro_batcher_coalesces_concurrent_requests(gpu_ctx, oracle):
+    """SURVEY 8f N1: 48 threads each submit frames one at a time (the reference's per-request shape);
+    the batcher must return every thread ITS record, bit-exact, using far fewer launches than frames."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ucfp_amd import image
+    rng = np.random.default_rng(33)
+    n = 600
+    fr = np.concatenate([_frames(rng, n // 2, 256, 256), _frames(rng, n // 2, 256, 256, kind="smooth")])
+    ex = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ref, _ = oracle.image_hash_batch(fr, 7, exact=ex)
+    b = image.ImageBatcher(256, 256, max_batch=64, max_delay_us=2000, ctx=gpu_ctx)
+    try:
+        with ThreadPoolExecutor(48) as pool:
+            got = list(pool.map(lambda i: b.submit(fr[i], ex[i].tobytes()), range(n)))
+        for i, (rec, st) in enumerate(got):
+            assert st == 0 and rec == ref[i].tobytes(), i
+        batches, items = b.stats()
+        assert items == n and batches < n // 4, (batches, items)
+        # a lone request is flushed by the deadline, not stuck waiting for a full batch
+        rec, st = b.submit(fr[0], ex[0].tobytes())
+        assert rec == ref[0].tobytes()
+    finally:
+        b.close()

@@ -26,5 +26,26 @@ def main():
                           "host_GBs": n * 512 * 512 / dt / 1e9}), flush=True)
 
 
+def batcher():
+    """Per-request shape through the micro-batcher: T threads, one frame per call."""
+    from concurrent.futures import ThreadPoolExecutor
+    ctx = _lib.default_context(0)
+    rng = np.random.default_rng(1)
+    fr = rng.integers(0, 256, (256, 512, 512), dtype=np.uint8)
+    for threads in (16, 64):
+        b = image.ImageBatcher(512, 512, max_batch=256, max_delay_us=300, ctx=ctx)
+        total = 8192
+        with ThreadPoolExecutor(threads) as pool:
+            list(pool.map(lambda i: b.submit(fr[i % 256]), range(256)))
+            t0 = time.perf_counter()
+            list(pool.map(lambda i: b.submit(fr[i % 256]), range(total)))
+            dt = time.perf_counter() - t0
+        nb, ni = b.stats()
+        print(json.dumps({"micro_batcher_threads": threads, "frames_per_s": total / dt,
+                          "avg_batch": ni / max(nb, 1)}), flush=True)
+        b.close()
+
+
 if __name__ == "__main__":
     main()
+    batcher()

@@ -81,6 +81,13 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t,
                                       C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_image_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                            C.POINTER(ImagePreprocess), C.c_size_t, C.c_uint32,
+                                            C.POINTER(C.c_void_p)]),
+    "ucfp_image_batcher_destroy": (None, [C.c_void_p]),
+    "ucfp_image_batcher_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_int32)]),
+    "ucfp_image_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                        C.c_uint32, C.c_size_t, C.c_void_p]),

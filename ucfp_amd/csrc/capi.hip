@@ -76,6 +76,10 @@ int grow(uint8_t** p, size_t* cap, size_t need) {
 
 namespace ucfp {
 int ctx_device(const ucfp_ctx* ctx) { return ctx->device; }
+uint8_t* ctx_norm_ws(const ucfp_ctx* ctx, size_t* frames) {
+    *frames = kNormWsFrames;
+    return ctx->norm_ws;
+}
 }  // namespace ucfp
 
 extern "C" {

@@ -174,3 +174,47 @@ def global_hashes(record_bytes_: bytes) -> dict:
     if len(b) == 168:
         return {"global": rd(32)}
     raise ModalityError(f"not an image fingerprint: {len(b)} bytes")
+
+
+class ImageBatcher:
+    """Host micro-batcher: many request threads call `submit` concurrently, the
+    library coalesces them into one GPU launch. `submit` blocks until this frame's record is ready."""
+
+    def __init__(self, width: int, height: int, *, algo: int = MULTI, pixfmt: int = PIX_GRAY8,
+                 max_batch: int = 512, max_delay_us: int = 200, preprocess: Optional[PreprocessConfig] = None,
+                 ctx=None):
+        self._lib = _lib.load()
+        self.ctx = ctx or _lib.default_context()
+        self.width, self.height, self.algo, self.pixfmt = width, height, algo, pixfmt
+        self.rec = record_bytes(algo)
+        pre = (preprocess or PreprocessConfig())._c()
+        h = C.c_void_p()
+        _lib.check(self._lib.ucfp_image_batcher_create(self.ctx.handle, algo, width, height, pixfmt, C.byref(pre),
+                                                       max_batch, max_delay_us, C.byref(h)))
+        self.handle = h
+
+    def submit(self, frame: np.ndarray, exact: Optional[bytes] = None):
+        """frame: uint8 [h, w] or [h, w, c], C-contiguous. Returns (record bytes, status)."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        out = (C.c_uint8 * self.rec)()
+        st = C.c_int32(0)
+        ex = (C.c_uint8 * 32).from_buffer_copy(exact) if exact is not None else None
+        _lib.check(self._lib.ucfp_image_batcher_submit(self.handle, frame.ctypes.data,
+                                                       self.width * _BPP[self.pixfmt], ex, out, C.byref(st)))
+        return bytes(out), int(st.value)
+
+    def stats(self):
+        b, i = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.ucfp_image_batcher_stats(self.handle, C.byref(b), C.byref(i)))
+        return int(b.value), int(i.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_image_batcher_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -50,7 +50,8 @@ struct ucfp_image_batcher {
     hipStream_t stream = nullptr;
 
     std::mutex mu;
-    std::condition_variable cv_work, cv_done, cv_room;
+    std::condition_variable cv_work, cv_room;
+    std::condition_variable cv_done[2];   // per set: a flush wakes only its own submitters
     struct Set {
         size_t pending = 0;       // slots handed out
         size_t copied = 0;        // of which the submitter has finished its memcpy into pinned memory
@@ -112,7 +113,7 @@ void worker_loop(ucfp_image_batcher* b) {
         S.copied = 0;
         b->batches++;
         b->items += n;
-        b->cv_done.notify_all();
+        b->cv_done[s].notify_all();
         b->cv_room.notify_all();
     }
 }
@@ -224,7 +225,7 @@ int ucfp_image_batcher_submit(ucfp_image_batcher* b, const uint8_t* frame, size_
     lk.lock();
     S.copied++;
     b->cv_work.notify_one();
-    b->cv_done.wait(lk, [&] { return S.gen_done >= my_gen; });
+    b->cv_done[s].wait(lk, [&] { return S.gen_done >= my_gen; });
     const int rc = S.rc;
     lk.unlock();
     // the worker does not flush this set again before `readers` drops to zero, so the pinned result

@@ -301,3 +301,29 @@ def test_hamming_properties_at_scale(gpu_ctx, torch_cuda):
     assert (d1[1:, 0] <= 1).all()
     assert (i1[1:, 0] == exp_ids).mean() > 0.99     # a random code at distance <= 1 is essentially impossible
     ix.close()
+
+
+def test_many_queries_small_corpus(gpu_ctx, oracle):
+    """Query batches far larger than the corpus (grid-dimension limits of the select/merge launches)."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(12)
+    n, dim, nq = 300, 16, 70000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    cx = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    cx.upsert(0, ids, rows)
+    gi, gs, _, gc = cx.search(0, q, 3)
+    assert (gc == 3).all()
+    for j in (0, 1, 32767, 32768, 65535, 65536, nq - 1):
+        oi, osc = oracle.cosine_knn(ids, rows, q[j], 3)
+        assert np.array_equal(gi[j], oi) and np.abs(gs[j] - osc).max() <= COS_TOL
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    hx = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    hx.upsert(0, ids, codes)
+    hq = rng.integers(0, 2**64, nq, dtype=np.uint64)
+    hi, _, hd, hc = hx.search(0, hq, 4)
+    oi, od, _ = oracle.hamming_topk(ids, codes, hq[:64], 4)
+    assert np.array_equal(hi[:64], oi) and np.array_equal(hd[:64], od) and (hc == 4).all()
+    oi, od, _ = oracle.hamming_topk(ids, codes, hq[-64:], 4)
+    assert np.array_equal(hi[-64:], oi) and np.array_equal(hd[-64:], od)

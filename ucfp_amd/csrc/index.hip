@@ -178,6 +178,7 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     // chunk the query batch so the key matrix stays under ~2 GiB
     size_t chunk = (size_t)2048 * 1024 * 1024 / (4 * n);
     if (chunk < (size_t)qpp) chunk = qpp;
+    if (chunk > 32768) chunk = 32768;  // queries ride on gridDim.y of the select kernel
     if (chunk > nq) chunk = nq;
     ucfp::SelectPlan sp = ucfp::select_plan(n, (uint32_t)chunk);
     size_t off = 0;
@@ -225,7 +226,7 @@ int check_search_args(ucfp_index* ix, const void* q, size_t nq, uint32_t k, cons
     if (!ix) return capi_fail(UCFP_E_INVALID, "index is NULL");
     if (k > UCFP_INDEX_MAX_K) return capi_fail(UCFP_E_INVALID, "k = %u exceeds UCFP_INDEX_MAX_K = %u", k, UCFP_INDEX_MAX_K);
     if (nq && k && (!q || !ids || !cnt)) return capi_fail(UCFP_E_INVALID, "queries/out_ids/out_counts is NULL");
-    if (nq > 0x7fffffu) return capi_fail(UCFP_E_INVALID, "query batch %zu too large for one call", nq);
+    if (nq > 4000000u) return capi_fail(UCFP_E_INVALID, "query batch %zu too large for one call (max 4 000 000)", nq);
     return 0;
 }
 

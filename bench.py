@@ -197,7 +197,21 @@ def bench_text(args, rank, world, dev, ctx):
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / steps
     assert int(status.abs().sum().item()) == 0
+    # SimHash-64 over the same documents (reference row a6)
+    sout = torch.empty((n_docs, 8), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ucfp_text_simhash_batch_dev(ctx.handle, blob.data_ptr(), offs.data_ptr(), n_docs, 0, sout.data_ptr(),
+                                               status.data_ptr(), stream))
+    torch.cuda.synchronize()
+    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev2[0].record()
+    for _ in range(steps):
+        _lib.check(lib.ucfp_text_simhash_batch_dev(ctx.handle, blob.data_ptr(), offs.data_ptr(), n_docs, 0,
+                                                   sout.data_ptr(), status.data_ptr(), stream))
+    ev2[1].record()
+    torch.cuda.synchronize()
+    sms = ev2[0].elapsed_time(ev2[1]) / steps
     res = {"metric": "documents/s (MinHash-128, k=5 word shingles, tokenised on GPU)",
+           "simhash": {"ms_per_pass": sms, "docs_per_s": n_docs / (sms / 1e3) * world},
            "value": n_docs / (ms / 1e3) * world, "unit": "docs/s", "docs_per_gpu": n_docs, "doc_bytes": doc_len,
            "ms_per_pass": ms, "algorithmic_GBs": n_docs * (doc_len + 1032) / (ms / 1e3) / 1e9,
            "note": "integer-VALU bound (DESIGN.md 5), HBM figure given as the common yardstick"}
@@ -297,7 +311,29 @@ def bench_audio(args, rank, world, dev, ctx):
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / steps
     nh = int(cnt.item())
-    res = {"metric": "audio-seconds/s (Wang landmarks incl. 44.1k->8k linear resample)",
+    # Haitsma-Kalker over the first hour (reference row a4): resample to 5 kHz, 2048-point STFT, 33 bands
+    hsecs = min(secs, 3600)
+    hn = sr * hsecs
+    hm = int(lib.ucfp_audio_resample_len(hn, sr, 5000))
+    x5 = torch.empty(hm, dtype=torch.float32, device=dev)
+    hframes = int(lib.ucfp_audio_haitsma_frames(hm, 5000))
+    hout = torch.empty((max(hframes, 1),), dtype=torch.int32, device=dev)
+
+    def hstep():
+        _lib.check(lib.ucfp_audio_resample_linear_dev(ctx.handle, x.data_ptr(), hn, sr, 5000, x5.data_ptr(), hm, stream))
+        _lib.check(lib.ucfp_audio_haitsma_dev(ctx.handle, x5.data_ptr(), hm, None, hout.data_ptr(), hframes, stream))
+    hstep()
+    torch.cuda.synchronize()
+    hev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    hev[0].record()
+    for _ in range(steps):
+        hstep()
+    hev[1].record()
+    torch.cuda.synchronize()
+    hms = hev[0].elapsed_time(hev[1]) / steps
+    res = {"haitsma": {"seconds": hsecs, "ms_per_pass": hms, "x_real_time": hsecs / (hms / 1e3) * world,
+                       "frames": hframes},
+           "metric": "audio-seconds/s (Wang landmarks incl. 44.1k->8k linear resample)",
            "value": secs / (ms / 1e3) * world, "unit": "x real time", "seconds_per_gpu": secs, "ms_per_pass": ms,
            "hashes": nh, "algorithmic_GBs": (n * 4 + nh * 8) / (ms / 1e3) / 1e9,
            "note": "spectrogram is spilled in 64 MiB chunks in round 1 (DESIGN.md 8)"}

@@ -153,6 +153,12 @@ def fingerprint_with(data: bytes, tenant_id: int, record_id: int,
     return _single(data, preprocess, MULTI, tenant_id, record_id)
 
 
+def fingerprint_multi_with(data: bytes, preprocess: PreprocessConfig, _multi_cfg, tenant_id: int,
+                           record_id: int) -> Record:
+    """image.rs:96-104: the MultiHashConfig is a compare-time setting and does not change the bytes."""
+    return fingerprint_with(data, tenant_id, record_id, preprocess)
+
+
 def fingerprint_phash(data: bytes, preprocess: PreprocessConfig, tenant_id: int, record_id: int) -> Record:
     return _single(data, preprocess, PHASH, tenant_id, record_id)
 

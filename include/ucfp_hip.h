@@ -195,7 +195,7 @@ int ucfp_audio_resample_linear_dev(ucfp_ctx* ctx, const float* d_in, size_t n, u
  *                           (Unicode tables live there) and resubmits it as
  *   UCFP_TEXT_PRETOKENIZED  tokens already canonical, separated by single spaces.
  * status[i]: 0, UCFP_TEXT_NEEDS_HOST, UCFP_E_MODALITY (no tokens), UCFP_E_UNSUPPORTED (one token,
- * or a run of fewer than k tokens, longer than the 2 KiB tile).
+ * or a run of fewer than k tokens, longer than the ~1.4 KiB LDS batch).
  */
 #define UCFP_TEXT_RAW_ASCII 0
 #define UCFP_TEXT_PRETOKENIZED 1

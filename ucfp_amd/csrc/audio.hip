@@ -108,8 +108,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
     // ---- transpose 1 ----
 #pragma unroll
     for (int i = 0; i < E; i++) buf[(E + 1) * lane + i] = make_float2(xr[i], xi[i]);   // p + p/E, p = E*lane + i
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     const int lo = lane & (E - 1), hi = lane >> B;
 #pragma unroll
     for (int m = 0; m < E; m++) {
@@ -135,8 +134,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         const int pp = hi * E * E + m * E + lo;
         buf[pp + (pp >> B)] = make_float2(xr[m], xi[m]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int pp = e * 64 + lane;
@@ -155,8 +153,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
             bfly(xr[e0], xi[e0], xr[e0 + halfe], xi[e0 + halfe], tw[jj * tstep][0], tw[jj * tstep][1]);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     // ---- power spectrum, bins k = e*64 + lane < N/2, into the (now free) buffer as float[N/2] ----
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
@@ -164,8 +161,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         const float a = xr[e] * xr[e], b = xi[e] * xi[e];
         pw[e * 64 + lane] = a + b;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
 }
 
 template <int N, bool HAITSMA>
@@ -213,8 +209,7 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict
                 out[f * (size_t)kHkBands + lane] = e;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
 }
 

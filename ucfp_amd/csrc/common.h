@@ -6,6 +6,15 @@
 
 namespace ucfp {
 
+// Intra-wave LDS hand-off: the DS unit executes one wave's LDS instructions in issue order, so a
+// later read sees an earlier write of another lane; what is needed is that the COMPILER keeps the
+// order (and, defensively, that outstanding LDS ops have landed).  Unlike a workgroup-scope fence
+// this does not wait for global loads/stores in flight (vmcnt), so prefetches stay overlapped.
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // image.hip
 int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w, uint32_t h,
                       size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim,

@@ -88,8 +88,7 @@ __global__ __launch_bounds__(64) void select_topk_u32(const uint32_t* __restrict
             first = false;
             kept++;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         cnt = kept;
         cur = nxt;
         if (cnt >= k) tau = l_key[cur][k - 1];
@@ -108,8 +107,7 @@ __global__ __launch_bounds__(64) void select_topk_u32(const uint32_t* __restrict
                 l_id[cur][pos] = ids[row];
             }
             cnt += (uint32_t)__popcll(mask);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             if (cnt > (uint32_t)(kSelCap - kWave)) prune();
         }
     }

@@ -160,7 +160,7 @@ def _raise_for(status: int):
     if status == -1:
         raise ModalityError("text has no tokens after canonicalisation")
     if status == -2:
-        raise UnsupportedError("a token (or a run of fewer than k tokens) exceeds the 2 KiB tile")
+        raise UnsupportedError("a token (or a run of fewer than k tokens) exceeds the ~1.4 KiB LDS batch")
     if status != 0:
         raise ModalityError(f"text fingerprint failed with status {status}")
 

@@ -215,6 +215,7 @@ def bench_text(args, rank, world, dev, ctx):
            "value": n_docs / (ms / 1e3) * world, "unit": "docs/s", "docs_per_gpu": n_docs, "doc_bytes": doc_len,
            "ms_per_pass": ms, "algorithmic_GBs": n_docs * (doc_len + 1032) / (ms / 1e3) / 1e9,
            "note": "integer-VALU bound (DESIGN.md 5), HBM figure given as the common yardstick"}
+    res["lsh"] = bench_lsh(n_docs, rank, world, dev, ctx)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle
         docs = [bytes(pool[i]) for i in range(2048)]
@@ -224,6 +225,43 @@ def bench_text(args, rank, world, dev, ctx):
         res["cpu_baseline"] = {"value": 2048 / dt, "unit": "docs/s", "cores": oracle.num_threads(), "kind": "port",
                                "gpu_matches_oracle_on_sample": bool(np.array_equal(o, out[:2048].cpu().numpy()))}
     return res
+
+
+def bench_lsh(n, rank, world, dev, ctx, nq=4096, k=10):
+    """Banded LSH (16 x 8) over n synthetic MinHash-128 records per GPU: build = band keys + 16 radix
+    sorts; query = 4096 near-duplicates (10 % of slots changed) -> top-10 by slot agreement."""
+    import torch
+    from ucfp_amd import text
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x15A + rank)
+    rec = torch.zeros((n, 1032), dtype=torch.uint8, device=dev)
+    rec[:, 8:] = torch.randint(0, 256, (n, 1024), dtype=torch.uint8, device=dev, generator=g)
+    ids = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64, device=dev)
+    q = rec[:nq].clone()
+    flip = torch.rand((nq, 128), device=dev, generator=g) < 0.10
+    q[:, 8:].view(nq, 128, 8)[flip] ^= 0x5A
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    o_sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    o_ct = torch.empty((nq,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    idx = text.LshIndex(16, 8, ctx=ctx)
+    idx.build_dev(ids.data_ptr(), rec.data_ptr(), n, stream)
+    idx.query_dev(q.data_ptr(), nq, k, o_ids.data_ptr(), o_sc.data_ptr(), o_ct.data_ptr(), stream)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    idx.build_dev(ids.data_ptr(), rec.data_ptr(), n, stream)
+    e[1].record()
+    for _ in range(5):
+        idx.query_dev(q.data_ptr(), nq, k, o_ids.data_ptr(), o_sc.data_ptr(), o_ct.data_ptr(), stream)
+    e[2].record()
+    torch.cuda.synchronize()
+    recall = float((o_ids[:, 0] == ids[:nq]).float().mean().item())
+    qms = e[1].elapsed_time(e[2]) / 5
+    idx.close()
+    return {"bands": 16, "rows": 8, "records_per_gpu": n, "build_ms": e[0].elapsed_time(e[1]),
+            "build_records_per_s": n / e[0].elapsed_time(e[1]) * 1e3 * world, "queries": nq, "k": k,
+            "query_ms": qms, "qps": nq / qms * 1e3 * world, "top1_is_source": recall}
 
 
 def bench_cosine(args, rank, world, dev, ctx):

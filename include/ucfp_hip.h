@@ -212,6 +212,22 @@ int ucfp_text_simhash_batch_dev(ucfp_ctx* ctx, const uint8_t* d_utf8, const uint
 int ucfp_text_simhash_batch(ucfp_ctx* ctx, const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode,
                             uint8_t* out, int32_t* status);
 
+/* ---- banded MinHash LSH (the reference only re-tags the record, text.rs:437-446) ----
+ * key_b = FNV-style fold of slots [b*rows, (b+1)*rows) + splitmix64 finaliser; bands*rows <= 128.
+ * ucfp_text_lsh_band_keys_dev writes keys band-major: d_keys[b*n + doc]. */
+int ucfp_text_lsh_band_keys_dev(ucfp_ctx* ctx, const uint8_t* d_records, size_t n, uint32_t bands, uint32_t rows,
+                                uint64_t* d_keys, void* stream);
+typedef struct ucfp_lsh ucfp_lsh;
+/* cand_per_band: rows examined per band per query (0 = 64). */
+int ucfp_lsh_create(ucfp_ctx* ctx, uint32_t bands, uint32_t rows, uint32_t cand_per_band, ucfp_lsh** out);
+void ucfp_lsh_destroy(ucfp_lsh* lsh);
+/* (Re)build from n device-resident 1032-byte MinHash records and their record ids. */
+int ucfp_lsh_build_dev(ucfp_lsh* lsh, const uint64_t* d_ids, const uint8_t* d_records, size_t n, void* stream);
+/* For each query record: candidates = rows sharing a band key (first cand_per_band per band, at most
+ * 1024 in total); score = equal slots / 128; best k by (score desc, id asc). */
+int ucfp_lsh_query_dev(ucfp_lsh* lsh, const uint8_t* d_query_records, size_t nq, uint32_t k, uint64_t* d_out_ids,
+                       float* d_out_scores, uint32_t* d_out_counts, void* stream);
+
 /* =============================== INDEX ========================================
  * Replaces `trait IndexBackend` kNN (src/index/mod.rs:29-35) as implemented by
  * EmbeddedBackend::knn (src/index/embedded/mod.rs:268-360): exact brute-force top-k inside

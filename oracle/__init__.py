@@ -299,3 +299,68 @@ def image_synth(n: int, w: int, h: int, first: int = 0) -> np.ndarray:
     out = np.zeros((n, h, w), np.uint8)
     lib().ucfp_oracle_image_synth(out.ctypes.data, n, w, h, first)
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# banded MinHash LSH (DESIGN.md "LSH"; the reference has no band index)
+# ------------------------------------------------------------------------------------------
+
+_M64 = (1 << 64) - 1
+
+
+def _records_slots(records) -> np.ndarray:
+    r = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1, 1032)
+    return np.ascontiguousarray(r[:, 8:]).view("<u8").reshape(-1, 128)
+
+
+def lsh_band_keys(records, bands: int = 16, rows: int = 8) -> np.ndarray:
+    """uint64 [n, bands]: h = FNV offset; h = (h ^ slot) * FNV prime per slot; splitmix64 finaliser."""
+    slots = _records_slots(records)
+    n = slots.shape[0]
+    with np.errstate(over="ignore"):
+        out = np.empty((n, bands), np.uint64)
+        for b in range(bands):
+            h = np.full(n, 0xCBF29CE484222325, np.uint64)
+            for r in range(rows):
+                h = (h ^ slots[:, b * rows + r]) * np.uint64(0x100000001B3)
+            h ^= h >> np.uint64(30)
+            h *= np.uint64(0xBF58476D1CE4E5B9)
+            h ^= h >> np.uint64(27)
+            h *= np.uint64(0x94D049BB133111EB)
+            h ^= h >> np.uint64(31)
+            out[:, b] = h
+    return out
+
+
+def lsh_query(ids, records, queries, k: int, bands: int = 16, rows: int = 8, cand_per_band: int = 64,
+              max_cand: int = 1024):
+    """Candidate list = for band 0..bands-1 the first `cand_per_band` corpus rows (ascending row) whose
+    band key equals the query's, the concatenation cut at `max_cand`; duplicates dropped; score =
+    equal slots / 128; best k by (score desc, id asc).  -> (ids [nq,k], scores [nq,k], counts [nq])."""
+    ids = np.asarray(ids, np.uint64)
+    cs, qs = _records_slots(records), _records_slots(queries)
+    ck, qk = lsh_band_keys(records, bands, rows), lsh_band_keys(queries, bands, rows)
+    nq = qs.shape[0]
+    o_ids = np.full((nq, k), _M64, np.uint64)
+    o_sc = np.full((nq, k), -1.0, np.float32)
+    o_ct = np.zeros(nq, np.uint32)
+    order = [np.argsort(ck[:, b], kind="stable") for b in range(bands)] if cs.shape[0] else []
+    skeys = [ck[order[b], b] for b in range(bands)] if cs.shape[0] else []
+    for q in range(nq):
+        cand = []
+        for b in range(bands if cs.shape[0] else 0):
+            lo = np.searchsorted(skeys[b], qk[q, b], "left")
+            hi = np.searchsorted(skeys[b], qk[q, b], "right")
+            cand.extend(order[b][lo:min(hi, lo + cand_per_band)].tolist())
+        cand = cand[:max_cand]
+        seen, uniq = set(), []
+        for r in cand:
+            if r not in seen:
+                seen.add(r)
+                uniq.append(r)
+        scored = sorted(((-int((cs[r] == qs[q]).sum()), int(ids[r])) for r in uniq))[:k]
+        o_ct[q] = len(scored)
+        for j, (na, i) in enumerate(scored):
+            o_ids[q, j] = i
+            o_sc[q, j] = np.float32(-na) * np.float32(1.0 / 128.0)
+    return o_ids, o_sc, o_ct

@@ -181,3 +181,37 @@ def test_resample_linear_matches_numpy_interp(oracle):
     pos = np.arange(y.size) * 44100 / 8000
     ref = np.interp(pos, np.arange(x.size), x.astype(np.float64))
     assert y.size == 4410 * 8000 // 44100 and np.abs(y - ref).max() < 1e-6
+
+
+def test_lsh_checker_against_pure_python(oracle):
+    """The numpy LSH checker agrees with a loop-level restatement."""
+    M = (1 << 64) - 1
+    rng = np.random.default_rng(9)
+    slots = rng.integers(0, 1 << 64, size=(60, 128), dtype=np.uint64)
+    slots[30:40] = slots[0]                       # a bucket of identical signatures
+    slots[40:50] = slots[1]
+    slots[40:50, :32] ^= np.uint64(7)             # near copies: bands 0-3 differ, 96 of 128 slots survive
+    rec = np.zeros((60, 1032), np.uint8)
+    rec[:, 8:] = slots.view(np.uint8).reshape(60, 1024)
+
+    def key(row, b, rows):
+        h = 0xCBF29CE484222325
+        for r in range(rows):
+            h = ((h ^ int(slots[row, b * rows + r])) * 0x100000001B3) & M
+        h ^= h >> 30
+        h = (h * 0xBF58476D1CE4E5B9) & M
+        h ^= h >> 27
+        h = (h * 0x94D049BB133111EB) & M
+        return h ^ (h >> 31)
+
+    for bands, rows in ((16, 8), (20, 6), (2, 64)):
+        k = oracle.lsh_band_keys(rec, bands, rows)
+        assert all(int(k[i, b]) == key(i, b, rows) for i in (0, 17, 59) for b in range(bands))
+    ids = np.arange(100, 160, dtype=np.uint64)
+    o_ids, o_sc, o_ct = oracle.lsh_query(ids, rec, rec[:2], 5, 16, 8)
+    assert o_ct.tolist() == [5, 5]
+    assert o_ids[0].tolist() == [100, 130, 131, 132, 133] and (o_sc[0] == 1.0).all()   # ties: id ascending
+    assert o_ids[1, 0] == 101 and o_sc[1, 0] == 1.0 and (o_sc[1, 1:] == 0.75).all()
+    # the per-band cap keeps the first rows of a run
+    o_ids, _, o_ct = oracle.lsh_query(ids, rec, rec[:1], 128, 16, 8, cand_per_band=3)
+    assert o_ct[0] == 3 and o_ids[0, :3].tolist() == [100, 130, 131]

@@ -68,6 +68,13 @@ SIGNATURES = {
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_text_simhash_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                           C.c_void_p, C.c_void_p]),
+    "ucfp_text_lsh_band_keys_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p,
+                                              C.c_void_p]),
+    "ucfp_lsh_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ucfp_lsh_destroy": (None, [C.c_void_p]),
+    "ucfp_lsh_build_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ucfp_lsh_query_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "ucfp_index_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ucfp_index_destroy": (None, [C.c_void_p]),
     "ucfp_index_upsert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),

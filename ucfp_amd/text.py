@@ -207,14 +207,93 @@ def fingerprint_lsh(text: str, opts: TextOpts, tenant_id: int, record_id: int) -
     return rec
 
 
-def lsh_band_keys(record: bytes, bands: int = 16, rows: int = 8) -> List[int]:
-    """Band keys over the 128 slots (the reference has no band index; 16 x 8 uses
-    every slot).  Key = FNV-1a over the band's slot bytes."""
-    assert bands * rows <= 128 and len(record) == MINHASH_BYTES
-    keys = []
-    for b in range(bands):
-        h = 0xCBF29CE484222325
-        for byte in record[8 + 8 * rows * b: 8 + 8 * rows * (b + 1)]:
-            h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
-        keys.append(h)
-    return keys
+def _dev(a: np.ndarray):
+    """Host array -> device tensor (torch is memory plumbing only)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise UnsupportedError("no HIP device: the LSH index only exists on the GPU")
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a if a.flags.writeable else a.copy()).cuda()
+
+
+def _records(records) -> np.ndarray:
+    if isinstance(records, (bytes, bytearray)):
+        records = np.frombuffer(bytes(records), np.uint8)
+    r = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1, MINHASH_BYTES)
+    return r
+
+
+def lsh_band_keys(records, bands: int = 16, rows: int = 8, ctx=None) -> np.ndarray:
+    """Band keys of MinHash-128 records (the reference has no band index).
+    -> uint64 [n, bands].  Key spec: DESIGN.md "LSH" (slot-wise FNV fold + splitmix64 finaliser);
+    computed by ucfp_text_lsh_band_keys_dev."""
+    import torch
+    ctx = ctx or _lib.default_context()
+    r = _records(records)
+    n = r.shape[0]
+    d_r = _dev(r)
+    d_k = torch.empty((bands, max(n, 1)), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.load().ucfp_text_lsh_band_keys_dev(ctx.handle, d_r.data_ptr(), n, bands, rows, d_k.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream or None))
+    return d_k[:, :n].t().contiguous().cpu().numpy().view(np.uint64)
+
+
+class LshIndex:
+    """Banded MinHash LSH shard on the GPU: `build` sorts (band key, row) per band, `query` returns
+    the best k candidates by slot agreement (the MinHash Jaccard estimate)."""
+
+    def __init__(self, bands: int = 16, rows: int = 8, cand_per_band: int = 64, ctx=None):
+        self._lib = _lib.load()
+        self.ctx = ctx or _lib.default_context()
+        self.bands, self.rows, self.cand_per_band = bands, rows, cand_per_band
+        h = C.c_void_p()
+        _lib.check(self._lib.ucfp_lsh_create(self.ctx.handle, bands, rows, cand_per_band, C.byref(h)))
+        self.handle = h
+        self.n = 0
+
+    def build_dev(self, ids_ptr: int, records_ptr: int, n: int, stream: int = 0) -> None:
+        _lib.check(self._lib.ucfp_lsh_build_dev(self.handle, ids_ptr or None, records_ptr or None, n, stream or None))
+        self.n = n
+
+    def build(self, ids, records) -> None:
+        import torch
+        ids = np.ascontiguousarray(ids, dtype=np.uint64).reshape(-1)
+        r = _records(records)
+        if r.shape[0] != ids.shape[0]:
+            raise ModalityError("ids and records disagree on the number of rows")
+        if ids.shape[0] == 0:
+            self.build_dev(0, 0, 0)
+            return
+        d_ids, d_r = _dev(ids.view(np.int64)), _dev(r)
+        self.build_dev(d_ids.data_ptr(), d_r.data_ptr(), ids.shape[0], torch.cuda.current_stream().cuda_stream)
+        torch.cuda.current_stream().synchronize()   # the build copies what it needs; inputs may go now
+
+    def query_dev(self, records_ptr: int, nq: int, k: int, out_ids_ptr: int, out_scores_ptr: int,
+                  out_counts_ptr: int, stream: int = 0) -> None:
+        _lib.check(self._lib.ucfp_lsh_query_dev(self.handle, records_ptr, nq, k, out_ids_ptr, out_scores_ptr,
+                                                out_counts_ptr, stream or None))
+
+    def query(self, records, k: int = 10):
+        """-> (ids uint64 [nq, k] (INVALID = 2^64-1), scores float32 [nq, k], counts uint32 [nq])."""
+        import torch
+        r = _records(records)
+        nq = r.shape[0]
+        d_r = _dev(r)
+        o_ids = torch.empty((max(nq, 1), k), dtype=torch.int64, device="cuda")
+        o_sc = torch.empty((max(nq, 1), k), dtype=torch.float32, device="cuda")
+        o_ct = torch.empty(max(nq, 1), dtype=torch.int32, device="cuda")
+        self.query_dev(d_r.data_ptr(), nq, k, o_ids.data_ptr(), o_sc.data_ptr(), o_ct.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+        return (o_ids[:nq].cpu().numpy().view(np.uint64), o_sc[:nq].cpu().numpy(),
+                o_ct[:nq].cpu().numpy().view(np.uint32))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_lsh_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Hamming top-k timing probe (one GPU): python tools/bench_hamming.py --n 100000000 --nq 4096
+Prints one JSON line per (n, nq) with ms per search and pairs/s; run it under
+`rocprofv3 --kernel-trace --stats` for the per-kernel split."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, nargs="+", default=[100_000_000])
+    ap.add_argument("--nq", type=int, nargs="+", default=[4096])
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    import torch
+    from ucfp_amd import _lib, index
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)
+    for n in a.n:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        codes = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, generator=g)
+        ids = torch.arange(n, dtype=torch.int64, device=dev)
+        ix = index.DeviceIndex(index.HAMMING64, flags=index.APPEND_ONLY, ctx=ctx)
+        ix.append_dev(0, ids.data_ptr(), codes.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        del codes, ids
+        for nq in a.nq:
+            q = torch.randint(-2**63, 2**63 - 1, (nq,), dtype=torch.int64, device=dev, generator=g)
+            o_ids = torch.empty((nq, a.k), dtype=torch.int64, device=dev)
+            o_sc = torch.empty((nq, a.k), dtype=torch.float32, device=dev)
+            o_d = torch.empty((nq, a.k), dtype=torch.int32, device=dev)
+            o_ct = torch.empty((nq,), dtype=torch.int32, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+
+            def go():
+                ix.search_dev(0, q.data_ptr(), nq, a.k, o_ids.data_ptr(), o_sc.data_ptr(), o_d.data_ptr(),
+                              o_ct.data_ptr(), st)
+            go()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                go()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            print(json.dumps({"n": n, "nq": nq, "k": a.k, "ms": ms, "qps": nq / ms * 1e3,
+                              "T_pairs_per_s": n * nq / ms / 1e9}), flush=True)
+        ix.close()
+
+
+if __name__ == "__main__":
+    main()

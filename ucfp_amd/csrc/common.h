@@ -30,13 +30,14 @@ struct HammingPlan {
     size_t sample_n = 0;        // codes in the tau0 sample pre-pass
     uint32_t sample_parts = 0;
     size_t per_part = 0;
-    size_t robust_n = 0;        // robust tier covers [0, robust_n) (== n when `fast` is off)
+    size_t robust_n = 0;        // robust tier covers [0, robust_n): everything when `fast` is off, nothing when on
     uint32_t slices = 0;        // robust tier: one wave per (slice, qgroup)
     size_t per_slice = 0;
-    bool fast = false;          // fast tier covers [robust_n, n)
-    uint32_t fslices = 0;
-    size_t fper_slice = 0;
+    bool fast = false;          // matrix-core filter in stages over [0, stage_end[0]), [stage_end[0], stage_end[1]), ...
+    uint32_t nstages = 0;
+    size_t stage_end[12] = {0};
     uint32_t cand_cap = 0;      // candidate slots per query in global memory
+    uint32_t log_cap = 0;       // suspect-block records per wave and stage
     uint32_t fb_slices = 0;     // fallback robust scan over [0, n), device-gated on overflow
     size_t fb_per_slice = 0;
 };

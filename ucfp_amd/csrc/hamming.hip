@@ -25,6 +25,7 @@
 // The same merge kernel is the last step after the multi-GPU all-gather.
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "common.h"
@@ -221,122 +222,338 @@ __global__ __launch_bounds__(64) void hamming_scan(
     }
 }
 
-// ---- fast tier ---------------------------------------------------------------------------
-// Once an exact top-k of a corpus PREFIX is known, its k-th distance tau1 bounds the final
-// k-th from above, so the rest of the corpus only has to be FILTERED: a lane appends the rare
-// row with d <= tau1 straight to its query's candidate list in global memory.  No LDS, a dozen
-// VGPRs -> 8 waves per SIMD, and the loop is the bare xor/bcnt/min3 stream.  Two 16-code SGPR
-// buffers ping-pong so the scalar loads of one half hide behind the VALU work of the other.
-// If a list overflows (adversarial order: the prefix says nothing about the tail) a flag is
-// raised and the robust tier re-does the whole corpus; results never depend on the heuristic.
-__global__ void hamming_tau1(const uint32_t* __restrict__ pre_d, const uint32_t* __restrict__ pre_cnt,
-                             uint32_t nq, uint32_t k, uint32_t* __restrict__ tau1,
-                             uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q == 0) *overflow = 0;
-    if (q >= nq) return;
-    tau1[q] = pre_cnt[q] >= k ? pre_d[(size_t)q * k + k - 1] : 64u;
-    cand_cnt[q] = 0;
+// ---- fast tier: a filter on the matrix cores ---------------------------------------------------
+// Once an upper bound tau[q] on the final k-th distance is known, the corpus only has to be
+// FILTERED: every row with d <= tau[q] goes to q's candidate list in global memory, everything else
+// is dropped unseen.  With a batch of queries that scan is ALU-bound (HBM sees < 1 TB/s), and the
+// distance is an exact small-integer contraction: with x_i = 1/0 for the code bits and y_i = +1/-1
+// for the query bits,  sum_i x_i y_i = popc(q) - d(q, x).  Two v_mfma_i32_32x32x32_i8 (K = 2 x 32)
+// with  A = 32 codes as 0/1 bytes (rows),  B = 32 queries as +-1 bytes (columns)  give 1024 of
+// these sums in 64 cycles (the popcount path: ~290), and a pair is a candidate iff
+// sum >= popc(q) - tau[q].  Integers throughout -- nothing is approximated.
+//   layout  the 16 results a lane holds all belong to ONE query (column = lane & 31), so they are
+//           folded with v_max3 (two results per instruction) before the single compare against the
+//           lane's threshold: no C operand, 8 v_max3 per MFMA pair, and the 32x32 shape keeps the
+//           vector issue port (8 cycles per MFMA + 4 per v_max3) below the matrix pipe's 64 cycles
+//   LDS     the +-1 image of the whole query pass (<= 2048 queries, 2 KiB per 32-query tile,
+//           lane-contiguous for ds_read_b128) and the thresholds, built once per workgroup
+//   wave    expands 4 code tiles (128 codes) into registers (lane half and K half pick the bits: the
+//           same k-permutation on both operands), then walks all query tiles: 8 MFMAs, 32 v_max3,
+//           1 compare, software-pipelined by one tile
+//   hits    rare by construction of tau.  The scan only RECORDS a suspect block (query tile, code
+//           tile, ballot of the lanes over threshold) in the wave's own slice of a global log -- one
+//           store, no atomics, nothing to wait for.  hamming_rescan then re-evaluates the flagged
+//           (query, 16-code half) combinations with plain popcounts (exact, independent of the MFMA
+//           result layout) and appends the true candidates to the per-query lists.
+// The scan runs in stages over geometrically growing ranges: tau0 (k-th distance inside a 32k-code
+// sample) filters [0, 8 x 32k); the k-th smallest distance of the candidates so far filters the next
+// 8x larger range, and so on, so every stage admits only ~8k..40k candidates per query.  The final
+// top-k is selected from the lists.  If a log or a list overflows (adversarial order) a flag routes
+// the batch through the robust tier, device-side -- results never depend on the heuristic.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int kQP = 2048;    // queries per pass (their +-1 image is resident in LDS)
+constexpr int kTB = 4;       // 32-code tiles per wave step
+constexpr int kMW = 8;       // waves per workgroup (2 per SIMD; the loop is software-pipelined inside a wave)
+constexpr int kStep = kTB * 32;
+constexpr int kRescanY = 8;  // rescan blocks per log slice
+
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) {   // bit i of nib -> byte i (0 / 1)
+    return __umul24(nib, 0x204081u) & 0x01010101u;
+}
+__device__ __forceinline__ i32x4 expand01(uint32_t bits16) {
+    i32x4 v;
+    v[0] = (int)spread4(bits16 & 15u);
+    v[1] = (int)spread4((bits16 >> 4) & 15u);
+    v[2] = (int)spread4((bits16 >> 8) & 15u);
+    v[3] = (int)spread4(bits16 >> 12);
+    return v;
+}
+__device__ __forceinline__ i32x4 expand_pm1(uint32_t bits16) {   // 1 -> +1, 0 -> -1
+    const i32x4 t = expand01(bits16);
+    i32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t u = ((uint32_t)t[j] << 8) - (uint32_t)t[j];   // 0xFF where set
+        v[j] = (int)(~u | 0x01010101u);
+    }
+    return v;
 }
 
-__global__ __launch_bounds__(64) void hamming_scan_fast(
-    const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t begin, size_t end,
-    size_t per_slice, const uint64_t* __restrict__ queries, uint32_t nq, const uint32_t* __restrict__ tau1,
-    uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id,
-    uint32_t cand_cap, uint32_t* __restrict__ overflow) {
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.y * kWave + lane;
-    const bool live = q < nq;
-    const uint64_t qv = queries[live ? q : nq - 1];
-    const uint32_t qlo = (uint32_t)qv, qhi = (uint32_t)(qv >> 32);
-    const int32_t tau = live ? (int32_t)tau1[q] : -1;
-    const size_t s0 = begin + (size_t)blockIdx.x * per_slice;
-    const size_t s1 = s0 + per_slice < end ? s0 + per_slice : end;
-    if (s0 >= s1) return;
+size_t hamming_mfma_lds_bytes(uint32_t nq) {
+    const uint32_t tiles = ((nq < (uint32_t)kQP ? nq : (uint32_t)kQP) + 31) / 32;
+    return (size_t)(tiles + 2) * (2048 + 128);   // +2: the drain tile and its operand prefetch
+}
+uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) * kMW; }
 
-    auto append = [&](size_t row, uint32_t d) {
-        if ((int32_t)d <= tau) {
-            const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
-            if (pos < cand_cap) {
-                cand_d[(size_t)q * cand_cap + pos] = d;
-                cand_id[(size_t)q * cand_cap + pos] = ids[row];
-            } else {
-                *overflow = 1;
+// log record: x = query tile (global: q / 32), y = row - begin of the 32-code tile, (z, w) = lane ballot
+__global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
+    const uint64_t* __restrict__ codes, size_t begin, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
+    const uint32_t* __restrict__ tau, uint4* __restrict__ log, uint32_t* __restrict__ log_cnt, uint32_t log_cap,
+    uint32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
+    const uint32_t q0 = blockIdx.y * kQP;
+    const uint32_t nqp = nq - q0 < (uint32_t)kQP ? nq - q0 : (uint32_t)kQP;
+    const uint32_t ntiles = (nqp + 31) / 32;
+    // [tile][K half][lane] 16 B: the B operand of query tile t, K half h, is one ds_read_b128 per lane
+    i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
+    int* THR = reinterpret_cast<int*>(mf_lds + (size_t)(ntiles + 2) * 2048);   // [tile][32]
+    for (uint32_t s = threadIdx.x; s < (ntiles + 2) * 128; s += kMW * 64) {
+        const uint32_t t = s >> 7, h = (s >> 6) & 1, l = s & 63, q = q0 + t * 32 + (l & 31);
+        i32x4 v = {0, 0, 0, 0};
+        if (t < ntiles && q < nq) v = expand_pm1((uint32_t)(queries[q] >> (32 * h + 16 * (l >> 5))) & 0xffffu);
+        QB[s] = v;
+    }
+    for (uint32_t s = threadIdx.x; s < (ntiles + 2) * 32; s += kMW * 64) {
+        const uint32_t q = q0 + s;
+        // dead columns (and the pad tiles) are all-zero: their sums are 0, below this threshold
+        THR[s] = ((s >> 5) < ntiles && q < nq) ? (int)__popcll(queries[q]) - (int)tau[q] : 0x7fffffff;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int nn = lane & 31, hh = lane >> 5;
+    const size_t gwave = (size_t)blockIdx.x * kMW + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * kMW;
+    const size_t nsuper = (end - begin + kStep - 1) / kStep;
+    const size_t slice = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kMW + (threadIdx.x >> 6);
+    uint4* __restrict__ mylog = log + slice * log_cap;
+    uint32_t ln = 0;   // records written, wave-uniform
+
+    // lane (nn, hh) needs bits [32h + 16hh, +16) of code nn for both K halves h: two 2-byte loads
+    const uint16_t* __restrict__ chunks = reinterpret_cast<const uint16_t*>(codes);
+    auto load_codes = [&](uint32_t (&x)[kTB], size_t st) {
+#pragma unroll
+        for (int b = 0; b < kTB; b++) {
+            const size_t row = begin + st * kStep + 32 * b + nn;
+            const bool ok = st < nsuper && row < end;
+            const uint32_t lo = ok ? (uint32_t)__builtin_nontemporal_load(chunks + row * 4 + hh) : 0u;
+            const uint32_t hi = ok ? (uint32_t)__builtin_nontemporal_load(chunks + row * 4 + 2 + hh) : 0u;
+            x[b] = lo | (hi << 16);
+        }
+    };
+    uint32_t x[kTB];
+    load_codes(x, gwave);
+    for (size_t st = gwave; st < nsuper; st += nwaves) {
+        i32x4 A[kTB][2];
+#pragma unroll
+        for (int b = 0; b < kTB; b++) {
+            A[b][0] = expand01(x[b] & 0xffffu);
+            A[b][1] = expand01(x[b] >> 16);
+        }
+        load_codes(x, st + nwaves);   // next step's codes travel while this one computes
+        const uint32_t off = (uint32_t)(st * kStep);   // row - begin of code tile 0 (the span is < 2^32)
+        // Software pipeline over the query tiles: the MFMAs of tile t are interleaved with the v_max3
+        // folding tile t-1's results -- an MFMA keeps the vector issue port for 8 of its 32 cycles, four
+        // v_max3 use 16 more, so one wave alone keeps the matrix pipe busy.  Issue order is pinned by
+        // volatile asm (the scheduler otherwise serialises MFMA bursts and fold bursts).  Hazards are
+        // covered by construction, not by compiler nops: a result is first read one whole step (8
+        // MFMAs, 256 cycles) after its MFMA issued; the accumulate pair is the same opcode on the same
+        // registers (hardware-forwarded); B operands come from LDS (waitcnt on the asm operands), A was
+        // written by VALU hundreds of cycles earlier.
+        auto step = [&](uint32_t t, i32x16 (&Dn)[kTB], const i32x16 (&Dp)[kTB], const i32x4& b0, const i32x4& b1,
+                        int thr, i32x4& n0, i32x4& n1, int& nthr) {
+            n0 = QB[(t + 1) * 128 + lane];   // operands of the next tile (the pad tiles end the array)
+            n1 = QB[(t + 1) * 128 + 64 + lane];
+            nthr = THR[(t + 1) * 32 + nn];
+            int m[kTB];
+#pragma unroll
+            for (int b = 0; b < kTB; b++) {
+                const i32x16& P = Dp[b];
+                asm volatile(
+                    "v_mfma_i32_32x32x32_i8 %0, %2, %4, 0\n\t"
+                    "v_max3_i32 %1, %6, %7, %8\n\t"
+                    "v_max3_i32 %1, %1, %9, %10\n\t"
+                    "v_max3_i32 %1, %1, %11, %12\n\t"
+                    "v_max3_i32 %1, %1, %13, %14\n\t"
+                    "v_mfma_i32_32x32x32_i8 %0, %3, %5, %0\n\t"
+                    "v_max3_i32 %1, %1, %15, %16\n\t"
+                    "v_max3_i32 %1, %1, %17, %18\n\t"
+                    "v_max3_i32 %1, %1, %19, %20\n\t"
+                    "v_max_i32 %1, %1, %21"
+                    : "=&v"(Dn[b]), "=&v"(m[b])
+                    : "v"(A[b][0]), "v"(A[b][1]), "v"(b0), "v"(b1), "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]),
+                      "v"(P[5]), "v"(P[6]), "v"(P[7]), "v"(P[8]), "v"(P[9]), "v"(P[10]), "v"(P[11]), "v"(P[12]),
+                      "v"(P[13]), "v"(P[14]), "v"(P[15]));
+            }
+            // m[] folds tile t-1 (its threshold was passed in as `thr`)
+            const int mm = max(max(m[0], m[1]), max(m[2], m[3]));
+            if (__builtin_expect(__any(mm >= thr), 0)) {
+#pragma unroll
+                for (int b = 0; b < kTB; b++) {
+                    const uint64_t mask = __ballot(m[b] >= thr);
+                    if (mask) {
+                        if (ln < log_cap) {
+                            if (lane == 0)
+                                mylog[ln] = make_uint4(q0 / 32 + (t - 1), off + 32 * b, (uint32_t)mask, (uint32_t)(mask >> 32));
+                        } else if (lane == 0) {
+                            *overflow = 1;
+                        }
+                        ln++;
+                    }
+                }
+            }
+        };
+        i32x16 D0[kTB], D1[kTB];
+#pragma unroll
+        for (int b = 0; b < kTB; b++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) D1[b][e] = -0x7fffffff;   // "tile -1": below every threshold
+        i32x4 p0 = QB[lane], p1 = QB[64 + lane], r0, r1;
+        // tiles 0 .. ntiles: the last one is a pad tile that only drains the pipeline.  Two steps per
+        // trip so that result and operand registers ping-pong without moves.  The fold inside step t
+        // tests tile t-1, so its threshold lags: tp = thr(t-1), tc = thr(t), tn = thr(t+1).
+        int tp = 0x7fffffff, tc = THR[nn], tn;
+        uint32_t t = 0;
+        for (; t + 2 <= ntiles + 1; t += 2) {
+            step(t, D0, D1, p0, p1, tp, r0, r1, tn);
+            tp = tc;
+            tc = tn;
+            step(t + 1, D1, D0, r0, r1, tp, p0, p1, tn);
+            tp = tc;
+            tc = tn;
+        }
+        if (t < ntiles + 1) step(t, D0, D1, p0, p1, tp, r0, r1, tn);
+        // the drain tile's MFMAs may still be writing D0/D1: 18 wait states before anything rewrites them
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    }
+    if (lane == 0) log_cnt[slice] = ln < log_cap ? ln : log_cap;
+}
+
+// grid (log slices, kRescanY), one wave per block: exact distances for the flagged (query, 16-code half)
+// lanes of every record; true candidates are appended to the per-query lists.
+__global__ __launch_bounds__(64) void hamming_rescan(
+    const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t begin, size_t end,
+    const uint64_t* __restrict__ queries, const uint32_t* __restrict__ tau, const uint4* __restrict__ log,
+    const uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ cand_cnt,
+    uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id, uint32_t cand_cap, uint32_t* __restrict__ overflow) {
+    const int lane = threadIdx.x;
+    const int nn = lane & 31, hh = lane >> 5;
+    const uint32_t cnt = log_cnt[blockIdx.x];
+    for (uint32_t i = blockIdx.y; i < cnt; i += gridDim.y) {
+        const uint4 r = log[(size_t)blockIdx.x * log_cap + i];
+        const uint64_t mask = (uint64_t)r.z | ((uint64_t)r.w << 32);
+        if (!((mask >> lane) & 1)) continue;
+        const uint32_t q = r.x * 32 + nn;          // a flagged lane always has a live query
+        const uint64_t qv = queries[q];
+        const uint32_t tq = tau[q];
+        // the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
+        const size_t row0 = begin + r.y + 4 * hh;
+        uint64_t cv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+            cv[j] = codes[row < end ? row : begin];
+        }
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+            const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
+            if (d <= tq && row < end) {
+                found = true;
+                const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
+                if (pos < cand_cap) {
+                    cand_d[(size_t)q * cand_cap + pos] = d;
+                    cand_id[(size_t)q * cand_cap + pos] = ids[row];
+                } else {
+                    *overflow = 1;
+                }
             }
         }
-    };
-    constexpr int G = 16;
-    auto process = [&](const uint64_t (&buf)[G], size_t base) {
-        uint32_t d[G];
-        bool any_hit = false;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-            d[j] = __builtin_popcount(qlo ^ (uint32_t)buf[j]) + __builtin_popcount(qhi ^ (uint32_t)(buf[j] >> 32));
-            any_hit |= (int32_t)d[j] <= tau;
-        }
-        if (__any(any_hit)) {
-#pragma unroll
-            for (int j = 0; j < G; j++) append(base + j, d[j]);
-        }
-    };
-    uint64_t a[G], b[G];
-    size_t i = s0;
-    if (i + G <= s1) {
-#pragma unroll
-        for (int j = 0; j < G; j++) a[j] = codes[i + j];
-    }
-    // invariant at loop head: a[] holds codes [i, i+G)
-    while (i + 2 * G <= s1) {
-#pragma unroll
-        for (int j = 0; j < G; j++) b[j] = codes[i + G + j];
-        process(a, i);
-        if (i + 3 * G <= s1) {
-#pragma unroll
-            for (int j = 0; j < G; j++) a[j] = codes[i + 2 * G + j];
-        }
-        process(b, i + G);
-        i += 2 * G;
-    }
-    if (i + G <= s1) {
-        process(a, i);
-        i += G;
-    }
-    for (; i < s1; i++) {
-        const uint64_t x = codes[i];
-        const uint32_t d = __builtin_popcount(qlo ^ (uint32_t)x) + __builtin_popcount(qhi ^ (uint32_t)(x >> 32));
-        if (__any((int32_t)d <= tau)) append(i, d);
+        // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
+        // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
+        // this kernel disagree about the result layout -> distrust the filter, take the robust tier
+        if (!found && (int)__popcll(qv) - (int)tq > 0) *overflow = 1;
     }
 }
 
-// One wave per query: best k of (prefix top-k list) U (candidate list), order (d, id) ascending.
-__global__ __launch_bounds__(64) void hamming_final_merge(
-    const uint64_t* __restrict__ pre_ids, const uint32_t* __restrict__ pre_d,
-    const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ cand_d,
-    const uint64_t* __restrict__ cand_id, uint32_t cand_cap, uint32_t nq, uint32_t k,
-    uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_d, uint32_t* __restrict__ out_cnt) {
+// tau1[q] = k-th smallest distance among q's candidates so far (one wave per query); also the exact
+// bound the second stage filters with.  Fewer than k candidates (only after an overflow) -> keep tau0.
+__global__ __launch_bounds__(64) void hamming_list_tau(const uint32_t* __restrict__ cand_cnt,
+                                                       const uint32_t* __restrict__ cand_d, uint32_t cand_cap,
+                                                       uint32_t k, const uint32_t* __restrict__ tau0,
+                                                       uint32_t* __restrict__ tau1) {
+    __shared__ uint32_t h[65];
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
+    h[lane] = 0;
+    if (lane == 0) h[64] = 0;
+    wave_lds_sync();
     uint32_t nc = cand_cnt[q];
     nc = nc < cand_cap ? nc : cand_cap;
-    const uint32_t total = k + nc;
-    uint32_t ld = 0;
+    for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[cand_d[(size_t)q * cand_cap + c]], 1u);
+    wave_lds_sync();
+    if (lane == 0) {
+        uint32_t cum = 0, t = tau0[q];
+        for (uint32_t b = 0; b < 65; b++) {
+            cum += h[b];
+            if (cum >= k) {
+                t = b;
+                break;
+            }
+        }
+        tau1[q] = t;
+    }
+}
+
+// One wave per query: best k of the candidate list, order (d, id) ascending.  A distance histogram
+// gives d* (the k-th smallest distance); only entries with d <= d* can win, and they are few, so
+// they are compacted into LDS and the k selection rounds run there (straight from the global list
+// when more than kSelCap of them tie).
+constexpr int kSelCap = 1024;
+__global__ __launch_bounds__(64) void hamming_final_select(
+    const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ cand_d, const uint64_t* __restrict__ cand_id,
+    uint32_t cand_cap, uint32_t k, uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_d,
+    uint32_t* __restrict__ out_cnt) {
+    __shared__ uint32_t h[65];
+    __shared__ uint32_t sd[kSelCap];
+    __shared__ uint64_t si[kSelCap];
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    h[lane] = 0;
+    if (lane == 0) h[64] = 0;
+    wave_lds_sync();
+    uint32_t nc = cand_cnt[q];
+    nc = nc < cand_cap ? nc : cand_cap;
+    const uint32_t* __restrict__ gd = cand_d + (size_t)q * cand_cap;
+    const uint64_t* __restrict__ gi = cand_id + (size_t)q * cand_cap;
+    for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[gd[c]], 1u);
+    wave_lds_sync();
+    uint32_t dstar = 64, cum = 0;   // wave-uniform: every lane walks the same 65 bins
+    for (uint32_t b = 0; b < 65; b++) {
+        cum += h[b];
+        if (cum >= k) {
+            dstar = b;
+            break;
+        }
+    }
+    // compact the possible winners
+    uint32_t m = 0;   // wave-uniform
+    for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
+        const uint32_t c = c0 + lane;
+        const uint32_t dd = c < nc ? gd[c] : 0xffffffffu;
+        const bool w = dd <= dstar;
+        const uint64_t mask = __ballot(w);
+        const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (w && pos < (uint32_t)kSelCap) {
+            sd[pos] = dd;
+            si[pos] = gi[c];
+        }
+        m += (uint32_t)__popcll(mask);
+    }
+    wave_lds_sync();
+    const bool in_lds = m <= (uint32_t)kSelCap;
+    const uint32_t total = in_lds ? m : nc;
+    uint32_t ld = 0, emitted = 0;
     uint64_t li = 0;
     bool first = true;
-    uint32_t emitted = 0;
     for (uint32_t r = 0; r < k; r++) {
         uint32_t bd = 0xffffffffu;
         uint64_t bi = ~0ull;
         for (uint32_t c = lane; c < total; c += kWave) {
-            uint32_t dd;
-            uint64_t ii;
-            if (c < k) {
-                dd = pre_d[(size_t)q * k + c];
-                ii = pre_ids[(size_t)q * k + c];
-            } else {
-                dd = cand_d[(size_t)q * cand_cap + (c - k)];
-                ii = cand_id[(size_t)q * cand_cap + (c - k)];
-            }
-            if (dd == 0xffffffffu) continue;
+            const uint32_t dd = in_lds ? sd[c] : gd[c];
+            const uint64_t ii = in_lds ? si[c] : gi[c];
             if ((first || key_less(ld, li, dd, ii)) && key_less(dd, ii, bd, bi)) {
                 bd = dd;
                 bi = ii;
@@ -368,6 +585,12 @@ __global__ __launch_bounds__(64) void hamming_final_merge(
         }
         out_cnt[q] = emitted;
     }
+}
+
+__global__ void hamming_reset_lists(uint32_t nq, uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) *overflow = 0;
+    if (q < nq) cand_cnt[q] = 0;
 }
 
 // score = 1 - d/64 (higher is better, src/core/mod.rs:113-115); invalid -> 0 count handles it
@@ -408,21 +631,25 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     p.sample_n = s;
     p.sample_parts = (uint32_t)((s + 1023) / 1024);  // short parts: the pre-pass is latency-bound per wave
     p.per_part = (s + p.sample_parts - 1) / p.sample_parts;
-    // two tiers once the corpus is big enough for the prefix to be a small fraction of it
-    p.fast = n >= (size_t)1 << 20;
+    // matrix-core filter once the corpus dwarfs the sample: stages over ranges growing 8x, so a stage
+    // admits ~ c k 8 candidates per query (c <= ~5: the boundary distance bin is fat)
+    p.fast = n >= (size_t)1 << 18 && n - 1 <= 0xfffffff0u;
     p.robust_n = n;
     if (p.fast) {
-        size_t pre = n / 32;
-        if (pre < 131072) pre = 131072;
-        if (pre > ((size_t)4 << 20)) pre = (size_t)4 << 20;
-        p.robust_n = (pre + 31) & ~(size_t)31;
-        slice_range(n - p.robust_n, p.qgroups, 256 * 32 * 2, 8192, p.fslices, p.fper_slice);
-        // expected candidates per query ~ (k .. 5k) * n / prefix (fat boundary bin); 8x headroom
-        size_t cc = (size_t)k * 8 * (n / p.robust_n + 1) * 5;
-        if (cc < 1024) cc = 1024;
-        if (cc > 16384) cc = 16384;
+        size_t e = p.sample_n;
+        while (e < n && p.nstages < 12) {
+            e = e * 8 < n ? e * 8 : n;
+            p.stage_end[p.nstages++] = e;
+        }
+        p.stage_end[p.nstages - 1] = n;
+        p.robust_n = 0;
+        size_t cc = (size_t)k * 8 * 5 * p.nstages * 2;   // 2x headroom
+        if (cc < 2048) cc = 2048;
+        if (cc > 65536) cc = 65536;
         p.cand_cap = (uint32_t)cc;
+        p.log_cap = 2048;
         slice_range(n, p.qgroups, 256 * 16, 4096, p.fb_slices, p.fb_per_slice);
+        return p;
     }
     slice_range(p.robust_n, p.qgroups, 256 * 16, 4096, p.slices, p.per_slice);
     return p;
@@ -430,8 +657,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
 
 namespace {
 struct HammingWs {
-    size_t hist, tau0, part_ids, part_d, part_cnt, pre_ids, pre_d, pre_cnt, tau1, cand_cnt, overflow, cand_d,
-        cand_id, total;
+    size_t hist, tau0, part_ids, part_d, part_cnt, tau1, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, total;
 };
 HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -443,14 +669,13 @@ HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     w.part_ids = off;  off = align(off + (size_t)ms * nq * k * 8);
     w.part_d = off;    off = align(off + (size_t)ms * nq * k * 4);
     w.part_cnt = off;  off = align(off + (size_t)ms * nq * 4);
-    w.pre_ids = off;   off = align(off + (size_t)nq * k * 8);
-    w.pre_d = off;     off = align(off + (size_t)nq * k * 4);
-    w.pre_cnt = off;   off = align(off + (size_t)nq * 4);
     w.tau1 = off;      off = align(off + (size_t)nq * 4);
     w.cand_cnt = off;  off = align(off + (size_t)nq * 4);
     w.overflow = off;  off = align(off + 4);
     w.cand_d = off;    off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 4 : 0));
     w.cand_id = off;   off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 8 : 0));
+    w.log_cnt = off;   off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * 4 : 0));
+    w.log = off;       off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * p.log_cap * 16 : 0));
     w.total = off;
     return w;
 }
@@ -493,22 +718,50 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                        p.sample_n, p.per_part, queries, nq, u32(w.hist));
     hipLaunchKernelGGL(hamming_tau0, dim3((nq + 255) / 256), dim3(256), 0, stream, u32(w.hist), nq, k,
                        u32(w.tau0));
-    // robust tier over [0, robust_n): exact top-k of the prefix (or of everything)
-    uint64_t* r_ids = p.fast ? u64(w.pre_ids) : out_ids;
-    uint32_t* r_d = p.fast ? u32(w.pre_d) : out_dist;
-    uint32_t* r_cnt = p.fast ? u32(w.pre_cnt) : out_cnt;
-    launch_robust(p.cap, dim3(p.slices, p.qgroups), stream, codes, ids, p.robust_n, p.per_slice, queries, nq, k,
-                  (const uint32_t*)u32(w.tau0), u64(w.part_ids), u32(w.part_d), u32(w.part_cnt),
-                  (const uint32_t*)nullptr);
-    launch_topk_merge_u32(u64(w.part_ids), u32(w.part_d), p.slices, nq, k, r_ids, r_d, r_cnt, nullptr, stream);
-    if (p.fast) {
-        hipLaunchKernelGGL(hamming_tau1, dim3((nq + 255) / 256), dim3(256), 0, stream, r_d, r_cnt, nq, k,
-                           u32(w.tau1), u32(w.cand_cnt), u32(w.overflow));
-        hipLaunchKernelGGL(hamming_scan_fast, dim3(p.fslices, p.qgroups), dim3(64), 0, stream, codes, ids,
-                           p.robust_n, n, p.fper_slice, queries, nq, (const uint32_t*)u32(w.tau1), u32(w.cand_cnt),
-                           u32(w.cand_d), u64(w.cand_id), p.cand_cap, u32(w.overflow));
-        hipLaunchKernelGGL(hamming_final_merge, dim3(nq), dim3(64), 0, stream, r_ids, r_d, u32(w.cand_cnt),
-                           u32(w.cand_d), u64(w.cand_id), p.cand_cap, nq, k, out_ids, out_dist, out_cnt);
+    if (!p.fast) {
+        // robust tier over the whole (small) corpus: exact top-k straight into the outputs
+        launch_robust(p.cap, dim3(p.slices, p.qgroups), stream, codes, ids, n, p.per_slice, queries, nq, k,
+                      (const uint32_t*)u32(w.tau0), u64(w.part_ids), u32(w.part_d), u32(w.part_cnt),
+                      (const uint32_t*)nullptr);
+        launch_topk_merge_u32(u64(w.part_ids), u32(w.part_d), p.slices, nq, k, out_ids, out_dist, out_cnt, nullptr,
+                              stream);
+    } else {
+        const uint32_t passes = (nq + kQP - 1) / kQP;
+        const size_t lds = hamming_mfma_lds_bytes(nq);
+        const uint32_t slices = hamming_log_slices(nq);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_scan_mfma),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(hamming_reset_lists, dim3((nq + 255) / 256), dim3(256), 0, stream, nq, u32(w.cand_cnt),
+                           u32(w.overflow));
+        uint32_t* tau_cur = u32(w.tau0);
+        uint32_t* tau_nxt = u32(w.tau1);
+        size_t begin = 0;
+        for (uint32_t sidx = 0; sidx < p.nstages; sidx++) {
+            const size_t end = p.stage_end[sidx];
+            const size_t supers = (end - begin + kStep - 1) / kStep;
+            unsigned wgs = 256;   // one workgroup of kMW waves per CU (the query image fills its LDS)
+            if ((size_t)wgs * kMW > supers) wgs = (unsigned)((supers + kMW - 1) / kMW);
+            (void)hipMemsetAsync(u32(w.log_cnt), 0, (size_t)slices * 4, stream);
+            hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(kMW * 64), lds, stream, codes, begin, end,
+                               queries, nq, (const uint32_t*)tau_cur, reinterpret_cast<uint4*>(ws + w.log),
+                               u32(w.log_cnt), p.log_cap, u32(w.overflow));
+            hipLaunchKernelGGL(hamming_rescan, dim3(slices, kRescanY), dim3(64), 0, stream, codes, ids, begin, end,
+                               queries, (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
+                               (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
+                               u64(w.cand_id), p.cand_cap, u32(w.overflow));
+            if (sidx + 1 < p.nstages) {
+                hipLaunchKernelGGL(hamming_list_tau, dim3(nq), dim3(64), 0, stream, (const uint32_t*)u32(w.cand_cnt),
+                                   (const uint32_t*)u32(w.cand_d), p.cand_cap, k, (const uint32_t*)tau_cur, tau_nxt);
+                uint32_t* t = tau_cur;
+                tau_cur = tau_nxt;
+                tau_nxt = t;
+            }
+            begin = end;
+        }
+        hipLaunchKernelGGL(hamming_final_select, dim3(nq), dim3(64), 0, stream, (const uint32_t*)u32(w.cand_cnt),
+                           (const uint32_t*)u32(w.cand_d), (const uint64_t*)u64(w.cand_id), p.cand_cap, k, out_ids,
+                           out_dist, out_cnt);
         // fallback: only runs (device-side check) when some candidate list overflowed
         launch_robust(p.cap, dim3(p.fb_slices, p.qgroups), stream, codes, ids, n, p.fb_per_slice, queries, nq, k,
                       (const uint32_t*)u32(w.tau0), u64(w.part_ids), u32(w.part_d), u32(w.part_cnt),

@@ -142,8 +142,15 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
                      hipStream_t st) {
     const size_t n = s ? s->n : 0;
     if (ix->kind == UCFP_INDEX_HAMMING64) {
-        ucfp::HammingPlan p = ucfp::hamming_plan(n, (uint32_t)nq, k);
-        size_t need = ucfp::hamming_workspace_bytes(p, (uint32_t)nq, k) + 4096;
+        // query chunks of 4096 reuse one workspace (candidate lists are nq x cand_cap), stream-ordered
+        const size_t chunk = nq < 4096 ? nq : 4096;
+        ucfp::HammingPlan p = ucfp::hamming_plan(n, (uint32_t)chunk, k);
+        size_t need = ucfp::hamming_workspace_bytes(p, (uint32_t)chunk, k) + 4096;
+        if (nq % chunk) {   // the tail chunk has its own plan
+            const uint32_t tail = (uint32_t)(nq % chunk);
+            const size_t nt = ucfp::hamming_workspace_bytes(ucfp::hamming_plan(n, tail, k), tail, k) + 4096;
+            need = nt > need ? nt : need;
+        }
         uint32_t* keys = d_out_keys;
         size_t keys_off = 0;
         if (!keys) {
@@ -153,9 +160,14 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
         int rc = ix->ws.ensure(need);
         if (rc) return rc;
         if (!keys) keys = reinterpret_cast<uint32_t*>(ix->ws.p + keys_off);
-        ucfp::launch_hamming_search(s ? reinterpret_cast<const uint64_t*>(s->rows) : nullptr, s ? s->ids : nullptr,
-                                    n, reinterpret_cast<const uint64_t*>(d_queries), (uint32_t)nq, k, ix->ws.p, p,
-                                    d_out_ids, keys, d_out_scores, d_out_cnt, st);
+        const uint64_t* dq = reinterpret_cast<const uint64_t*>(d_queries);
+        for (size_t c0 = 0; c0 < nq; c0 += chunk) {
+            const uint32_t cn = (uint32_t)(nq - c0 < chunk ? nq - c0 : chunk);
+            if (cn != chunk) p = ucfp::hamming_plan(n, cn, k);
+            ucfp::launch_hamming_search(s ? reinterpret_cast<const uint64_t*>(s->rows) : nullptr, s ? s->ids : nullptr,
+                                        n, dq + c0, cn, k, ix->ws.p, p, d_out_ids + c0 * k, keys + c0 * k,
+                                        d_out_scores ? d_out_scores + c0 * k : nullptr, d_out_cnt + c0, st);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }

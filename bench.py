@@ -140,22 +140,24 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
         return None
     qps = nq * args.ann_steps / dt
     pairs_per_s = qps * corpus_total
-    # un-packed 32-bit VALU: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-op/s (the 157.3 TF
-    # datasheet figure counts packed FMA); tools/ubench_valu.hip measures 35-41 T on this chip
-    # (profiles/r01/ubench_valu.txt). The scan issues 73 VALU ops per 16 code-query pairs per lane.
-    valu_peak = 256 * 64 * 2.4e9
-    ops_per_pair = 73.0 / 16.0
+    # The filter is a +-1 x 0/1 byte contraction on v_mfma_i32_32x32x32_i8: 64 MACs = 128 int8 ops per
+    # code-query pair.  Dense i8 peak = 2 x the bf16 rate = 5 POP/s (MI355X_MICROARCH.md, matrix cores);
+    # tools/ubench_hamming_core.hip measures 26.7 T pairs/s (3.4 POP/s) for the bare inner loop on random
+    # operands (the chip clocks down under toggling data), 38 T on constant operands.
+    i8_peak = 5.0e15
+    ops_per_pair = 128.0
     return {
         "metric": "ANN queries/sec (Hamming k=10, brute force, exact)", "value": qps, "unit": "queries/s",
         "corpus_total": corpus_total, "corpus_per_gpu": n_local, "queries_per_batch": nq, "k": k,
         "ms_per_batch": dt / args.ann_steps * 1e3, "scaling": "strong",
         "exchange": "one all-gather of nq*k*(8+4) B per rank + merge on every rank" if world > 1 else "none",
         "pairs_per_s": pairs_per_s,
-        "roofline": {"bound": "valu", "achieved": pairs_per_s * ops_per_pair / world / 1e12,
-                     "peak": valu_peak / 1e12,
-                     "unit": "T lane-op/s per GPU (4.56 VALU ops per code-query pair: 2 xor, 2 bcnt, 0.56 min3/cmp)",
-                     "frac": pairs_per_s * ops_per_pair / world / valu_peak,
-                     "hbm_GBs_per_gpu": (nq / 64) * n_local * 8 / (dt / args.ann_steps) / 1e9},
+        "roofline": {"bound": "mfma", "kernel": "hamming_scan_mfma",
+                     "achieved": pairs_per_s * ops_per_pair / world / 1e12, "peak": i8_peak / 1e12,
+                     "unit": "TOP/s per GPU (int8 MFMA, 128 ops per code-query pair; whole search incl. staging, "
+                             "rescan and selection)",
+                     "frac": pairs_per_s * ops_per_pair / world / i8_peak,
+                     "hbm_GBs_per_gpu": ((nq + 2047) // 2048) * n_local * 8 / (dt / args.ann_steps) / 1e9},
         "planted_neighbours_found": f"{planted_found}/{(nq + 1) // 2}",
     }
 

@@ -256,7 +256,7 @@ constexpr int kQP = 2048;    // queries per pass (their +-1 image is resident in
 constexpr int kTB = 4;       // 32-code tiles per wave step
 constexpr int kMW = 8;       // waves per workgroup (2 per SIMD; the loop is software-pipelined inside a wave)
 constexpr int kStep = kTB * 32;
-constexpr int kRescanY = 8;  // rescan blocks per log slice
+constexpr int kRescanY = 32; // rescan blocks per log slice
 
 __device__ __forceinline__ uint32_t spread4(uint32_t nib) {   // bit i of nib -> byte i (0 / 1)
     return __umul24(nib, 0x204081u) & 0x01010101u;
@@ -285,6 +285,43 @@ size_t hamming_mfma_lds_bytes(uint32_t nq) {
     return (size_t)(tiles + 2) * (2048 + 128);   // +2: the drain tile and its operand prefetch
 }
 uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) * kMW; }
+
+// One code tile of the software-pipelined step, as text: MFMA (K half 0), four v_max3 folding the previous
+// tile's results, MFMA (K half 1, accumulating), four more.  %0 result, %1 running max, %2/%3 the code
+// tile's two K halves (A), %4/%5 the query tile's (B), %6..%21 the 16 previous results of this lane.
+#define UCFP_FOLD                                     \
+    "v_mfma_i32_32x32x32_i8 %0, %2, %4, 0\n\t"        \
+    "v_max3_i32 %1, %6, %7, %8\n\t"                   \
+    "v_max3_i32 %1, %1, %9, %10\n\t"                  \
+    "v_max3_i32 %1, %1, %11, %12\n\t"                 \
+    "v_max3_i32 %1, %1, %13, %14\n\t"                 \
+    "v_mfma_i32_32x32x32_i8 %0, %3, %5, %0\n\t"       \
+    "v_max3_i32 %1, %1, %15, %16\n\t"                 \
+    "v_max3_i32 %1, %1, %17, %18\n\t"                 \
+    "v_max3_i32 %1, %1, %19, %20\n\t"                 \
+    "v_max_i32 %1, %1, %21"
+// the last tile of a step also folds the four running maxima and compares with the lane's threshold:
+// %2 scratch, %3 = lane mask of (max >= thr) in an SGPR pair, inputs shifted by two, %24..%26 the other
+// three maxima, %27 the threshold
+#define UCFP_FOLD_LAST                                \
+    "v_mfma_i32_32x32x32_i8 %0, %4, %6, 0\n\t"        \
+    "v_max3_i32 %1, %8, %9, %10\n\t"                  \
+    "v_max3_i32 %1, %1, %11, %12\n\t"                 \
+    "v_max3_i32 %1, %1, %13, %14\n\t"                 \
+    "v_max3_i32 %1, %1, %15, %16\n\t"                 \
+    "v_mfma_i32_32x32x32_i8 %0, %5, %7, %0\n\t"       \
+    "v_max3_i32 %1, %1, %17, %18\n\t"                 \
+    "v_max3_i32 %1, %1, %19, %20\n\t"                 \
+    "v_max3_i32 %1, %1, %21, %22\n\t"                 \
+    "v_max_i32 %1, %1, %23\n\t"                       \
+    "v_max3_i32 %2, %1, %24, %25\n\t"                 \
+    "v_max_i32 %2, %2, %26\n\t"                       \
+    "v_cmp_ge_i32 %3, %2, %27\n\t"                  \
+    "s_nop 1"
+#define UCFP_FOLD_IN(b)                                                                                           \
+    "v"(A[b][0]), "v"(A[b][1]), "v"(b0), "v"(b1), "v"(Dp[b][0]), "v"(Dp[b][1]), "v"(Dp[b][2]), "v"(Dp[b][3]),     \
+        "v"(Dp[b][4]), "v"(Dp[b][5]), "v"(Dp[b][6]), "v"(Dp[b][7]), "v"(Dp[b][8]), "v"(Dp[b][9]), "v"(Dp[b][10]), \
+        "v"(Dp[b][11]), "v"(Dp[b][12]), "v"(Dp[b][13]), "v"(Dp[b][14]), "v"(Dp[b][15])
 
 // log record: x = query tile (global: q / 32), y = row - begin of the 32-code tile, (z, w) = lane ballot
 __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
@@ -331,6 +368,13 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
             x[b] = lo | (hi << 16);
         }
     };
+    // result buffers of the software pipeline.  Their content at the start of a code step is irrelevant:
+    // the first fold of every step runs against the threshold INT_MAX ("tile -1").
+    i32x16 D0[kTB], D1[kTB];
+#pragma unroll
+    for (int b = 0; b < kTB; b++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) D0[b][e] = D1[b][e] = 0;
     uint32_t x[kTB];
     load_codes(x, gwave);
     for (size_t st = gwave; st < nsuper; st += nwaves) {
@@ -352,32 +396,24 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         // written by VALU hundreds of cycles earlier.
         auto step = [&](uint32_t t, i32x16 (&Dn)[kTB], const i32x16 (&Dp)[kTB], const i32x4& b0, const i32x4& b1,
                         int thr, i32x4& n0, i32x4& n1, int& nthr) {
-            n0 = QB[(t + 1) * 128 + lane];   // operands of the next tile (the pad tiles end the array)
+            static_assert(kTB == 4, "four fold blocks");
+            int m0, m1, m2, m3, mm;
+            uint64_t hit;
+            // The "memory" clobbers keep the operand prefetch of the next tile (plain LDS loads: the compiler
+            // places their address arithmetic and waitcnt) where it is written, in the shadow of the first
+            // MFMAs; the verdict on tile t-1 (threshold `thr`) is taken inside the last MFMA's shadow.
+            asm volatile(UCFP_FOLD : "=&v"(Dn[0]), "=&v"(m0) : UCFP_FOLD_IN(0) : "memory");
+            n0 = QB[(t + 1) * 128 + lane];   // the pad tiles end the array
             n1 = QB[(t + 1) * 128 + 64 + lane];
             nthr = THR[(t + 1) * 32 + nn];
-            int m[kTB];
-#pragma unroll
-            for (int b = 0; b < kTB; b++) {
-                const i32x16& P = Dp[b];
-                asm volatile(
-                    "v_mfma_i32_32x32x32_i8 %0, %2, %4, 0\n\t"
-                    "v_max3_i32 %1, %6, %7, %8\n\t"
-                    "v_max3_i32 %1, %1, %9, %10\n\t"
-                    "v_max3_i32 %1, %1, %11, %12\n\t"
-                    "v_max3_i32 %1, %1, %13, %14\n\t"
-                    "v_mfma_i32_32x32x32_i8 %0, %3, %5, %0\n\t"
-                    "v_max3_i32 %1, %1, %15, %16\n\t"
-                    "v_max3_i32 %1, %1, %17, %18\n\t"
-                    "v_max3_i32 %1, %1, %19, %20\n\t"
-                    "v_max_i32 %1, %1, %21"
-                    : "=&v"(Dn[b]), "=&v"(m[b])
-                    : "v"(A[b][0]), "v"(A[b][1]), "v"(b0), "v"(b1), "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]),
-                      "v"(P[5]), "v"(P[6]), "v"(P[7]), "v"(P[8]), "v"(P[9]), "v"(P[10]), "v"(P[11]), "v"(P[12]),
-                      "v"(P[13]), "v"(P[14]), "v"(P[15]));
-            }
-            // m[] folds tile t-1 (its threshold was passed in as `thr`)
-            const int mm = max(max(m[0], m[1]), max(m[2], m[3]));
-            if (__builtin_expect(__any(mm >= thr), 0)) {
+            asm volatile(UCFP_FOLD : "=&v"(Dn[1]), "=&v"(m1) : UCFP_FOLD_IN(1) : "memory");
+            asm volatile(UCFP_FOLD : "=&v"(Dn[2]), "=&v"(m2) : UCFP_FOLD_IN(2) : "memory");
+            asm volatile(UCFP_FOLD_LAST
+                         : "=&v"(Dn[3]), "=&v"(m3), "=&v"(mm), "=s"(hit)
+                         : UCFP_FOLD_IN(3), "v"(m0), "v"(m1), "v"(m2), "v"(thr)
+                         : "memory");
+            if (__builtin_expect(hit != 0, 0)) {
+                const int m[kTB] = {m0, m1, m2, m3};
 #pragma unroll
                 for (int b = 0; b < kTB; b++) {
                     const uint64_t mask = __ballot(m[b] >= thr);
@@ -393,11 +429,6 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
                 }
             }
         };
-        i32x16 D0[kTB], D1[kTB];
-#pragma unroll
-        for (int b = 0; b < kTB; b++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) D1[b][e] = -0x7fffffff;   // "tile -1": below every threshold
         i32x4 p0 = QB[lane], p1 = QB[64 + lane], r0, r1;
         // tiles 0 .. ntiles: the last one is a pad tile that only drains the pipeline.  Two steps per
         // trip so that result and operand registers ping-pong without moves.  The fold inside step t

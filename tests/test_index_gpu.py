@@ -47,31 +47,33 @@ def test_hamming_matches_oracle(gpu_ctx, oracle, n, nq, k):
     ix.close()
 
 
-def test_hamming_massive_ties_and_duplicates(gpu_ctx, oracle):
+@pytest.mark.parametrize("n,extra_q", [(40000, 0), (300_000, 0), (300_000, 90)])
+def test_hamming_massive_ties_and_duplicates(gpu_ctx, oracle, n, extra_q):
     """All rows identical (every distance ties) and a corpus of few distinct codes: the id
-    tie-break alone decides, under the heaviest slow-path load."""
+    tie-break alone decides, under the heaviest slow-path load (robust tier, lane scan, matrix-core scan)."""
     from ucfp_amd import index
     rng = np.random.default_rng(9)
-    n = 40000
     ids = rng.permutation(n).astype(np.uint64)
     for codes in (np.full(n, 0xDEADBEEFCAFEF00D, np.uint64),
                   rng.choice(np.array([1, 3, 7, 2**63], np.uint64), n)):
         ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
         ix.upsert(0, ids, codes)
-        q = np.array([0xDEADBEEFCAFEF00D, 0, 1], np.uint64)
+        q = np.concatenate([np.array([0xDEADBEEFCAFEF00D, 0, 1], np.uint64),
+                            rng.integers(0, 2**64, extra_q, dtype=np.uint64)])
         g_ids, _, g_d, g_c = ix.search(0, q, 10)
         o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, q, 10)
         assert np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids) and np.array_equal(g_c, o_c)
         ix.close()
 
 
-def test_hamming_adversarial_order(gpu_ctx, oracle):
+@pytest.mark.parametrize("nq", [8, 100])
+def test_hamming_adversarial_order(gpu_ctx, oracle, nq):
     """The sample pre-pass only sees the head of the corpus; put all near neighbours at the tail
     and far codes (distance ~64) at the head so tau0 is useless. Correctness must not depend on it."""
     from ucfp_amd import index
     rng = np.random.default_rng(4)
     n = 300000
-    q = rng.integers(0, 2**64, 8, dtype=np.uint64)
+    q = rng.integers(0, 2**64, nq, dtype=np.uint64)
     codes = np.empty(n, np.uint64)
     codes[:] = ~q[0]                       # far from q[0] everywhere
     codes[n - 5000:] = q[0] ^ rng.integers(0, 2**12, 5000, dtype=np.uint64)  # near, at the tail
@@ -84,9 +86,13 @@ def test_hamming_adversarial_order(gpu_ctx, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("n,nq,k", [(1_200_000, 70, 10), (2_500_000, 9, 10), (1_100_000, 3, 64)])
+@pytest.mark.parametrize("n,nq,k", [(1_200_000, 70, 10), (2_500_000, 9, 10), (1_100_000, 3, 64),
+                                    (300_000, 130, 10), (777_777, 300, 37), (600_000, 2100, 5),
+                                    (400_003, 65, 128), (262_144, 64, 10), (262_145, 97, 1)])
 def test_hamming_two_tier_matches_oracle(gpu_ctx, oracle, n, nq, k):
-    """n >= 2^20 takes the prefix + fast-filter path (hamming_scan_fast / hamming_final_merge)."""
+    """n >= 2^18 takes the staged filter path: the matrix-core scan (hamming_scan_mfma + hamming_rescan)
+    for more than 64 queries, the lane-per-code scan (hamming_scan_lanes) below; ragged tails, two
+    query passes (nq > 2048), k up to 128."""
     from ucfp_amd import index
     rng = np.random.default_rng(n + k)
     ids, codes, queries = _planted_corpus(rng, n, nq, planted_per_q=12)
@@ -98,13 +104,15 @@ def test_hamming_two_tier_matches_oracle(gpu_ctx, oracle, n, nq, k):
     ix.close()
 
 
-def test_hamming_two_tier_overflow_falls_back(gpu_ctx, oracle):
-    """Prefix far from the query (tau1 = 64) and a tail full of near rows: every candidate list
-    overflows, the device-side flag routes the batch through the robust tier, results stay exact."""
+@pytest.mark.parametrize("nq", [5, 80])
+def test_hamming_two_tier_overflow_falls_back(gpu_ctx, oracle, nq):
+    """Prefix far from the query (tau = 64) and a tail full of near rows: every candidate list (and, on
+    the matrix-core path, the suspect-block log) overflows, the device-side flag routes the batch through
+    the robust tier, results stay exact."""
     from ucfp_amd import index
     rng = np.random.default_rng(77)
     n = 1_300_000
-    q = rng.integers(0, 2**64, 5, dtype=np.uint64)
+    q = rng.integers(0, 2**64, nq, dtype=np.uint64)
     codes = rng.integers(0, 2**64, n, dtype=np.uint64)
     codes[: n // 4] = ~q[0]                                   # prefix: distance 64 from q[0]
     codes[n // 2:] = q[0] ^ rng.integers(0, 2**10, n - n // 2, dtype=np.uint64)  # tail: d <= 10

@@ -498,6 +498,81 @@ __global__ __launch_bounds__(64) void hamming_rescan(
     }
 }
 
+// ---- few queries: lane = code ---------------------------------------------------------------
+// With a handful of queries the matrix cores have nothing to amortise the operand expansion over and
+// the scan is a pure HBM stream: each lane holds 8 codes (4 x 16-byte loads in flight), the queries
+// and their thresholds are wave-uniform (SGPRs), a pair costs 2 v_xor + 2 v_bcnt + 1 compare, and the
+// rare candidate is appended to its query's list directly.  Same staging and lists as the MFMA filter.
+constexpr int kFewQueries = 64;
+
+__global__ __launch_bounds__(256) void hamming_sample_hist_lanes(const uint64_t* __restrict__ codes, size_t sample_n,
+                                                                 const uint64_t* __restrict__ queries, uint32_t nq,
+                                                                 uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[kFewQueries * 65];
+    for (uint32_t i = threadIdx.x; i < nq * 65; i += 256) h[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < sample_n; i += (size_t)gridDim.x * 256) {
+        const uint64_t c = codes[i];
+        for (uint32_t j = 0; j < nq; j++) atomicAdd(&h[j * 65 + (uint32_t)__popcll(c ^ queries[j])], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nq * 65; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(256) void hamming_scan_lanes(
+    const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t begin, size_t end,
+    const uint64_t* __restrict__ queries, uint32_t nq, const uint32_t* __restrict__ tau,
+    uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id,
+    uint32_t cand_cap, uint32_t* __restrict__ overflow) {
+    constexpr int kC = 8;   // codes per lane per trip
+    const size_t trip = (size_t)gridDim.x * 256 * kC;
+    for (size_t base = begin + (size_t)blockIdx.x * 256 * kC; base < end; base += trip) {
+        // lane l owns codes base + 2 l + {0, 1} + 512 k'  (k' = 0..3): 16-byte loads, 1 KiB contiguous per wave
+        uint64_t c[kC];
+        size_t row[kC];
+#pragma unroll
+        for (int k = 0; k < kC; k += 2) {
+            row[k] = base + (size_t)(k / 2) * 512 + 2 * threadIdx.x;
+            row[k + 1] = row[k] + 1;
+            if (row[k + 1] < end) {
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(codes + row[k]));
+                c[k] = v[0];
+                c[k + 1] = v[1];
+            } else {
+                c[k] = row[k] < end ? codes[row[k]] : 0ull;
+                c[k + 1] = 0ull;
+            }
+        }
+        for (uint32_t j = 0; j < nq; j++) {
+            const uint64_t q = queries[j];   // wave-uniform: scalar loads
+            const uint32_t t = tau[j];
+            uint32_t d[kC];
+            uint32_t best = 64;
+#pragma unroll
+            for (int k = 0; k < kC; k++) {
+                d[k] = (uint32_t)__popcll(c[k] ^ q);
+                best = d[k] < best ? d[k] : best;
+            }
+            if (__any(best <= t)) {
+#pragma unroll
+                for (int k = 0; k < kC; k++) {
+                    if (d[k] <= t && row[k] < end) {
+                        const uint32_t pos = atomicAdd(&cand_cnt[j], 1u);
+                        if (pos < cand_cap) {
+                            cand_d[(size_t)j * cand_cap + pos] = d[k];
+                            cand_id[(size_t)j * cand_cap + pos] = ids[row[k]];
+                        } else {
+                            *overflow = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // tau1[q] = k-th smallest distance among q's candidates so far (one wave per query); also the exact
 // bound the second stage filters with.  Fewer than k candidates (only after an overflow) -> keep tau0.
 __global__ __launch_bounds__(64) void hamming_list_tau(const uint32_t* __restrict__ cand_cnt,
@@ -745,8 +820,12 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
     }
     // tau0 from the sample
     (void)hipMemsetAsync(u32(w.hist), 0, (size_t)nq * 65 * 4, stream);
-    hipLaunchKernelGGL(hamming_sample_hist, dim3(p.sample_parts, p.qgroups), dim3(64), 0, stream, codes,
-                       p.sample_n, p.per_part, queries, nq, u32(w.hist));
+    if (nq <= (uint32_t)kFewQueries)
+        hipLaunchKernelGGL(hamming_sample_hist_lanes, dim3((unsigned)((p.sample_n + 1023) / 1024)), dim3(256), 0, stream,
+                           codes, p.sample_n, queries, nq, u32(w.hist));
+    else
+        hipLaunchKernelGGL(hamming_sample_hist, dim3(p.sample_parts, p.qgroups), dim3(64), 0, stream, codes,
+                           p.sample_n, p.per_part, queries, nq, u32(w.hist));
     hipLaunchKernelGGL(hamming_tau0, dim3((nq + 255) / 256), dim3(256), 0, stream, u32(w.hist), nq, k,
                        u32(w.tau0));
     if (!p.fast) {
@@ -773,6 +852,14 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             const size_t supers = (end - begin + kStep - 1) / kStep;
             unsigned wgs = 256;   // one workgroup of kMW waves per CU (the query image fills its LDS)
             if ((size_t)wgs * kMW > supers) wgs = (unsigned)((supers + kMW - 1) / kMW);
+            if (nq <= (uint32_t)kFewQueries) {
+                const size_t per_block = 256 * 8;
+                size_t blocks = (end - begin + per_block - 1) / per_block;
+                if (blocks > 256 * 8) blocks = 256 * 8;
+                hipLaunchKernelGGL(hamming_scan_lanes, dim3((unsigned)blocks), dim3(256), 0, stream, codes, ids, begin,
+                                   end, queries, nq, (const uint32_t*)tau_cur, u32(w.cand_cnt), u32(w.cand_d),
+                                   u64(w.cand_id), p.cand_cap, u32(w.overflow));
+            } else {
             (void)hipMemsetAsync(u32(w.log_cnt), 0, (size_t)slices * 4, stream);
             hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(kMW * 64), lds, stream, codes, begin, end,
                                queries, nq, (const uint32_t*)tau_cur, reinterpret_cast<uint4*>(ws + w.log),
@@ -781,6 +868,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                                queries, (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
                                u64(w.cand_id), p.cand_cap, u32(w.overflow));
+            }
             if (sidx + 1 < p.nstages) {
                 hipLaunchKernelGGL(hamming_list_tau, dim3(nq), dim3(64), 0, stream, (const uint32_t*)u32(w.cand_cnt),
                                    (const uint32_t*)u32(w.cand_d), p.cand_cap, k, (const uint32_t*)tau_cur, tau_nxt);

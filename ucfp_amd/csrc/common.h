@@ -41,6 +41,7 @@ struct HammingPlan {
     uint32_t fb_slices = 0;     // fallback robust scan over [0, n), device-gated on overflow
     size_t fb_per_slice = 0;
 };
+constexpr uint32_t kHammingMaxBatch = 4096;   // queries per launch_hamming_search call (workspace and log sizing)
 HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k);
 size_t hamming_workspace_bytes(const HammingPlan& p, uint32_t nq, uint32_t k);
 int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,

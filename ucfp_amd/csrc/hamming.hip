@@ -41,41 +41,66 @@ __device__ __forceinline__ uint32_t hamming64(uint64_t q, uint64_t x) {
 }
 
 // ---- sample pre-pass --------------------------------------------------------------------
-// grid (parts, qgroups), block 64. hist layout: [q][65] u32 (global, zeroed by the launcher).
-__global__ __launch_bounds__(64) void hamming_sample_hist(const uint64_t* __restrict__ codes,
-                                                          size_t sample_n, size_t per_part,
-                                                          const uint64_t* __restrict__ queries,
-                                                          uint32_t nq, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[65 * kWave];  // [bin][lane]: lane-private columns, conflict-free
-    const int lane = threadIdx.x;
+// hist layout: [q][65] u32 (global, zeroed by the launcher).
+// grid (parts, qgroups), block 256: four waves scan a quarter of the part each for the same 64 queries and
+// share one LDS histogram (more waves in flight to hide the scalar-load latency, one flush per block).
+__global__ __launch_bounds__(256) void hamming_sample_hist(const uint64_t* __restrict__ codes,
+                                                           size_t sample_n, size_t per_part,
+                                                           const uint64_t* __restrict__ queries,
+                                                           uint32_t nq, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[65 * kWave];  // [bin][query lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.y * kWave + lane;
-    for (int b = 0; b < 65; b++) h[b * kWave + lane] = 0;
+    for (int b = threadIdx.x; b < 65 * kWave; b += 256) h[b] = 0;
+    __syncthreads();
     const uint64_t qv = queries[q < nq ? q : nq - 1];
-    const size_t s0 = (size_t)blockIdx.x * per_part;
-    const size_t s1 = s0 + per_part < sample_n ? s0 + per_part : sample_n;
-    for (size_t i = s0; i < s1; i++) {
-        const uint64_t x = codes[i];  // wave-uniform address -> scalar load
-        const uint32_t d = hamming64(qv, x);
-        h[d * kWave + lane] += 1;
+    const size_t p0 = (size_t)blockIdx.x * per_part;
+    const size_t p1 = p0 + per_part < sample_n ? p0 + per_part : sample_n;
+    const size_t quarter = (p1 - p0 + 3) / 4;
+    const size_t s0 = p0 + wave * quarter < p1 ? p0 + wave * quarter : p1;
+    const size_t s1 = s0 + quarter < p1 ? s0 + quarter : p1;
+    size_t i = s0;
+    for (; i + 16 <= s1; i += 16) {   // 16 codes per trip: two s_load_dwordx16, one scalar-load latency per trip
+        uint64_t x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = codes[i + j];   // wave-uniform address -> scalar loads
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            atomicAdd(&h[hamming64(qv, x[j]) * kWave + lane], 1u);   // ds_add without return: no RMW latency chain
     }
-    if (q < nq) {
-        for (int b = 0; b < 65; b++) {
-            const uint32_t c = h[b * kWave + lane];
-            if (c) atomicAdd(&hist[(size_t)q * 65 + b], c);
-        }
-    }
+    for (; i < s1; i++) atomicAdd(&h[hamming64(qv, codes[i]) * kWave + lane], 1u);
+    __syncthreads();
+    // partial histogram of this part: hist[part][bin][query], plain coalesced stores (no atomics, no memset)
+    const size_t nqp = (size_t)gridDim.y * kWave;
+    for (int e = threadIdx.x; e < 65 * kWave; e += 256)
+        hist[((size_t)blockIdx.x * 65 + (e >> 6)) * nqp + blockIdx.y * kWave + (e & 63)] = h[e];
 }
 
-__global__ void hamming_tau0(const uint32_t* __restrict__ hist, uint32_t nq, uint32_t k,
-                             uint32_t* __restrict__ tau0) {
+// sum of the partial histograms [part][bin][padded q] into part 0, one thread per (bin, q): 32 independent loads
+__global__ void hamming_hist_reduce(uint32_t* __restrict__ hist, uint32_t parts, uint32_t nq_padded) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)65 * nq_padded) return;
+    uint32_t c = 0;
+    for (uint32_t p = 0; p < parts; p++) c += hist[(size_t)p * 65 * nq_padded + i];
+    hist[i] = c;
+}
+
+// stride_b / stride_q: hist[b * stride_b + q * stride_q]  ([q][65] on the few-query path, [bin][padded q] otherwise)
+__global__ void hamming_tau0(const uint32_t* __restrict__ hist, uint32_t nq, uint32_t k, uint32_t stride_b,
+                             uint32_t stride_q, uint32_t* __restrict__ tau0) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
+    uint32_t c[65];
+#pragma unroll
+    for (int b = 0; b < 65; b++) c[b] = hist[(size_t)b * stride_b + (size_t)q * stride_q];   // 65 loads in flight
     uint32_t cum = 0, t = 64;
-    for (uint32_t b = 0; b < 65; b++) {
-        cum += hist[(size_t)q * 65 + b];
-        if (cum >= k) {
+    bool done = false;
+#pragma unroll
+    for (int b = 0; b < 65; b++) {
+        cum += c[b];
+        if (!done && cum >= k) {
             t = b;
-            break;
+            done = true;
         }
     }
     tau0[q] = t;  // 64 when the sample holds fewer than k codes: accept everything
@@ -256,7 +281,6 @@ constexpr int kQP = 2048;    // queries per pass (their +-1 image is resident in
 constexpr int kTB = 4;       // 32-code tiles per wave step
 constexpr int kMW = 8;       // waves per workgroup (2 per SIMD; the loop is software-pipelined inside a wave)
 constexpr int kStep = kTB * 32;
-constexpr int kRescanY = 32; // rescan blocks per log slice
 
 __device__ __forceinline__ uint32_t spread4(uint32_t nib) {   // bit i of nib -> byte i (0 / 1)
     return __umul24(nib, 0x204081u) & 0x01010101u;
@@ -323,11 +347,22 @@ uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) 
         "v"(Dp[b][4]), "v"(Dp[b][5]), "v"(Dp[b][6]), "v"(Dp[b][7]), "v"(Dp[b][8]), "v"(Dp[b][9]), "v"(Dp[b][10]), \
         "v"(Dp[b][11]), "v"(Dp[b][12]), "v"(Dp[b][13]), "v"(Dp[b][14]), "v"(Dp[b][15])
 
+// +-1 image of the query batch in the scan's LDS layout, built once per search: [tile][K half][lane] 16 B
+__global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __restrict__ queries, uint32_t nq,
+                                                           i32x4* __restrict__ img) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= ((nq + 31) / 32) * 128) return;
+    const uint32_t t = s >> 7, h = (s >> 6) & 1, l = s & 63, q = t * 32 + (l & 31);
+    i32x4 v = {0, 0, 0, 0};   // dead columns are all-zero: their sums are 0
+    if (q < nq) v = expand_pm1((uint32_t)(queries[q] >> (32 * h + 16 * (l >> 5))) & 0xffffu);
+    img[s] = v;
+}
+
 // log record: x = query tile (global: q / 32), y = row - begin of the 32-code tile, (z, w) = lane ballot
 __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint64_t* __restrict__ codes, size_t begin, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
-    const uint32_t* __restrict__ tau, uint4* __restrict__ log, uint32_t* __restrict__ log_cnt, uint32_t log_cap,
-    uint32_t* __restrict__ overflow) {
+    const i32x4* __restrict__ qimg, const uint32_t* __restrict__ tau, uint4* __restrict__ log,
+    uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
     const uint32_t q0 = blockIdx.y * kQP;
     const uint32_t nqp = nq - q0 < (uint32_t)kQP ? nq - q0 : (uint32_t)kQP;
@@ -335,16 +370,38 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     // [tile][K half][lane] 16 B: the B operand of query tile t, K half h, is one ds_read_b128 per lane
     i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
     int* THR = reinterpret_cast<int*>(mf_lds + (size_t)(ntiles + 2) * 2048);   // [tile][32]
-    for (uint32_t s = threadIdx.x; s < (ntiles + 2) * 128; s += kMW * 64) {
-        const uint32_t t = s >> 7, h = (s >> 6) & 1, l = s & 63, q = q0 + t * 32 + (l & 31);
-        i32x4 v = {0, 0, 0, 0};
-        if (t < ntiles && q < nq) v = expand_pm1((uint32_t)(queries[q] >> (32 * h + 16 * (l >> 5))) & 0xffffu);
-        QB[s] = v;
+    // copy of the prebuilt image + 2 zero pad tiles; 8 loads in flight per thread (a plain loop would pay the
+    // global latency 17 times in a row)
+    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 128; s0 += kMW * 64 * 8) {
+        i32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t s = s0 + u * kMW * 64;
+            v[u] = s < ntiles * 128 ? qimg[(size_t)(q0 / 32) * 128 + s] : i32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t s = s0 + u * kMW * 64;
+            if (s < (ntiles + 2) * 128) QB[s] = v[u];
+        }
     }
-    for (uint32_t s = threadIdx.x; s < (ntiles + 2) * 32; s += kMW * 64) {
-        const uint32_t q = q0 + s;
-        // dead columns (and the pad tiles) are all-zero: their sums are 0, below this threshold
-        THR[s] = ((s >> 5) < ntiles && q < nq) ? (int)__popcll(queries[q]) - (int)tau[q] : 0x7fffffff;
+    {   // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) are all-zero, their sums stay below INT_MAX
+        constexpr int kT = (kQP / 32 + 2) * 32 / (kMW * 64) + 1;   // slots per thread
+        uint64_t qv[kT];
+        uint32_t tv[kT];
+#pragma unroll
+        for (int u = 0; u < kT; u++) {
+            const uint32_t s = threadIdx.x + u * kMW * 64, q = q0 + s;
+            const bool live = s < ntiles * 32 && q < nq;
+            qv[u] = live ? queries[q] : 0ull;
+            tv[u] = live ? tau[q] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kT; u++) {
+            const uint32_t s = threadIdx.x + u * kMW * 64, q = q0 + s;
+            if (s < (ntiles + 2) * 32)
+                THR[s] = (s < ntiles * 32 && q < nq) ? (int)__popcll(qv[u]) - (int)tv[u] : 0x7fffffff;
+        }
     }
     __syncthreads();
 
@@ -450,51 +507,65 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     if (lane == 0) log_cnt[slice] = ln < log_cap ? ln : log_cap;
 }
 
-// grid (log slices, kRescanY), one wave per block: exact distances for the flagged (query, 16-code half)
-// lanes of every record; true candidates are appended to the per-query lists.
-__global__ __launch_bounds__(64) void hamming_rescan(
+// One block per log slice, one LANE per record: exact distances for the flagged (query, 16 results) lanes of
+// the record; true candidates are appended to the per-query lists.
+__global__ __launch_bounds__(256) void hamming_rescan(
     const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t begin, size_t end,
     const uint64_t* __restrict__ queries, const uint32_t* __restrict__ tau, const uint4* __restrict__ log,
     const uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ cand_cnt,
     uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id, uint32_t cand_cap, uint32_t* __restrict__ overflow) {
-    const int lane = threadIdx.x;
-    const int nn = lane & 31, hh = lane >> 5;
     const uint32_t cnt = log_cnt[blockIdx.x];
-    for (uint32_t i = blockIdx.y; i < cnt; i += gridDim.y) {
-        const uint4 r = log[(size_t)blockIdx.x * log_cap + i];
-        const uint64_t mask = (uint64_t)r.z | ((uint64_t)r.w << 32);
-        if (!((mask >> lane) & 1)) continue;
-        const uint32_t q = r.x * 32 + nn;          // a flagged lane always has a live query
-        const uint64_t qv = queries[q];
-        const uint32_t tq = tau[q];
-        // the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
-        const size_t row0 = begin + r.y + 4 * hh;
-        uint64_t cv[16];
+    for (uint32_t rix = threadIdx.x; rix < cnt; rix += 256) {
+        const uint4 r = log[(size_t)blockIdx.x * log_cap + rix];
+        uint64_t mask = (uint64_t)r.z | ((uint64_t)r.w << 32);
+        while (mask) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint32_t q = r.x * 32 + (l & 31);   // a flagged lane always has a live query
+            const uint64_t qv = queries[q];
+            const uint32_t tq = tau[q];
+            // the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
+            const size_t row0 = begin + r.y + 4 * (l >> 5);
+            uint64_t cv[16];
+            if (row0 + 28 <= end) {   // four groups of four consecutive codes: 16-byte loads (row0 is a multiple of 4)
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const size_t row = row0 + (j & 3) + 8 * (j >> 2);
-            cv[j] = codes[row < end ? row : begin];
-        }
-        bool found = false;
+                for (int g = 0; g < 4; g++) {
+                    const u64x2 a = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g);
+                    const u64x2 b = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g + 2);
+                    cv[4 * g] = a[0];
+                    cv[4 * g + 1] = a[1];
+                    cv[4 * g + 2] = b[0];
+                    cv[4 * g + 3] = b[1];
+                }
+            } else {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const size_t row = row0 + (j & 3) + 8 * (j >> 2);
-            const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
-            if (d <= tq && row < end) {
-                found = true;
-                const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
-                if (pos < cand_cap) {
-                    cand_d[(size_t)q * cand_cap + pos] = d;
-                    cand_id[(size_t)q * cand_cap + pos] = ids[row];
-                } else {
-                    *overflow = 1;
+                for (int j = 0; j < 16; j++) {
+                    const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+                    cv[j] = codes[row < end ? row : begin];
                 }
             }
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+                const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
+                if (d <= tq && row < end) {
+                    found = true;
+                    const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
+                    if (pos < cand_cap) {
+                        cand_d[(size_t)q * cand_cap + pos] = d;
+                        cand_id[(size_t)q * cand_cap + pos] = ids[row];
+                    } else {
+                        *overflow = 1;
+                    }
+                }
+            }
+            // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
+            // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
+            // this kernel disagree about the result layout -> distrust the filter, take the robust tier
+            if (!found && (int)__popcll(qv) - (int)tq > 0) *overflow = 1;
         }
-        // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
-        // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
-        // this kernel disagree about the result layout -> distrust the filter, take the robust tier
-        if (!found && (int)__popcll(qv) - (int)tq > 0) *overflow = 1;
     }
 }
 
@@ -590,7 +661,7 @@ __global__ __launch_bounds__(64) void hamming_list_tau(const uint32_t* __restric
     for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[cand_d[(size_t)q * cand_cap + c]], 1u);
     wave_lds_sync();
     if (lane == 0) {
-        uint32_t cum = 0, t = tau0[q];
+        uint32_t cum = 0, t = tau0[q];   // fewer than k candidates so far: the previous threshold stands
         for (uint32_t b = 0; b < 65; b++) {
             cum += h[b];
             if (cum >= k) {
@@ -763,14 +834,14 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
 
 namespace {
 struct HammingWs {
-    size_t hist, tau0, part_ids, part_d, part_cnt, tau1, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, total;
+    size_t hist, tau0, part_ids, part_d, part_cnt, tau1, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, qimg, total;
 };
 HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     HammingWs w;
     size_t off = 0;
     const uint32_t ms = p.slices > p.fb_slices ? p.slices : p.fb_slices;
-    w.hist = off;      off = align(off + (size_t)nq * 65 * 4);
+    w.hist = off;      off = align(off + (size_t)(p.sample_parts ? p.sample_parts : 1) * 65 * p.qgroups * kWave * 4);
     w.tau0 = off;      off = align(off + (size_t)nq * 4);
     w.part_ids = off;  off = align(off + (size_t)ms * nq * k * 8);
     w.part_d = off;    off = align(off + (size_t)ms * nq * k * 4);
@@ -782,6 +853,7 @@ HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     w.cand_id = off;   off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 8 : 0));
     w.log_cnt = off;   off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * 4 : 0));
     w.log = off;       off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * p.log_cap * 16 : 0));
+    w.qimg = off;      off = align(off + (p.fast ? (size_t)((nq + 31) / 32) * 128 * 16 : 0));
     w.total = off;
     return w;
 }
@@ -803,6 +875,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                           const HammingPlan& p, uint64_t* out_ids, uint32_t* out_dist,
                           float* out_scores, uint32_t* out_cnt, hipStream_t stream) {
     if (nq == 0) return 0;
+    if (nq > kHammingMaxBatch) return -1;   // callers chunk (index.hip)
     const HammingWs w = hamming_ws_layout(p, nq, k);
     auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
     auto u64 = [&](size_t off) { return reinterpret_cast<uint64_t*>(ws + off); };
@@ -819,15 +892,21 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         return 0;
     }
     // tau0 from the sample
-    (void)hipMemsetAsync(u32(w.hist), 0, (size_t)nq * 65 * 4, stream);
-    if (nq <= (uint32_t)kFewQueries)
+    if (nq <= (uint32_t)kFewQueries) {
+        (void)hipMemsetAsync(u32(w.hist), 0, (size_t)nq * 65 * 4, stream);
         hipLaunchKernelGGL(hamming_sample_hist_lanes, dim3((unsigned)((p.sample_n + 1023) / 1024)), dim3(256), 0, stream,
                            codes, p.sample_n, queries, nq, u32(w.hist));
-    else
-        hipLaunchKernelGGL(hamming_sample_hist, dim3(p.sample_parts, p.qgroups), dim3(64), 0, stream, codes,
+        hipLaunchKernelGGL(hamming_tau0, dim3((nq + 255) / 256), dim3(256), 0, stream, (const uint32_t*)u32(w.hist), nq,
+                           k, 1u, 65u, u32(w.tau0));
+    } else {
+        hipLaunchKernelGGL(hamming_sample_hist, dim3(p.sample_parts, p.qgroups), dim3(256), 0, stream, codes,
                            p.sample_n, p.per_part, queries, nq, u32(w.hist));
-    hipLaunchKernelGGL(hamming_tau0, dim3((nq + 255) / 256), dim3(256), 0, stream, u32(w.hist), nq, k,
-                       u32(w.tau0));
+        const uint32_t nqp = p.qgroups * kWave;
+        hipLaunchKernelGGL(hamming_hist_reduce, dim3((65 * nqp + 255) / 256), dim3(256), 0, stream, u32(w.hist),
+                           p.sample_parts, nqp);
+        hipLaunchKernelGGL(hamming_tau0, dim3((nq + 63) / 64), dim3(64), 0, stream, (const uint32_t*)u32(w.hist), nq, k,
+                           nqp, 1u, u32(w.tau0));
+    }
     if (!p.fast) {
         // robust tier over the whole (small) corpus: exact top-k straight into the outputs
         launch_robust(p.cap, dim3(p.slices, p.qgroups), stream, codes, ids, n, p.per_slice, queries, nq, k,
@@ -844,6 +923,10 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(hamming_reset_lists, dim3((nq + 255) / 256), dim3(256), 0, stream, nq, u32(w.cand_cnt),
                            u32(w.overflow));
+        i32x4* qimg = reinterpret_cast<i32x4*>(ws + w.qimg);
+        if (nq > (uint32_t)kFewQueries)
+            hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 128 + 255) / 256), dim3(256), 0, stream, queries,
+                               nq, qimg);
         uint32_t* tau_cur = u32(w.tau0);
         uint32_t* tau_nxt = u32(w.tau1);
         size_t begin = 0;
@@ -862,10 +945,10 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             } else {
             (void)hipMemsetAsync(u32(w.log_cnt), 0, (size_t)slices * 4, stream);
             hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(kMW * 64), lds, stream, codes, begin, end,
-                               queries, nq, (const uint32_t*)tau_cur, reinterpret_cast<uint4*>(ws + w.log),
-                               u32(w.log_cnt), p.log_cap, u32(w.overflow));
-            hipLaunchKernelGGL(hamming_rescan, dim3(slices, kRescanY), dim3(64), 0, stream, codes, ids, begin, end,
-                               queries, (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
+                               queries, nq, (const i32x4*)qimg, (const uint32_t*)tau_cur,
+                               reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow));
+            hipLaunchKernelGGL(hamming_rescan, dim3(slices), dim3(256), 0, stream, codes, ids, begin, end, queries,
+                               (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
                                u64(w.cand_id), p.cand_cap, u32(w.overflow));
             }

@@ -142,8 +142,8 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
                      hipStream_t st) {
     const size_t n = s ? s->n : 0;
     if (ix->kind == UCFP_INDEX_HAMMING64) {
-        // query chunks of 4096 reuse one workspace (candidate lists are nq x cand_cap), stream-ordered
-        const size_t chunk = nq < 4096 ? nq : 4096;
+        // query chunks of kHammingMaxBatch reuse one workspace (candidate lists are nq x cand_cap), stream-ordered
+        const size_t chunk = nq < ucfp::kHammingMaxBatch ? nq : ucfp::kHammingMaxBatch;
         ucfp::HammingPlan p = ucfp::hamming_plan(n, (uint32_t)chunk, k);
         size_t need = ucfp::hamming_workspace_bytes(p, (uint32_t)chunk, k) + 4096;
         if (nq % chunk) {   // the tail chunk has its own plan

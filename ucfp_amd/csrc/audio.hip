@@ -64,14 +64,17 @@ struct FftLds {
     float2 buf[4][N + 64];   // per wave; reused as the power spectrum (float[N/2]) afterwards
 };
 
-__device__ __forceinline__ void bfly(float& ur, float& ui, float& xr, float& xi, float c, float sn) {
-    const float t1 = xr * c, t2 = xi * sn, t3 = xr * sn, t4 = xi * c;
-    const float vr = t1 - t2, vi = t3 + t4;
-    const float ar = ur, ai = ui;
-    ur = ar + vr;
-    ui = ai + vi;
-    xr = ar - vr;
-    xi = ai - vi;
+// One radix-2 butterfly on (re, im) pairs in packed f32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations
+// per lane per instruction, so 6 instructions instead of 10).  Same operations in the same order as the
+// oracle: t1 = xr c, t2 = xi s, t3 = xr s, t4 = xi c, v = (t1 - t2, t3 + t4), u' = u + v, x' = u - v.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bfly(f32x2& u, f32x2& x, float c, float sn) {
+    const f32x2 a = x * f32x2{c, c};                    // (t1, t4)
+    const f32x2 b = f32x2{x.y, x.x} * f32x2{sn, sn};    // (t2, t3)
+    const f32x2 v = a + f32x2{-b.x, b.y};               // (t1 - t2, t4 + t3)
+    const f32x2 w = u;
+    u = w + v;
+    x = w - v;
 }
 
 template <int N>
@@ -81,7 +84,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
     constexpr int B = E == 16 ? 4 : 5;
     constexpr int BITS = N == 1024 ? 10 : 11;
     constexpr int TWS = 2048 / N;
-    float xr[E], xi[E];
+    f32x2 x[E];
     // ---- load + window, element i of lane L is p = E*L + i = bit-reversed sample index ----
     const uint32_t rl = __brev((uint32_t)lane) >> 26;  // 6-bit reversal of the lane
 #pragma unroll
@@ -91,8 +94,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         float c = tw[(n * TWS) & 1023][0];
         if (n * TWS >= 1024) c = -c;
         const float w = 0.5f - 0.5f * c;
-        xr[i] = src[n] * w;
-        xi[i] = 0.0f;
+        x[i] = f32x2{src[n] * w, 0.0f};
     }
     // ---- phase 1: stages 1..B on bits 0..B-1 (register index), twiddles are table constants ----
 #pragma unroll
@@ -102,20 +104,19 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         for (int i0 = 0; i0 < E; i0++) {
             if (i0 & half) continue;
             const int jj = i0 & (half - 1);
-            bfly(xr[i0], xi[i0], xr[i0 + half], xi[i0 + half], c_tw[jj * tstep][0], c_tw[jj * tstep][1]);
+            bfly(x[i0], x[i0 + half], c_tw[jj * tstep][0], c_tw[jj * tstep][1]);
         }
     }
     // ---- transpose 1 ----
 #pragma unroll
-    for (int i = 0; i < E; i++) buf[(E + 1) * lane + i] = make_float2(xr[i], xi[i]);   // p + p/E, p = E*lane + i
+    for (int i = 0; i < E; i++) buf[(E + 1) * lane + i] = make_float2(x[i].x, x[i].y);   // p + p/E, p = E*lane + i
     wave_lds_sync();
     const int lo = lane & (E - 1), hi = lane >> B;
 #pragma unroll
     for (int m = 0; m < E; m++) {
         const int pp = hi * E * E + m * E + lo;
         const float2 v = buf[pp + (pp >> B)];
-        xr[m] = v.x;
-        xi[m] = v.y;
+        x[m] = f32x2{v.x, v.y};
     }
     // ---- phase 2: stages B+1..2B on bits B..2B-1 (register index m) ----
 #pragma unroll
@@ -125,22 +126,21 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         for (int m0 = 0; m0 < E; m0++) {
             if (m0 & halfm) continue;
             const int jj = ((m0 & (halfm - 1)) << B) | lo;
-            bfly(xr[m0], xi[m0], xr[m0 + halfm], xi[m0 + halfm], tw[jj * tstep][0], tw[jj * tstep][1]);
+            bfly(x[m0], x[m0 + halfm], tw[jj * tstep][0], tw[jj * tstep][1]);
         }
     }
     // ---- transpose 2 (own slots back, then gather p = e*64 + lane) ----
 #pragma unroll
     for (int m = 0; m < E; m++) {
         const int pp = hi * E * E + m * E + lo;
-        buf[pp + (pp >> B)] = make_float2(xr[m], xi[m]);
+        buf[pp + (pp >> B)] = make_float2(x[m].x, x[m].y);
     }
     wave_lds_sync();
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int pp = e * 64 + lane;
         const float2 v = buf[pp + (pp >> B)];
-        xr[e] = v.x;
-        xi[e] = v.y;
+        x[e] = f32x2{v.x, v.y};
     }
     // ---- phase 3: stages 2B+1..BITS on bits 2B.. (register index e, bit st-1-6) ----
 #pragma unroll
@@ -150,7 +150,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         for (int e0 = 0; e0 < E; e0++) {
             if (e0 & halfe) continue;
             const int jj = ((e0 & (halfe - 1)) << 6) | lane;
-            bfly(xr[e0], xi[e0], xr[e0 + halfe], xi[e0 + halfe], tw[jj * tstep][0], tw[jj * tstep][1]);
+            bfly(x[e0], x[e0 + halfe], tw[jj * tstep][0], tw[jj * tstep][1]);
         }
     }
     wave_lds_sync();
@@ -158,8 +158,8 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
     for (int e = 0; e < E / 2; e++) {
-        const float a = xr[e] * xr[e], b = xi[e] * xi[e];
-        pw[e * 64 + lane] = a + b;
+        const f32x2 sq = x[e] * x[e];
+        pw[e * 64 + lane] = sq.x + sq.y;
     }
     wave_lds_sync();
 }
@@ -273,6 +273,146 @@ __global__ __launch_bounds__(256) void wang_cand_kernel(const float* __restrict_
             cand_k[(size_t)sec * kCandCap + pos] = (uint32_t)k;
             cand_p[(size_t)sec * kCandCap + pos] = v;
         }
+    }
+}
+
+// ---- A3 + A5 fused: STFT frames streamed through LDS, peaks picked without spilling the spectrogram ----
+// A workgroup (8 waves) owns a segment of kSeg consecutive frames and walks it in rounds of 8 frames, one
+// FFT per wave (plus kRT halo frames on each side, recomputed: 14 / kSeg extra).  Of every frame only two
+// things survive in LDS:
+//   ring    its +-kRK-bin running maximum ("row maximum"), 2 KiB, in a ring of kRing frames
+//   plist   its row-local peak candidates: bins with P == row maximum > 0 and no equal value among the kRK
+//           bins below (the same-row half of the tie rule) -- two of them are >= 16 bins apart, so <= 32 per frame
+// Once the rows t-kRT .. t+kRT are in the ring, a candidate (t, k, v) is a peak iff v equals the largest
+// of those 15 row maxima at bin k and none of the EARLIER rows' maxima equals v (an equal cell earlier in
+// (t, k) order wins the tie; rows outside [0, total) duplicate rows inside the window, so they are simply
+// skipped).  Identical decisions to wang_cand_kernel on a spilled spectrogram, with HBM seeing the
+// samples once and the peaks -- not 2 x 4 B x 512 bins per frame.
+constexpr int kSeg = 256;    // frames per workgroup segment
+constexpr int kRing = 24;    // >= 2 kRT + 1 + 8 frames in flight
+constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
+
+struct WangStreamLds {
+    float tw[1024][2];
+    float2 buf[8][kWangN + 64];
+    float ring[kRing][kWangBins];
+    uint32_t pl_cnt[kRing];
+    uint32_t pl_k[kRing][kPl];
+    float pl_v[kRing][kPl];
+};
+
+__global__ __launch_bounds__(512) void wang_stream_kernel(const float* __restrict__ x, size_t total_frames,
+                                                          uint32_t* __restrict__ cand_cnt,
+                                                          uint32_t* __restrict__ cand_t,
+                                                          uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    WangStreamLds& L = *reinterpret_cast<WangStreamLds*>(lds_raw);
+    for (int i = threadIdx.x; i < 1024; i += 512) {
+        L.tw[i][0] = c_tw[i][0];
+        L.tw[i][1] = c_tw[i][1];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2* buf = L.buf[wave];
+    const float* pw = reinterpret_cast<const float*>(buf);
+    const long total = (long)total_frames;
+    const long s0 = (long)blockIdx.x * kSeg;                       // frames [s0, s1) are this segment's to judge
+    const long s1 = s0 + kSeg < total ? s0 + kSeg : total;
+    const long f_lo = s0 - kRT < 0 ? 0 : s0 - kRT;                 // frames [f_lo, f_hi) are computed
+    const long f_hi = s1 + kRT < total ? s1 + kRT : total;
+    for (long base = f_lo; base < f_hi + kRT; base += 8) {
+        // ---- produce frame base + wave ----
+        const long f = base + wave;
+        if (f < f_hi) {
+            wave_fft_power<kWangN>(x + (size_t)f * kWangHop, lane, L.tw, buf);
+            // Row maximum over +-kRK bins and the same-row tie test, blocked: lane L owns bins 8L .. 8L+7.  The
+            // window [k-15, k+15] of bin k = 8L + j is  suffix_{L-2}[j+1] u block_{L-1} u block_L u block_{L+1} u
+            // prefix_{L+2}[j-1], and the 15 bins below k are  suffix_{L-2}[j+1] u block_{L-1} u prefix_L[j-1]:
+            // 14 maxima per lane for the prefix / suffix tables, two LDS exchanges, instead of 31 taps per bin.
+            // P >= 0, so -1 stands for "no bin there" (a clamped duplicate never changes a maximum either).
+            float* row = L.ring[f % kRing];
+            float* sx = reinterpret_cast<float*>(buf) + kWangBins;   // scratch behind the spectrum: [lane][8] suffix,
+            float* px = sx + 64 * 9;                                 // [lane][8] prefix (row stride 9: conflict-free)
+            float b8[8], pre[8], suf[8];
+            {
+                const float4 lo4 = *reinterpret_cast<const float4*>(pw + 8 * lane);
+                const float4 hi4 = *reinterpret_cast<const float4*>(pw + 8 * lane + 4);
+                b8[0] = lo4.x; b8[1] = lo4.y; b8[2] = lo4.z; b8[3] = lo4.w;
+                b8[4] = hi4.x; b8[5] = hi4.y; b8[6] = hi4.z; b8[7] = hi4.w;
+            }
+            pre[0] = b8[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) pre[j] = fmaxf(pre[j - 1], b8[j]);
+            suf[7] = b8[7];
+#pragma unroll
+            for (int j = 6; j >= 0; j--) suf[j] = fmaxf(suf[j + 1], b8[j]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                sx[9 * lane + j] = suf[j];
+                px[9 * lane + j] = pre[j];
+            }
+            wave_lds_sync();
+            const float blk_m1 = lane >= 1 ? px[9 * (lane - 1) + 7] : -1.0f;    // block maxima of the neighbours
+            const float blk_p1 = lane <= 62 ? px[9 * (lane + 1) + 7] : -1.0f;
+            float rm[8];
+            uint32_t cbits = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float s2 = (lane >= 2 && j < 7) ? sx[9 * (lane - 2) + j + 1] : -1.0f;   // suffix_{L-2}[j+1]
+                const float p2 = (lane <= 61 && j > 0) ? px[9 * (lane + 2) + j - 1] : -1.0f;  // prefix_{L+2}[j-1]
+                const float below = fmaxf(fmaxf(s2, blk_m1), j > 0 ? pre[j - 1] : -1.0f);
+                const float m = fmaxf(fmaxf(below, pre[7]), fmaxf(blk_p1, p2));
+                rm[j] = m;
+                if (b8[j] > 0.0f && b8[j] == m && below != b8[j]) cbits |= 1u << j;
+            }
+            *reinterpret_cast<float4*>(row + 8 * lane) = make_float4(rm[0], rm[1], rm[2], rm[3]);
+            *reinterpret_cast<float4*>(row + 8 * lane + 4) = make_float4(rm[4], rm[5], rm[6], rm[7]);
+            uint32_t npl = 0;   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const bool c = (cbits >> j) & 1;
+                const uint64_t mask = __ballot(c);
+                if (mask) {
+                    const uint32_t pos = npl + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (c && pos < (uint32_t)kPl) {
+                        L.pl_k[f % kRing][pos] = (uint32_t)(8 * lane + j);
+                        L.pl_v[f % kRing][pos] = b8[j];
+                    }
+                    npl += (uint32_t)__popcll(mask);
+                }
+            }
+            if (lane == 0) L.pl_cnt[f % kRing] = npl < (uint32_t)kPl ? npl : (uint32_t)kPl;
+        }
+        __syncthreads();
+        // ---- judge frame base + wave - kRT: its whole window [t - kRT, t + kRT] is now in the ring ----
+        const long t = base + wave - kRT;
+        if (t >= s0 && t < s1) {
+            const uint32_t n = L.pl_cnt[t % kRing];
+            for (uint32_t e = lane; e < n; e += 64) {
+                const uint32_t k = L.pl_k[t % kRing][e];
+                const float v = L.pl_v[t % kRing][e];
+                float m = v;
+                bool lose = false;
+#pragma unroll
+                for (int d = -kRT; d <= kRT; d++) {
+                    const long tt = t + d;
+                    if (tt < 0 || tt >= total) continue;   // duplicates of in-window rows
+                    const float r = L.ring[tt % kRing][k];
+                    m = fmaxf(m, r);
+                    lose |= d < 0 && r == v;
+                }
+                if (lose || v != m) continue;
+                const uint32_t sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
+                const uint32_t pos = atomicAdd(&cand_cnt[sec], 1u);
+                if (pos < (uint32_t)kCandCap) {
+                    cand_t[(size_t)sec * kCandCap + pos] = (uint32_t)t;
+                    cand_k[(size_t)sec * kCandCap + pos] = k;
+                    cand_p[(size_t)sec * kCandCap + pos] = v;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -446,10 +586,9 @@ WangWs wang_ws_layout(size_t n_samples, uint32_t pps) {
     WangWs w;
     w.frames = audio_stft_frames(n_samples, kWangN, kWangHop);
     w.n_sec = w.frames ? (uint32_t)(((w.frames - 1) * kWangHop) / kWangSr + 1) : 0;
-    const size_t win = (w.frames < kChunkFrames ? w.frames : kChunkFrames) + 2 * kRT;
     size_t off = 0;
-    w.P = off;        off = align(off + win * kWangBins * 4);
-    w.rowmax = off;   off = align(off + win * kWangBins * 4);
+    w.P = off;        // (the spectrogram is no longer spilled: wang_stream_kernel)
+    w.rowmax = off;
     w.cand_cnt = off; off = align(off + (size_t)w.n_sec * 4);
     w.cand_t = off;   off = align(off + (size_t)w.n_sec * kCandCap * 4);
     w.cand_k = off;   off = align(off + (size_t)w.n_sec * kCandCap * 4);
@@ -479,23 +618,11 @@ int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t,
     auto f32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
     (void)hipMemsetAsync(u32(w.cand_cnt), 0, (size_t)w.n_sec * 4, stream);
-    const size_t lds = sizeof(FftLds<kWangN>);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_power_kernel<kWangN, false>),
+    const size_t lds = sizeof(WangStreamLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wang_stream_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (size_t e0 = 0; e0 < w.frames; e0 += kChunkFrames) {
-        const size_t e1 = e0 + kChunkFrames < w.frames ? e0 + kChunkFrames : w.frames;
-        const size_t w0 = e0 >= (size_t)kRT ? e0 - kRT : 0;
-        const size_t w1 = e1 + kRT < w.frames ? e1 + kRT : w.frames;
-        const size_t wn = w1 - w0;
-        unsigned grid = blocks_for(wn, 4);
-        if (grid > 256 * 8) grid = 256 * 8;
-        hipLaunchKernelGGL((stft_power_kernel<kWangN, false>), dim3(grid), dim3(256), lds, stream, pcm8k, w0, wn,
-                           kWangHop, f32(w.P), (const uint32_t*)nullptr, f32(w.rowmax));
-        hipLaunchKernelGGL(wang_cand_kernel, dim3(blocks_for(((e1 - e0 + kRun - 1) / kRun) * kWangBins, 256)),
-                           dim3(256), 0, stream,
-                           f32(w.P), f32(w.rowmax), w0, wn, e0, e1, w.frames, u32(w.cand_cnt), u32(w.cand_t),
-                           u32(w.cand_k), f32(w.cand_p));
-    }
+    hipLaunchKernelGGL(wang_stream_kernel, dim3((unsigned)((w.frames + kSeg - 1) / kSeg)), dim3(512), lds, stream, pcm8k,
+                       w.frames, u32(w.cand_cnt), u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
     hipLaunchKernelGGL(wang_select_kernel, dim3(w.n_sec), dim3(64), 0, stream, u32(w.cand_cnt), u32(w.cand_t),
                        u32(w.cand_k), f32(w.cand_p), pps, u32(w.sel_cnt), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p));
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, u32(w.sel_cnt), (size_t)w.n_sec,

@@ -376,7 +376,7 @@ def bench_audio(args, rank, world, dev, ctx):
            "metric": "audio-seconds/s (Wang landmarks incl. 44.1k->8k linear resample)",
            "value": secs / (ms / 1e3) * world, "unit": "x real time", "seconds_per_gpu": secs, "ms_per_pass": ms,
            "hashes": nh, "algorithmic_GBs": (n * 4 + nh * 8) / (ms / 1e3) / 1e9,
-           "note": "spectrogram is spilled in 64 MiB chunks in round 1 (DESIGN.md 8)"}
+           "note": "peaks are picked inside the STFT kernel (LDS ring of row maxima); no spectrogram spill"}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle
         s = 60 * sr

@@ -7,16 +7,15 @@
 // library is built with -ffp-contract=off), so the integer outputs are bit-identical.
 //
 //   resample_linear   A1   one thread per output sample
-//   stft_power<N>     A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT, 16/32 points
-//                          per lane in registers, two LDS transposes, no block barrier;
-//                          Wang: power spectrum to HBM; Haitsma: 33 band energies per frame
-//   (stft epilogue)/cand A5 separable neighbourhood maximum, then the exact tie rule only on the
-//                          (rare) cells that equal their window maximum
+//   wave_fft_power<N> A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT, 16/32 points per lane
+//                          in registers as (re, im) pairs on packed-f32 instructions, two LDS transposes
+//   wang_stream       A3+5 Wang: frames streamed through an LDS ring of row maxima, peaks judged in the
+//                          kernel (separable neighbourhood maximum + exact tie rule); nothing is spilled
+//   stft_power<2048>  A7   Haitsma: 33 band energies per frame (chunked so the band buffer stays bounded)
 //   wang_select       A5   one wave per second of audio: rank by strength, keep peaks_per_sec,
 //                          order by (t, k)
 //   wang_pair_*       A6   one thread per anchor walks the time-sorted peaks (audio.rs:965-1003)
 //   haitsma_bits      A8   sign of the time/frequency double difference
-// Long inputs are processed in chunks of frames so the spilled spectrogram stays bounded.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -182,26 +181,7 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict
     // frames are dealt to waves round-robin over the whole grid
     for (size_t f = (size_t)blockIdx.x * 4 + wave; f < n_frames; f += (size_t)gridDim.x * 4) {
         wave_fft_power<N>(x + (first_frame + f) * (size_t)hop, lane, L.tw, buf);
-        if (!HAITSMA) {
-            // power spectrum to HBM and, while the frame is still in LDS, its +-kRK-bin running
-            // maximum (the row half of the separable peak neighbourhood)
-            float* o = out + f * (size_t)(N / 2);
-            float* ro = rowmax_out + f * (size_t)(N / 2);
-#pragma unroll 2
-            for (int k = lane; k < N / 2; k += 64) {
-                // fixed 31 taps with clamped indices (duplicates do not change a maximum): the LDS
-                // reads are independent, so their latency overlaps instead of adding up
-                const float pk = pw[k];
-                float m = pk;
-#pragma unroll
-                for (int d = 1; d <= kRK; d++) {
-                    const int lo = k - d < 0 ? 0 : k - d, hi = k + d > N / 2 - 1 ? N / 2 - 1 : k + d;
-                    m = fmaxf(m, fmaxf(pw[lo], pw[hi]));
-                }
-                o[k] = pk;
-                ro[k] = m;
-            }
-        } else {
+        {
             // lane b sums band b sequentially (same order as the oracle)
             if (lane < kHkBands) {
                 float e = 0.0f;
@@ -213,71 +193,8 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict
     }
 }
 
-// ---- A5: peaks ---------------------------------------------------------------------------------
-// P / rowmax hold frames [w0, w0 + wn) of the spectrogram (window incl. halo), row-major 512 bins;
-// rowmax is written by the STFT kernel's epilogue.
-// Emit candidates for frames [e0, e1) (absolute); the window buffer starts at absolute frame w0.
-// A thread owns one frequency bin k for a RUN of kRun consecutive frames: it loads the
-// kRun + 2*kRT row maxima of its column once (independent, coalesced across k) and slides the
-// +-kRT-frame window over them in registers, so every rowmax / P element is read ~1.4x instead
-// of 16x and nothing depends on which XCD's L2 a neighbouring block landed on.
-constexpr int kRun = 32;
-
-__global__ __launch_bounds__(256) void wang_cand_kernel(const float* __restrict__ P, const float* __restrict__ rowmax,
-                                                        size_t w0, size_t wn, size_t e0, size_t e1,
-                                                        size_t total_frames, uint32_t* __restrict__ cand_cnt,
-                                                        uint32_t* __restrict__ cand_t, uint32_t* __restrict__ cand_k,
-                                                        float* __restrict__ cand_p) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = (int)(i & (kWangBins - 1));
-    const size_t tr0 = e0 + (i >> 9) * kRun;  // first frame of this thread's run
-    if (tr0 >= e1) return;
-    (void)wn;
-    const long last = (long)total_frames - 1;
-    float win[kRun + 2 * kRT];
-#pragma unroll
-    for (int j = 0; j < kRun + 2 * kRT; j++) {
-        long tt = (long)tr0 - kRT + j;
-        tt = tt < 0 ? 0 : (tt > last ? last : tt);   // clamped rows duplicate an in-window row
-        win[j] = rowmax[((size_t)tt - w0) * kWangBins + k];
-    }
-    float pv[kRun];
-#pragma unroll
-    for (int j = 0; j < kRun; j++) {
-        const size_t t = tr0 + j;
-        pv[j] = t < e1 ? P[(t - w0) * kWangBins + k] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < kRun; j++) {
-        const float v = pv[j];
-        float m = win[j];
-#pragma unroll
-        for (int d = 1; d <= 2 * kRT; d++) m = fmaxf(m, win[j + d]);
-        if (!(v > 0.0f) || v != m) continue;
-        const size_t t = tr0 + j;
-        // v is a window maximum; an equal value earlier in (t, k) order wins the tie.
-        // Earlier ROWS: every cell of the window is <= v, so row tt holds an equal cell inside
-        // [k-kRK, k+kRK] exactly when its row maximum equals v -- already in registers.
-        bool lose = false;
-#pragma unroll
-        for (int d = 0; d < kRT; d++) lose |= ((long)t - kRT + d >= 0) && (win[j + d] == v);
-        // Same row, bins below k: kRK independent reads (no early exit: one latency, not fifteen)
-        const float* prow = P + (t - w0) * kWangBins;
-#pragma unroll
-        for (int d = 1; d <= kRK; d++) lose |= (k - d >= 0) && (prow[k - d >= 0 ? k - d : 0] == v);
-        if (lose) continue;
-        const uint32_t sec = (uint32_t)((t * kWangHop) / kWangSr);
-        const uint32_t pos = atomicAdd(&cand_cnt[sec], 1u);
-        if (pos < (uint32_t)kCandCap) {
-            cand_t[(size_t)sec * kCandCap + pos] = (uint32_t)t;
-            cand_k[(size_t)sec * kCandCap + pos] = (uint32_t)k;
-            cand_p[(size_t)sec * kCandCap + pos] = v;
-        }
-    }
-}
-
 // ---- A3 + A5 fused: STFT frames streamed through LDS, peaks picked without spilling the spectrogram ----
-// A workgroup (8 waves) owns a segment of kSeg consecutive frames and walks it in rounds of 8 frames, one
+// A workgroup (kSW waves) owns a segment of kSeg consecutive frames and walks it in rounds of kSW frames, one
 // FFT per wave (plus kRT halo frames on each side, recomputed: 14 / kSeg extra).  Of every frame only two
 // things survive in LDS:
 //   ring    its +-kRK-bin running maximum ("row maximum"), 2 KiB, in a ring of kRing frames
@@ -286,28 +203,28 @@ __global__ __launch_bounds__(256) void wang_cand_kernel(const float* __restrict_
 // Once the rows t-kRT .. t+kRT are in the ring, a candidate (t, k, v) is a peak iff v equals the largest
 // of those 15 row maxima at bin k and none of the EARLIER rows' maxima equals v (an equal cell earlier in
 // (t, k) order wins the tie; rows outside [0, total) duplicate rows inside the window, so they are simply
-// skipped).  Identical decisions to wang_cand_kernel on a spilled spectrogram, with HBM seeing the
-// samples once and the peaks -- not 2 x 4 B x 512 bins per frame.
+// skipped).  HBM sees the samples once and the peaks -- not 2 x 4 B x 512 bins per frame of spilled spectrum.
 constexpr int kSeg = 256;    // frames per workgroup segment
-constexpr int kRing = 24;    // >= 2 kRT + 1 + 8 frames in flight
+constexpr int kSW = 10;      // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
+constexpr int kRing = 26;    // >= 2 kRT + 1 + kSW frames in flight
 constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
 
 struct WangStreamLds {
     float tw[1024][2];
-    float2 buf[8][kWangN + 64];
+    float2 buf[kSW][kWangN + 64];
     float ring[kRing][kWangBins];
     uint32_t pl_cnt[kRing];
     uint32_t pl_k[kRing][kPl];
     float pl_v[kRing][kPl];
 };
 
-__global__ __launch_bounds__(512) void wang_stream_kernel(const float* __restrict__ x, size_t total_frames,
+__global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __restrict__ x, size_t total_frames,
                                                           uint32_t* __restrict__ cand_cnt,
                                                           uint32_t* __restrict__ cand_t,
                                                           uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     WangStreamLds& L = *reinterpret_cast<WangStreamLds*>(lds_raw);
-    for (int i = threadIdx.x; i < 1024; i += 512) {
+    for (int i = threadIdx.x; i < 1024; i += kSW * 64) {
         L.tw[i][0] = c_tw[i][0];
         L.tw[i][1] = c_tw[i][1];
     }
@@ -320,7 +237,7 @@ __global__ __launch_bounds__(512) void wang_stream_kernel(const float* __restric
     const long s1 = s0 + kSeg < total ? s0 + kSeg : total;
     const long f_lo = s0 - kRT < 0 ? 0 : s0 - kRT;                 // frames [f_lo, f_hi) are computed
     const long f_hi = s1 + kRT < total ? s1 + kRT : total;
-    for (long base = f_lo; base < f_hi + kRT; base += 8) {
+    for (long base = f_lo; base < f_hi + kRT; base += kSW) {
         // ---- produce frame base + wave ----
         const long f = base + wave;
         if (f < f_hi) {
@@ -464,15 +381,23 @@ __global__ __launch_bounds__(64) void wang_select_kernel(const uint32_t* __restr
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* __restrict__ in, size_t n,
                                                               uint32_t* __restrict__ out) {
+    // one block; a thread scans kE consecutive elements serially, the block scans the thread totals
+    constexpr int kE = 16;
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (size_t base = 0; base < n; base += 1024) {
-        const size_t i = base + tid;
-        const uint32_t v = i < n ? in[i] : 0u;
-        uint32_t inc = v;
+    for (size_t base = 0; base < n; base += (size_t)1024 * kE) {
+        const size_t i0 = base + (size_t)tid * kE;
+        uint32_t v[kE];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int e = 0; e < kE; e++) {
+            v[e] = i0 + e < n ? in[i0 + e] : 0u;
+            tot += v[e];
+        }
+        uint32_t inc = tot;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off, 64);
@@ -483,7 +408,12 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* __
         uint32_t woff = 0;
         for (int w = 0; w < wave; w++) woff += wsum[w];
         const uint32_t c = carry;
-        if (i < n) out[i] = c + woff + inc - v;
+        uint32_t run = c + woff + inc - tot;
+#pragma unroll
+        for (int e = 0; e < kE; e++) {
+            if (i0 + e < n) out[i0 + e] = run;
+            run += v[e];
+        }
         __syncthreads();
         if (tid == 1023) carry = c + woff + inc;
         __syncthreads();
@@ -579,7 +509,7 @@ int launch_resample_linear(const float* in, size_t n, uint32_t sr_in, uint32_t s
 size_t audio_stft_frames(size_t n, int N, int hop) { return n >= (size_t)N ? 1 + (n - N) / hop : 0; }
 
 // ---- Wang orchestration ------------------------------------------------------------------------
-constexpr size_t kChunkFrames = 32768;  // 64 MiB of spilled power spectrum per chunk
+constexpr size_t kChunkFrames = 32768;  // Haitsma band energies are produced in chunks of 4 x this many frames
 
 WangWs wang_ws_layout(size_t n_samples, uint32_t pps) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -621,7 +551,7 @@ int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t,
     const size_t lds = sizeof(WangStreamLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wang_stream_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wang_stream_kernel, dim3((unsigned)((w.frames + kSeg - 1) / kSeg)), dim3(512), lds, stream, pcm8k,
+    hipLaunchKernelGGL(wang_stream_kernel, dim3((unsigned)((w.frames + kSeg - 1) / kSeg)), dim3(kSW * 64), lds, stream, pcm8k,
                        w.frames, u32(w.cand_cnt), u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
     hipLaunchKernelGGL(wang_select_kernel, dim3(w.n_sec), dim3(64), 0, stream, u32(w.cand_cnt), u32(w.cand_t),
                        u32(w.cand_k), f32(w.cand_p), pps, u32(w.sel_cnt), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p));

@@ -63,6 +63,11 @@ int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, 
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts,
                           uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key,
                           uint32_t* out_cnt, const uint32_t* run_flag, hipStream_t stream);
+// tree merge (fan-in 64 per level); tmp_* hold 2 x topk_merge_tmp_entries(parts, nq, k) entries
+size_t topk_merge_tmp_entries(uint32_t parts, uint32_t nq, uint32_t k);
+int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,
+                               uint32_t k, uint64_t* tmp_ids, uint32_t* tmp_key, uint64_t* out_ids, uint32_t* out_key,
+                               uint32_t* out_cnt, hipStream_t stream);
 
 // cosine.hip
 int launch_cosine_norms(const float* rows, size_t n, uint32_t dim, float* norms, hipStream_t stream);

@@ -135,8 +135,11 @@ __global__ __launch_bounds__(256) void cosine_keys(const float* __restrict__ row
 // G = 3 (48 queries per pass) at dim 768.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int G>
-__global__ __launch_bounds__(512) void cosine_keys_mfma(const float* __restrict__ rows,
+// FULL: dim is a multiple of 32 * U (256): every chunk load is unconditional (dead rows read row 0), so the
+// loop body is loads + LDS reads + MFMAs with no exec masking in between.
+constexpr int kCW = 8;    // waves per workgroup (one workgroup per CU: the queries fill its LDS); 12 measured the same
+template <int G, bool FULL>
+__global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __restrict__ rows,
                                                         const float* __restrict__ norms, size_t n, uint32_t dim,
                                                         const float* __restrict__ queries,
                                                         const float* __restrict__ qnorm, uint32_t nq_pass,
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(512) void cosine_keys_mfma(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [16*G][dim16 + 4]
     const uint32_t dim16 = (dim + 15) & ~15u;
     const uint32_t qstride = dim16 + 4;
-    for (uint32_t i = threadIdx.x; i < 16u * G * qstride; i += 512) {
+    for (uint32_t i = threadIdx.x; i < 16u * G * qstride; i += kCW * 64) {
         const uint32_t qt = i / qstride, c = i - qt * qstride;
         qs[i] = (qt < nq_pass && c < dim) ? queries[(size_t)qt * dim + c] : 0.f;
     }
@@ -152,57 +155,97 @@ __global__ __launch_bounds__(512) void cosine_keys_mfma(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nn = lane & 15, q4 = lane >> 4;
     const size_t tiles = (n + 15) / 16;
-    for (size_t tile = (size_t)blockIdx.x * 8 + wave; tile < tiles; tile += (size_t)gridDim.x * 8) {
+    // per-pass constants of this lane's 4 G result slots: query norm (0 marks "no such query")
+    float qnr[G][4];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t qt = g * 16 + 4 * q4 + r;
+            qnr[g][r] = qt < nq_pass ? qnorm[qt] : 0.f;
+        }
+    // U row chunks (16 floats per row each) are in flight while the previous U are consumed: one block per CU
+    // (LDS holds the queries), so latency must be hidden inside the wave -- including across tiles: the first
+    // chunks of the NEXT tile are requested before this tile's epilogue.
+    constexpr int U = 8;
+    float4 xa[U], xb[U];
+    const size_t tstep = (size_t)gridDim.x * kCW;
+    auto row_ptr = [&](size_t t) {
+        const size_t r = t * 16 + nn;
+        return rows + (r < n ? r : 0) * (size_t)dim;   // dead rows read row 0; their results are not stored
+    };
+    auto load_chunks = [&](float4 (&x)[U], const float* __restrict__ v, bool live, uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = c0 + 16 * u + 4 * q4;
+            if (FULL) {
+                const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v + c));
+                x[u] = make_float4(t[0], t[1], t[2], t[3]);
+            } else {
+                x[u] = (live && c < dim) ? *reinterpret_cast<const float4*>(v + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    // (the read one chunk past dim16 at the very end lands in the next query row / the slack behind the
+    // last row and is never used)
+    auto load_q = [&](float4 (&qv)[G], uint32_t c16) {
+#pragma unroll
+        for (int g = 0; g < G; g++) qv[g] = *reinterpret_cast<const float4*>(&qs[(g * 16 + nn) * qstride + c16 + 4 * q4]);
+    };
+    size_t tile = (size_t)blockIdx.x * kCW + wave;
+    if (tile < tiles) load_chunks(xa, row_ptr(tile), tile * 16 + nn < n, 0);
+    for (; tile < tiles; tile += tstep) {
         const size_t row = tile * 16 + nn;
         const bool live = row < n;
-        const float* __restrict__ v = rows + (live ? row : 0) * (size_t)dim;
+        const float* __restrict__ v = row_ptr(tile);
+        const float vn = norms[live ? row : 0];   // requested now, used in the epilogue
         f32x4v acc[G];
 #pragma unroll
         for (int g = 0; g < G; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        // U row chunks (16 floats per row each) are in flight while the previous U are consumed:
-        // one block per CU (LDS holds the queries), so latency must be hidden inside the wave.
-        constexpr int U = 8;
-        float4 xa[U], xb[U];
-        auto load_chunks = [&](float4 (&x)[U], uint32_t c0) {
+        auto mfma4 = [&](const float4 (&qv)[G], const float4& xv) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t c = c0 + 16 * u + 4 * q4;
-                x[u] = (live && c < dim) ? *reinterpret_cast<const float4*>(v + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < G; g++) {
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[g].x, xv.x, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[g].y, xv.y, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[g].z, xv.z, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[g].w, xv.w, acc[g], 0, 0, 0);
             }
         };
+        float4 qA[G], qB[G];   // operands of even / odd chunks: ping-pong, no moves
+        load_q(qA, 0);
         auto consume = [&](const float4 (&x)[U], uint32_t c0) {
+            static_assert(U % 2 == 0, "chunks are consumed in pairs");
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t c = c0 + 16 * u + 4 * q4;
-                if (c0 + 16 * u < dim16) {  // wave-uniform
-#pragma unroll
-                    for (int g = 0; g < G; g++) {
-                        const float4 qa = *reinterpret_cast<const float4*>(&qs[(g * 16 + nn) * qstride + c]);
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, x[u].x, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, x[u].y, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, x[u].z, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, x[u].w, acc[g], 0, 0, 0);
-                    }
+            for (int u = 0; u < U; u += 2) {
+                if (FULL || c0 + 16 * u < dim16) {  // wave-uniform
+                    load_q(qB, c0 + 16 * (u + 1));
+                    mfma4(qA, x[u]);
+                }
+                if (FULL || c0 + 16 * (u + 1) < dim16) {
+                    load_q(qA, c0 + 16 * (u + 2));
+                    mfma4(qB, x[u + 1]);
                 }
             }
         };
-        load_chunks(xa, 0);
         for (uint32_t c0 = 0; c0 < dim16; c0 += 32 * U) {
-            load_chunks(xb, c0 + 16 * U);
+            load_chunks(xb, v, live, c0 + 16 * U);
             consume(xa, c0);
-            load_chunks(xa, c0 + 32 * U);
+            if (c0 + 32 * U < dim16) {
+                load_chunks(xa, v, live, c0 + 32 * U);
+            } else if (tile + tstep < tiles) {   // xa is free: the next tile's first chunks travel during the rest
+                load_chunks(xa, row_ptr(tile + tstep), (tile + tstep) * 16 + nn < n, 0);
+            }
             consume(xb, c0 + 16 * U);
         }
         // D: col = lane&15 = row in tile, row = 4*(lane>>4) + reg = query in group
         if (live) {
-            const float vn = norms[row];
 #pragma unroll
             for (int g = 0; g < G; g++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint32_t qt = g * 16 + 4 * q4 + r;
                     if (qt < nq_pass) {
-                        const float qn = qnorm[qt];
+                        const float qn = qnr[g][r];
                         uint32_t key = 0xffffffffu;
                         if (vn != 0.f && qn != 0.f) {
                             const float sc = acc[g][r] / (qn * vn);
@@ -255,20 +298,27 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
     if (mfma_ok(rows, dim)) {
         const int G = (int)((nq_pass + 15) / 16);  // <= mfma_groups(dim) by construction of the pass size
         const uint32_t dim16 = (dim + 15) & ~15u;
-        const size_t lds = (size_t)16 * G * (dim16 + 4) * sizeof(float);
+        const size_t lds = (size_t)16 * G * (dim16 + 4) * sizeof(float) + 64;   // + slack for the operand prefetch past the last row
         const size_t tiles = (n + 15) / 16;
-        unsigned grid = (unsigned)((tiles + 7) / 8);
+        unsigned grid = (unsigned)((tiles + kCW - 1) / kCW);
         if (grid > 256 * 4) grid = 256 * 4;
         auto go = [&](auto kern) {
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kCW * 64), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass,
                                keys);
         };
-        if (G == 1) go(cosine_keys_mfma<1>);
-        else if (G == 2) go(cosine_keys_mfma<2>);
-        else go(cosine_keys_mfma<3>);
+        const bool full = dim % 256 == 0;   // 32 * U
+        if (full) {
+            if (G == 1) go(cosine_keys_mfma<1, true>);
+            else if (G == 2) go(cosine_keys_mfma<2, true>);
+            else go(cosine_keys_mfma<3, true>);
+        } else {
+            if (G == 1) go(cosine_keys_mfma<1, false>);
+            else if (G == 2) go(cosine_keys_mfma<2, false>);
+            else go(cosine_keys_mfma<3, false>);
+        }
         return 0;
     }
     const uint32_t dim4 = (dim + 3) & ~3u;

@@ -206,6 +206,11 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     off = align256(off + (size_t)sp.slices * chunk * 4);
     const size_t o_ok = off;
     off = align256(off + nq * k * 4);
+    const size_t tmp_e = 2 * ucfp::topk_merge_tmp_entries(sp.slices, (uint32_t)chunk, k);   // both tree levels
+    const size_t o_tid = off;
+    off = align256(off + tmp_e * 8);
+    const size_t o_tk = off;
+    off = align256(off + tmp_e * 4);
     int rc = ix->ws.ensure(off);
     if (rc) return rc;
     uint8_t* w = ix->ws.p;
@@ -225,9 +230,10 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
         if (spc.slices > sp.slices) spc = sp;  // never exceed the reserved partial space
         ucfp::launch_select_topk_u32(keymat, s->ids, n, spc, (uint32_t)qc, k, reinterpret_cast<uint64_t*>(w + o_pid),
                                      reinterpret_cast<uint32_t*>(w + o_pk), reinterpret_cast<uint32_t*>(w + o_pc), st);
-        ucfp::launch_topk_merge_u32(reinterpret_cast<uint64_t*>(w + o_pid), reinterpret_cast<uint32_t*>(w + o_pk),
-                                    spc.slices, (uint32_t)qc, k, d_out_ids + q0 * k, okeys + q0 * k, d_out_cnt + q0,
-                                    nullptr, st);
+        ucfp::launch_topk_merge_tree_u32(reinterpret_cast<uint64_t*>(w + o_pid), reinterpret_cast<uint32_t*>(w + o_pk),
+                                         spc.slices, (uint32_t)qc, k, reinterpret_cast<uint64_t*>(w + o_tid),
+                                         reinterpret_cast<uint32_t*>(w + o_tk), d_out_ids + q0 * k, okeys + q0 * k,
+                                         d_out_cnt + q0, st);
     }
     if (d_out_scores) ucfp::launch_cosine_scores_from_keys(okeys, nq * k, d_out_scores, st);
     HIP_TRY(hipGetLastError());

@@ -129,11 +129,18 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
                                                      uint64_t* __restrict__ out_ids,
                                                      uint32_t* __restrict__ out_key,
                                                      uint32_t* __restrict__ out_cnt,
-                                                     const uint32_t* __restrict__ run_flag) {
+                                                     const uint32_t* __restrict__ run_flag, uint32_t group_parts) {
     if (run_flag && *run_flag == 0) return;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
-    const uint32_t total = parts * k;
+    // blockIdx.y = group of `group_parts` consecutive parts (tree merge: one output list per group and query)
+    const uint32_t p_lo = blockIdx.y * group_parts;
+    const uint32_t p_n = parts - p_lo < group_parts ? parts - p_lo : group_parts;
+    part_ids += (size_t)p_lo * nq * k;
+    part_key += (size_t)p_lo * nq * k;
+    out_ids += (size_t)blockIdx.y * nq * k;
+    out_key += (size_t)blockIdx.y * nq * k;
+    const uint32_t total = p_n * k;
     uint32_t ld = 0;
     uint64_t li = 0;
     bool first = true;
@@ -168,15 +175,15 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
             out_ids[(size_t)q * k + r] = ~0ull;
             out_key[(size_t)q * k + r] = 0xffffffffu;
         }
-        out_cnt[q] = emitted;
+        if (out_cnt) out_cnt[(size_t)blockIdx.y * nq + q] = emitted;
     }
 }
 
 SelectPlan select_plan(size_t n, uint32_t nq) {
     SelectPlan p;
-    const uint32_t want_waves = 256 * 16;
+    const uint32_t want_waves = 256 * 64;   // the scan is latency-bound per wave: short slices, many waves
     uint32_t slices = nq ? (want_waves + nq - 1) / nq : 1;
-    const size_t max_slices = (n + 8191) / 8192;
+    const size_t max_slices = (n + 511) / 512;
     if (slices > max_slices) slices = (uint32_t)(max_slices ? max_slices : 1);
     if (slices < 1) slices = 1;
     p.per_slice = (n + slices - 1) / slices;
@@ -200,8 +207,28 @@ int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, ui
                           const uint32_t* run_flag, hipStream_t stream) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(topk_merge_u32, dim3(nq), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, out_ids,
-                       out_key, out_cnt, run_flag);
+                       out_key, out_cnt, run_flag, parts);
     return 0;
+}
+
+// Tree merge for many parts: groups of kMergeFan parts are merged in parallel into `tmp_*`
+// ([groups][nq][k]), then the group lists.  One wave walking thousands of lists serially is the slow part
+// of a single-query search otherwise.
+constexpr uint32_t kMergeFan = 64;
+size_t topk_merge_tmp_entries(uint32_t parts, uint32_t nq, uint32_t k) {
+    return parts > kMergeFan ? (size_t)((parts + kMergeFan - 1) / kMergeFan) * nq * k : 0;
+}
+int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,
+                               uint32_t k, uint64_t* tmp_ids, uint32_t* tmp_key, uint64_t* out_ids, uint32_t* out_key,
+                               uint32_t* out_cnt, hipStream_t stream) {
+    if (nq == 0) return 0;
+    if (parts <= kMergeFan)
+        return launch_topk_merge_u32(part_ids, part_key, parts, nq, k, out_ids, out_key, out_cnt, nullptr, stream);
+    const uint32_t groups = (parts + kMergeFan - 1) / kMergeFan;
+    hipLaunchKernelGGL(topk_merge_u32, dim3(nq, groups), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, tmp_ids,
+                       tmp_key, (uint32_t*)nullptr, (const uint32_t*)nullptr, kMergeFan);
+    return launch_topk_merge_tree_u32(tmp_ids, tmp_key, groups, nq, k, tmp_ids + (size_t)groups * nq * k,
+                                      tmp_key + (size_t)groups * nq * k, out_ids, out_key, out_cnt, stream);
 }
 
 }  // namespace ucfp

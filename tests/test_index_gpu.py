@@ -335,3 +335,35 @@ def test_many_queries_small_corpus(gpu_ctx, oracle):
     assert np.array_equal(hi[:64], oi) and np.array_equal(hd[:64], od) and (hc == 4).all()
     oi, od, _ = oracle.hamming_topk(ids, codes, hq[-64:], 4)
     assert np.array_equal(hi[-64:], oi) and np.array_equal(hd[-64:], od)
+
+
+def test_hamming_randomised_configs(gpu_ctx, oracle):
+    """Twenty random (n, nq, k, data shape) draws across the robust / lane / matrix-core paths, including
+    clustered corpora (many rows near a few centres: fat distance bins, heavy candidate traffic)."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(20260101)
+    for trial in range(20):
+        n = int(rng.integers(1, 1_500_000)) if trial % 4 else int(rng.integers(262_144, 400_000))
+        nq = int(rng.integers(1, 260))
+        k = int(rng.choice([1, 3, 10, 17, 64, 128]))
+        style = trial % 3
+        if style == 0:
+            codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+        elif style == 1:   # clustered: centres with 0..6 random bit flips
+            centres = rng.integers(0, 2**64, 50, dtype=np.uint64)
+            codes = centres[rng.integers(0, 50, n)]
+            for _ in range(6):
+                flip = rng.random(n) < 0.5
+                codes = np.where(flip, codes ^ (np.uint64(1) << rng.integers(0, 64, n).astype(np.uint64)), codes)
+        else:              # low entropy: only 12 bits vary
+            codes = rng.integers(0, 2**12, n, dtype=np.uint64) * np.uint64(0x0010000100001001)
+        queries = codes[rng.integers(0, n, nq)] ^ (np.uint64(1) << rng.integers(0, 64, nq).astype(np.uint64))
+        ids = rng.permutation(n).astype(np.uint64) + np.uint64(1000)
+        ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+        ix.upsert(0, ids, codes)
+        g_ids, _, g_d, g_c = ix.search(0, queries, k)
+        o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+        assert np.array_equal(g_c, o_c), (trial, n, nq, k, style)
+        assert np.array_equal(g_d, o_d), (trial, n, nq, k, style)
+        assert np.array_equal(g_ids, o_ids), (trial, n, nq, k, style)
+        ix.close()

@@ -158,7 +158,11 @@ def test_upsert_overwrite_delete_tenants(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("n,dim,nq,k", [(2000, 768, 3, 10), (5000, 384, 17, 10), (3000, 100, 40, 5),
-                                        (1500, 3, 4, 10), (800, 1536, 2, 20), (50, 33, 2, 100)])
+                                        (1500, 3, 4, 10), (800, 1536, 2, 20), (50, 33, 2, 100),
+                                        # batches beyond the LDS-resident kernel: the K-sliced GEMM kernel
+                                        # (64 / 128 / 256 queries per corpus read, ragged row and query counts)
+                                        (3001, 768, 60, 10), (2500, 128, 130, 5), (1777, 64, 300, 3),
+                                        (900, 1024, 257, 10), (4000, 96, 70, 7)])
 def test_cosine_matches_oracle(gpu_ctx, oracle, n, dim, nq, k):
     from ucfp_amd import index
     rng = np.random.default_rng(n + dim)

@@ -71,7 +71,7 @@ int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_ke
 
 // cosine.hip
 int launch_cosine_norms(const float* rows, size_t n, uint32_t dim, float* norms, hipStream_t stream);
-int cosine_queries_per_pass(uint32_t dim);
+int cosine_queries_per_pass(uint32_t dim, size_t nq);
 int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                        const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream);
 int launch_cosine_scores_from_keys(const uint32_t* keys, size_t total, float* scores, hipStream_t stream);

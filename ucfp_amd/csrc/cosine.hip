@@ -259,6 +259,125 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
     }
 }
 
+// ---- GEMM variant for large batches: every query of the pass against the corpus in ONE read of the rows ----
+// The LDS-resident form above holds whole query rows, so 48 queries are all that fit and a batch of 256 reads
+// the corpus six times, each pass sitting on the MFMA/HBM ridge.  Here a wave owns 16 rows x ALL 16*NG queries
+// (4 NG accumulator registers) and the workgroup walks K in slices of 32 dims: the slice of every query is
+// staged through LDS (double-buffered, laid out so that the A operand of (group, 16-dim chunk) is one
+// conflict-free ds_read_b128 per lane), the rows stream from HBM once.  f32 MFMA-bound: NG = 16 is 2.5 ms of
+// matrix work per million 768-d rows.
+constexpr int kGW = 8;      // waves per workgroup
+constexpr int kGK = 32;     // dims per K slice
+
+template <int NG>
+__global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cosine_keys_gemm(const float* __restrict__ rows,
+                                                             const float* __restrict__ norms, size_t n, uint32_t dim,
+                                                             const float* __restrict__ queries,
+                                                             const float* __restrict__ qnorm, uint32_t nq_pass,
+                                                             uint32_t* __restrict__ keys) {
+    // [buffer][group][chunk][lane] float4: 2 x NG x 2 KiB
+    __shared__ __attribute__((aligned(16))) float4 qsl[2][NG][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nn = lane & 15, q4 = lane >> 4;
+    const uint32_t nks = dim / kGK;
+    // staging: float4 number f of a slice = (query f / 8, dims 4 (f % 8) .. +4); a thread moves NG * 128 / 512 of them
+    constexpr int kSt = NG * 16 * 8 / (kGW * 64);
+    static_assert(kSt >= 1, "slice smaller than the workgroup");
+    auto stage_load = [&](float4 (&st)[kSt], uint32_t ks) {
+#pragma unroll
+        for (int i = 0; i < kSt; i++) {
+            const uint32_t f = threadIdx.x + i * kGW * 64, q = f >> 3, c4 = f & 7;
+            st[i] = q < nq_pass ? *reinterpret_cast<const float4*>(queries + (size_t)q * dim + ks * kGK + 4 * c4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage_store = [&](const float4 (&st)[kSt], int buf) {
+#pragma unroll
+        for (int i = 0; i < kSt; i++) {
+            const uint32_t f = threadIdx.x + i * kGW * 64, q = f >> 3, c4 = f & 7;
+            qsl[buf][q >> 4][c4 >> 2][(c4 & 3) * 16 + (q & 15)] = st[i];   // lane (nn = q % 16, q4 = c4 % 4)
+        }
+    };
+    const size_t tiles = (n + 15) / 16;
+    for (size_t tb = (size_t)blockIdx.x * kGW; tb < tiles; tb += (size_t)gridDim.x * kGW) {
+        const size_t tile = tb + wave;
+        const size_t row = tile * 16 + nn;
+        const bool live = row < n;
+        const float* __restrict__ v = rows + (live ? row : 0) * (size_t)dim + 4 * q4;
+        const float vn = norms[live ? row : 0];
+        f32x4v acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        float4 st[kSt];
+        stage_load(st, 0);
+        // row chunks of slices ks and ks + 1 in flight
+        float4 xc[2], xn[2];
+        auto load_x = [&](float4 (&x)[2], uint32_t ks) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v + ks * kGK + 16 * ch));
+                x[ch] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        };
+        load_x(xc, 0);
+        __syncthreads();             // everyone is done with both LDS buffers of the previous tile block
+        stage_store(st, 0);
+        __syncthreads();
+        for (uint32_t ks = 0; ks < nks; ks++) {
+            const int buf = ks & 1;
+            if (ks + 1 < nks) load_x(xn, ks + 1);
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                const float4 xv = xc[ch];
+                // groups in batches of four: four operand reads in flight, sixteen MFMAs; the scheduling barrier keeps
+                // the compiler from hoisting all 2 NG reads of the slice (64 registers at NG = 16) to the top
+#pragma unroll
+                for (int g0 = 0; g0 < NG; g0 += 4) {
+                    float4 qa[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) qa[i] = qsl[buf][g0 + i][ch][lane];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int g = g0 + i;
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].x, xv.x, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].y, xv.y, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].z, xv.z, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].w, xv.w, acc[g], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (ks + 1 < nks) {
+                // the next slice goes global (L2) -> registers -> LDS only now: holding it across the MFMAs would cost
+                // 4 NG registers' worth of spills; the other waves of the SIMD cover this latency
+                stage_load(st, ks + 1);
+                stage_store(st, buf ^ 1);   // last read during slice ks - 1; every wave passed the barrier since
+                xc[0] = xn[0];
+                xc[1] = xn[1];
+            }
+            __syncthreads();
+        }
+        if (live) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t qt = g * 16 + 4 * q4 + r;
+                    if (qt < nq_pass) {
+                        const float qn = qnorm[qt];   // once per 16 rows x 768 dims of matrix work: not worth 4 NG registers
+                        uint32_t key = 0xffffffffu;
+                        if (vn != 0.f && qn != 0.f) {
+                            const float sc = acc[g][r] / (qn * vn);
+                            if (sc == sc) key = score_to_key(sc);
+                        }
+                        keys[(size_t)qt * n + row] = key;
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ void cosine_scores_from_keys(const uint32_t* __restrict__ keys, size_t total, float* __restrict__ scores) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) scores[i] = keys[i] == 0xffffffffu ? -2.0f : key_to_score(keys[i]);
@@ -285,7 +404,9 @@ bool mfma_ok(const float* rows, uint32_t dim) {
 
 // queries per corpus pass. MFMA path (dim % 4 == 0): 16 per LDS-resident group, up to 48;
 // VALU path: kQT, or fewer when kQT query rows do not fit 144 KiB of LDS
-int cosine_queries_per_pass(uint32_t dim) {
+int cosine_queries_per_pass(uint32_t dim, size_t nq) {
+    // batches beyond what the LDS-resident kernel holds go through the GEMM kernel, 256 queries per corpus read
+    if (dim % kGK == 0 && dim % 4 == 0 && mfma_groups(dim) >= 1 && nq > (size_t)16 * mfma_groups(dim)) return 256;
     if (dim % 4 == 0 && mfma_groups(dim) >= 1) return 16 * mfma_groups(dim);
     const uint32_t dim4 = (dim + 3) & ~3u;
     const size_t fit = (144u * 1024u) / ((size_t)dim4 * sizeof(float));
@@ -295,6 +416,22 @@ int cosine_queries_per_pass(uint32_t dim) {
 int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                        const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream) {
     if (n == 0 || nq_pass == 0) return 0;
+    if (mfma_ok(rows, dim) && dim % kGK == 0 && nq_pass > (uint32_t)16 * mfma_groups(dim) &&
+        (reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {
+        const size_t tiles = (n + 15) / 16;
+        unsigned grid = (unsigned)((tiles + kGW - 1) / kGW);
+        if (grid > 256 * 2) grid = 256 * 2;
+        if (nq_pass <= 64)
+            hipLaunchKernelGGL(cosine_keys_gemm<4>, dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
+                               qnorm, nq_pass, keys);
+        else if (nq_pass <= 128)
+            hipLaunchKernelGGL(cosine_keys_gemm<8>, dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
+                               qnorm, nq_pass, keys);
+        else
+            hipLaunchKernelGGL(cosine_keys_gemm<16>, dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
+                               qnorm, nq_pass, keys);
+        return 0;
+    }
     if (mfma_ok(rows, dim)) {
         const int G = (int)((nq_pass + 15) / 16);  // <= mfma_groups(dim) by construction of the pass size
         const uint32_t dim16 = (dim + 15) & ~15u;

@@ -185,7 +185,7 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
         }
         return 0;
     }
-    const int qpp = ucfp::cosine_queries_per_pass(dim);
+    const int qpp = ucfp::cosine_queries_per_pass(dim, nq);
     if (qpp < 1) return capi_fail(UCFP_E_UNSUPPORTED, "cosine dim %u does not fit one query row in LDS", dim);
     // chunk the query batch so the key matrix stays under ~2 GiB
     size_t chunk = (size_t)2048 * 1024 * 1024 / (4 * n);

@@ -64,6 +64,85 @@ def traffic_from_profiles(frames):
     return best
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def bench_config1_phash_png(dev, ctx, n_img=1000):
+    """BASELINE configs[0]: ?algorithm=phash on 1 k 256x256 PNGs -- the reference's own per-item plumbing
+    (decode -> hash -> 168-B record), CPU side = Pillow decode + the C restatement, split decode vs hash;
+    GPU side = the same decoded frames hashed by the HIP path (device-resident, and through the
+    host-pointer ABI incl. PCIe).  N = 1, rank 0 only; a bounded ~10 s of CPU work."""
+    import io
+    import numpy as np
+    import torch
+    from PIL import Image
+    import oracle
+    from ucfp_amd import image
+    side = 256
+    yy, xx = np.mgrid[0:side, 0:side]
+    rng = np.random.default_rng(0xC0F1)
+    pngs = []
+    for i in range(n_img):   # colour ramp of benches/end_to_end.rs:77-85 xor per-image noise (SURVEY 8d)
+        base = np.stack([(xx + i) & 255, (yy + 2 * i) & 255, (xx + yy) & 255], -1).astype(np.uint8)
+        img = base ^ rng.integers(0, 8, (side, side, 3), dtype=np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(img, "RGB").save(b, "PNG", compress_level=1)
+        pngs.append(b.getvalue())
+    t0 = time.perf_counter()
+    frames = np.stack([np.asarray(Image.open(io.BytesIO(p)).convert("RGB")) for p in pngs])
+    t_dec = time.perf_counter() - t0
+    cores = oracle.num_threads()
+    oracle.set_threads(1)
+    t0 = time.perf_counter()
+    ref, _ = oracle.image_hash_batch(frames, 2, pixfmt=1)
+    t_h1 = time.perf_counter() - t0
+    oracle.set_threads(cores)
+    t0 = time.perf_counter()
+    oracle.image_hash_batch(frames, 2, pixfmt=1)
+    t_hn = time.perf_counter() - t0
+    # GPU: host-pointer ABI (pageable host memory in, records out), then device-resident frames
+    t0 = time.perf_counter()
+    got, st = image.fingerprint_frames(frames, algo=image.PHASH, pixfmt=image.PIX_RGB8, ctx=ctx)
+    t_gh = time.perf_counter() - t0
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_out = torch.empty((n_img, 168), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def go():
+        image.fingerprint_frames_dev(d_frames.data_ptr(), n_img, side, side, algo=image.PHASH, pixfmt=image.PIX_RGB8,
+                                     out_ptr=d_out.data_ptr(), stream=stream, ctx=ctx)
+    go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    t_gd = e0.elapsed_time(e1) / 20 / 1e3
+    return {
+        "workload": f"{n_img} synthetic 256x256 RGB PNGs, ?algorithm=phash (168-B records)",
+        "cpu": {"kind": "port", "cpu_model": cpu_model(), "cores": cores,
+                "png_decode_s": t_dec, "decode_images_per_s_1_thread": n_img / t_dec,
+                "hash_images_per_s_1_thread": n_img / t_h1, "hash_images_per_s_all_cores": n_img / t_hn,
+                "decode_plus_hash_images_per_s_1_thread": n_img / (t_dec + t_h1)},
+        "gpu": {"hash_images_per_s_device_resident": n_img / t_gd,
+                "hash_images_per_s_host_pointer_abi_incl_pcie": n_img / t_gh,
+                "matches_oracle": bool(np.array_equal(got, ref) and not st.any()
+                                       and np.array_equal(d_out.cpu().numpy(), ref))},
+        "gpu_hash_over_cpu_hash_all_cores": (n_img / t_gd) / (n_img / t_hn),
+        "note": "decode stays on the host in both columns (SURVEY 8f N4: GPU decode is out of scope); the reference "
+                "path is decode-bound here",
+    }
+
+
 def cpu_baseline(sample: int, gpu_records_head):
     """Time the CPU oracle (OpenMP over frames) on the first `sample` frames of the same
     synthetic workload, and use the occasion to check the GPU records of those frames."""
@@ -79,8 +158,16 @@ def cpu_baseline(sample: int, gpu_records_head):
     if gpu_records_head is not None:
         m = min(sample, gpu_records_head.shape[0])
         parity = bool(np.array_equal(recs[:m], gpu_records_head[:m]))
+    # the same restatement on ONE thread (SURVEY 8d asks for both), on a smaller slice
+    ns = max(1, min(sample, 256))
+    oracle.set_threads(1)
+    t0 = time.perf_counter()
+    oracle.image_hash_batch(frames[:ns], 7)
+    dt1 = time.perf_counter() - t0
+    oracle.set_threads(cores)
     return {
         "value": sample / dt, "unit": "fingerprints/s", "cores": cores, "kind": "port",
+        "single_thread_value": ns / dt1, "cpu_model": cpu_model(),
         "sample": f"first {sample} frames of the same synthetic batch ({dt:.2f} s wall, "
                   f"{dt * cores:.1f} core-s); C restatement oracle/ucfp_oracle_image.c, "
                   "not the reference Rust binary (no Rust toolchain, SDK crates un-vendored)",
@@ -529,6 +616,7 @@ def main():
         if args.cpu_sample > 0 and world == 1:
             head = out[:min(args.cpu_sample, n)].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), head)
+            res["config1_phash_png"] = bench_config1_phash_png(dev, ctx)
         elif args.cpu_sample > 0:
             res["cpu_baseline"] = None  # measured at N=1 only (see BENCH at n_gpus=1)
     else:

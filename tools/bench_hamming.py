@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--nq", type=int, nargs="+", default=[4096])
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--clustered", type=int, default=0, help="centres: half of the corpus sits within 6 bits of one of them, queries are perturbed corpus rows")
     a = ap.parse_args()
     import torch
     from ucfp_amd import _lib, index
@@ -25,6 +26,16 @@ def main():
         g = torch.Generator(device=dev)
         g.manual_seed(1)
         codes = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, generator=g)
+        if a.clustered:
+            centres = torch.randint(-2**63, 2**63 - 1, (a.clustered,), dtype=torch.int64, device=dev, generator=g)
+            near = centres[torch.randint(0, a.clustered, (n // 2,), device=dev, generator=g)]
+            for _ in range(6):
+                bit = torch.randint(0, 63, (n // 2,), device=dev, generator=g)
+                flip = torch.rand((n // 2,), device=dev, generator=g) < 0.5
+                near = torch.where(flip, near ^ (torch.ones_like(near) << bit), near)
+            codes[: n // 2] = near
+            codes = codes[torch.randperm(n, device=dev, generator=g)]
+        corpus_sample = codes[torch.randint(0, n, (max(a.nq),), device=dev, generator=g)].clone()
         ids = torch.arange(n, dtype=torch.int64, device=dev)
         ix = index.DeviceIndex(index.HAMMING64, flags=index.APPEND_ONLY, ctx=ctx)
         ix.append_dev(0, ids.data_ptr(), codes.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
@@ -32,6 +43,8 @@ def main():
         del codes, ids
         for nq in a.nq:
             q = torch.randint(-2**63, 2**63 - 1, (nq,), dtype=torch.int64, device=dev, generator=g)
+            if a.clustered:
+                q = corpus_sample[:nq] ^ (torch.ones((nq,), dtype=torch.int64, device=dev) << (torch.arange(nq, device=dev) % 61))
             o_ids = torch.empty((nq, a.k), dtype=torch.int64, device=dev)
             o_sc = torch.empty((nq, a.k), dtype=torch.float32, device=dev)
             o_d = torch.empty((nq, a.k), dtype=torch.int32, device=dev)

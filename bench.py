@@ -223,6 +223,19 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
         dt = float(t.item())
     out_ids, _, out_keys, out_cnt = out
     planted_found = int((out_keys[0::2, 0] <= 3).sum().item())
+    # the exchange step alone ("all-gather time separately"): one all-gather + merge on this rank
+    exch_ms = None
+    if world > 1:
+        b = six._buffers(nq, k, dev)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            g_ids, g_keys = sharded.all_gather_topk(b["ids"], b["keys"], None)
+            index.topk_merge_dev(index.HAMMING64, g_ids.data_ptr(), g_keys.data_ptr(), g_ids.shape[0], nq, k,
+                                 b["out_ids"].data_ptr(), b["out_scores"].data_ptr(), b["out_keys"].data_ptr(),
+                                 b["out_cnt"].data_ptr(), torch.cuda.current_stream().cuda_stream, ctx=ctx)
+        barrier()
+        exch_ms = (time.perf_counter() - t0) / 10 * 1e3
     if rank != 0:
         return None
     qps = nq * args.ann_steps / dt
@@ -238,7 +251,7 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
         "corpus_total": corpus_total, "corpus_per_gpu": n_local, "queries_per_batch": nq, "k": k,
         "ms_per_batch": dt / args.ann_steps * 1e3, "scaling": "strong",
         "exchange": "one all-gather of nq*k*(8+4) B per rank + merge on every rank" if world > 1 else "none",
-        "pairs_per_s": pairs_per_s,
+        "pairs_per_s": pairs_per_s, "exchange_ms_per_batch": exch_ms,
         "roofline": {"bound": "mfma", "kernel": "hamming_scan_mfma",
                      "achieved": pairs_per_s * ops_per_pair / world / 1e12, "peak": i8_peak / 1e12,
                      "unit": "TOP/s per GPU (int8 MFMA, 128 ops per code-query pair; whole search incl. staging, "

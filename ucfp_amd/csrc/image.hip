@@ -646,26 +646,34 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
     const uint32_t t = threadIdx.x;  // ONE WAVE per band: no workgroup barrier anywhere
     const size_t img = blockIdx.y;
     const uint8_t* __restrict__ f = frames + img * frame_stride;
-    const uint32_t nblk = w / 4;                              // w % 4 == 0, w <= 256 SP (launcher)
+    const uint32_t nrow = w / 4;                              // strips in a source row (w % 4 == 0)
+    // column part: destination columns [c0, c1) and the source strips [blk0, blk0 + nblk) that overlap them
+    const uint32_t c0 = 256u * blockIdx.z / gridDim.z, c1 = 256u * (blockIdx.z + 1) / gridDim.z;
+    const uint32_t blk0 = (uint32_t)(((uint64_t)w * c0) >> 8) / 4;
+    const uint32_t blk1 = ((uint32_t)(((uint64_t)w * c1 - 1) >> 8)) / 4 + 1;
+    const uint32_t nblk = blk1 - blk0;                        // <= 64 SP (launcher)
     const uint32_t j0 = 256u * blockIdx.x / gridDim.x, j1 = 256u * (blockIdx.x + 1) / gridDim.x;
     const uint32_t ys = (uint32_t)(((uint64_t)h * j0) / 256);
     const uint64_t D = (uint64_t)w * h;
     uint32_t acc[SP][4];
 #pragma unroll
     for (int s = 0; s < SP; s++) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
-    RawStrip<BPP> cur[SP], nxt[SP];
+    // rows in flight ahead of the one being consumed: narrow frames have registers to spare and need the depth
+    // (a wave moves only 64 x 4 BPP bytes per row and strip)
+    constexpr int PF = SP <= 1 ? 6 : SP <= 2 ? 4 : SP <= 4 ? 2 : 1;
+    RawStrip<BPP> cur[SP], nxt[PF][SP];
     auto load_row = [&](RawStrip<BPP> (&dst)[SP], uint32_t y) {
         const uint8_t* __restrict__ row = f + (size_t)y * row_stride;
 #pragma unroll
         for (int s = 0; s < SP; s++) {
             const uint32_t blk = s * 64 + t;   // interleaved strips: a load instruction reads 64 x 4 BPP contiguous bytes
             // strips past the row end re-read the last strip: their accumulators are never emitted
-            dst[s] = load_raw_strip<BPP>(row + (size_t)(blk < nblk ? blk : nblk - 1) * 4 * BPP);
+            dst[s] = load_raw_strip<BPP>(row + (size_t)(blk0 + (blk < nblk ? blk : nblk - 1)) * 4 * BPP);
         }
     };
     // emit destination row j: prefix sums of the accumulated row -> LDS -> 4 output pixels per lane
     auto emit = [&](uint32_t j) {
-        if (SP == 1 && w == 256) {   // destination column = source column: R = 256 T, no prefix needed
+        if (SP == 1 && w == 256 && gridDim.z == 1) {   // destination column = source column: R = 256 T, no prefix needed
             uint32_t q4 = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -701,20 +709,18 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
                 acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
             }
         }
-        if (t == 0) P[w] = base;
+        if (t == 0) P[4 * nblk] = base;
         wave_lds_sync();
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const uint32_t i = c * 64 + t;   // destination column
+        for (uint32_t i = c0 + t; i < c1; i += 64) {   // destination column
             const uint64_t di0 = (uint64_t)w * i, di1 = di0 + w;
-            const uint32_t xa = (uint32_t)(di0 >> 8), xb = (uint32_t)((di1 - 1) >> 8);
+            const uint32_t xa = (uint32_t)(di0 >> 8) - 4 * blk0, xb = (uint32_t)((di1 - 1) >> 8) - 4 * blk0;   // local pixels
             const uint32_t pa0 = P[xa], pa1 = P[xa + 1];
             uint64_t R;
             if (xa == xb) {
                 R = (uint64_t)w * (uint32_t)(pa1 - pa0);
             } else {
                 const uint32_t pb0 = P[xb], pb1 = P[xb + 1];
-                const uint64_t ovA = 256ull * (xa + 1) - di0, ovB = di1 - 256ull * xb;
+                const uint64_t ovA = 256ull * (xa + 4 * blk0 + 1) - di0, ovB = di1 - 256ull * (xb + 4 * blk0);
                 R = ovA * (uint32_t)(pa1 - pa0) + 256ull * (uint32_t)(pb0 - pa1) + ovB * (uint32_t)(pb1 - pb0);
             }
             // q = floor((2R + D) / 2D) <= 255: float estimate, exact integer correction
@@ -730,8 +736,10 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
     uint32_t j = j0;
     uint32_t y = ys;
     load_row(cur, y);
+#pragma unroll
+    for (int p = 0; p < PF - 1; p++) load_row(nxt[p], y + 1 + p < h ? y + 1 + p : h - 1);
     while (j < j1 && y < h) {
-        if (y + 1 < h) load_row(nxt, y + 1);
+        load_row(nxt[PF - 1], y + PF < h ? y + PF : h - 1);
         // source row y spans [256 y, 256 y + 256); destination row j spans [h j, h j + h)
         const uint64_t s0 = 256ull * y, s1 = s0 + 256;
         while (j < j1) {
@@ -759,7 +767,11 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
         }
         y++;
 #pragma unroll
-        for (int s = 0; s < SP; s++) cur[s] = nxt[s];
+        for (int s = 0; s < SP; s++) {
+            cur[s] = nxt[0][s];
+#pragma unroll
+            for (int p = 0; p + 1 < PF; p++) nxt[p][s] = nxt[p + 1][s];
+        }
     }
 }
 
@@ -843,19 +855,27 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
     }
     // generic: normalise into the workspace in chunks, then hash the 256x256 planes (S = 1).
     const size_t align_need = pixfmt == 2 ? 15u : 3u;
-    const bool stream_ok = w % 4 == 0 && w <= 2048 && ((((uintptr_t)frames) | row_stride | frame_stride) & align_need) == 0;
-    const size_t ns_lds = ((size_t)w + 4) * 4;
+    const bool stream_ok = w % 4 == 0 && ((((uintptr_t)frames) | row_stride | frame_stride) & align_need) == 0;
+    // column parts so that a wave owns at most 4 x 64 strips (+ the strip shared with its neighbour)
+    const unsigned parts = (unsigned)((w / 4 + 251) / 252);
+    uint32_t part_strips = 0;   // widest part, exactly as the kernel derives it
+    for (unsigned z = 0; z < parts; z++) {
+        const uint32_t c0 = 256u * z / parts, c1 = 256u * (z + 1) / parts;
+        const uint32_t b0 = (uint32_t)(((uint64_t)w * c0) >> 8) / 4, b1 = ((uint32_t)(((uint64_t)w * c1 - 1) >> 8)) / 4 + 1;
+        part_strips = b1 - b0 > part_strips ? b1 - b0 : part_strips;
+    }
+    const size_t ns_lds = ((size_t)4 * part_strips + 8) * 4;
     for (size_t done = 0; done < n;) {
         const size_t chunk = (n - done) < norm_ws_frames ? (n - done) : norm_ws_frames;
         if (stream_ok) {
-            // waves = bands x frames: enough to fill 256 CUs x 16 waves, at least 8 destination rows per band
-            unsigned bands = (unsigned)((16384 + chunk - 1) / chunk);
+            // waves = bands x frames x parts: enough to fill 256 CUs x 16 waves, at least 8 destination rows per band
+            unsigned bands = (unsigned)((16384 + chunk * parts - 1) / (chunk * parts));
             if (bands > 32) bands = 32;
             if (bands < 1) bands = 1;
-            const dim3 grid(bands, (unsigned)chunk);
+            const dim3 grid(bands, (unsigned)chunk, parts);
             const uint8_t* fr = frames + done * frame_stride;
             auto go = [&](auto k1, auto k2, auto k3, auto k4, auto k6, auto k8) {
-                const uint32_t nblk = w / 4;
+                const uint32_t nblk = part_strips;
                 auto launch = [&](auto k) {
                     hipLaunchKernelGGL(k, grid, dim3(64), ns_lds, stream, fr, w, h, row_stride, frame_stride, norm_ws);
                 };

@@ -74,7 +74,11 @@ def test_single_algorithm_records(gpu_ctx, oracle, algo):
     assert np.array_equal(multi[:, off:off + 168], gpu)
 
 
-@pytest.mark.parametrize("geom", [(300, 200), (32, 32), (33, 47), (640, 480), (257, 256), (1000, 777)])
+@pytest.mark.parametrize("geom", [(300, 200), (32, 32), (33, 47), (640, 480), (257, 256), (1000, 777),
+                                  # streaming normaliser: up- and down-scaling, column parts (w > 1008), tall / wide,
+                                  # widths not divisible by 4 (gather fallback)
+                                  (1920, 1080), (100, 60), (60, 100), (300, 2000), (2000, 300), (1366, 768),
+                                  (4096, 36), (36, 4096), (1012, 1012), (260, 252)])
 def test_generic_geometry_gray(gpu_ctx, oracle, geom):
     w, h = geom
     rng = np.random.default_rng(w * 1000 + h)
@@ -86,11 +90,12 @@ def test_generic_geometry_gray(gpu_ctx, oracle, geom):
 
 
 @pytest.mark.parametrize("pixfmt,c", [(1, 3), (2, 4)])
-@pytest.mark.parametrize("geom", [(512, 512), (256, 256), (320, 240)])
+@pytest.mark.parametrize("geom", [(512, 512), (256, 256), (320, 240), (1920, 1080), (3840, 2160), (100, 60),
+                                  (1000, 1000), (1364, 40), (8192, 32)])
 def test_rgb_rgba(gpu_ctx, oracle, pixfmt, c, geom):
     w, h = geom
     rng = np.random.default_rng(pixfmt * 100 + w)
-    fr = _frames(rng, 5, h, w, c)
+    fr = _frames(rng, 5 if w * h <= 1 << 21 else 2, h, w, c)
     gpu, st = _gpu_host(fr, 7, pixfmt=pixfmt)
     ref, _ = oracle.image_hash_batch(fr, 7, pixfmt=pixfmt)
     _assert_same(gpu, ref, f"pixfmt {pixfmt} {w}x{h}")

@@ -19,7 +19,7 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 /* device-only in HIP translation units: the secret lives in constant memory */
-#define UCFP_XXH3_FN __device__ static inline
+#define UCFP_XXH3_FN __device__ static inline __attribute__((always_inline))
 #define UCFP_XXH3_CONST __constant__ const
 #else
 #define UCFP_XXH3_FN static inline
@@ -96,7 +96,10 @@ UCFP_XXH3_FN uint64_t ucfp_xxh3_avalanche(uint64_t h) {
 }
 
 /* Generic body: RD8(i) must yield input byte i as an integer. */
-#define UCFP_XXH3_DEFINE(NAME, SRC_T, RD8)                                                          \
+/* UCFP_XXH3_DEFINE = the byte-assembling little-endian readers + the hash body.  A caller with a faster way to
+ * read unaligned words (e.g. aligned LDS dwords + v_alignbyte) defines NAME_rd64 / NAME_rd32 itself and uses
+ * UCFP_XXH3_DEFINE_BODY alone. */
+#define UCFP_XXH3_DEFINE_READERS(NAME, SRC_T, RD8)                                                  \
     UCFP_XXH3_FN uint64_t NAME##_rd64(SRC_T src, size_t o) {                                        \
         uint64_t v = 0;                                                                             \
         for (int i = 7; i >= 0; i--) v = (v << 8) | (uint64_t)(RD8(src, o + (size_t)i));            \
@@ -106,7 +109,11 @@ UCFP_XXH3_FN uint64_t ucfp_xxh3_avalanche(uint64_t h) {
         uint32_t v = 0;                                                                             \
         for (int i = 3; i >= 0; i--) v = (v << 8) | (uint32_t)(RD8(src, o + (size_t)i));            \
         return v;                                                                                   \
-    }                                                                                               \
+    }
+#define UCFP_XXH3_DEFINE(NAME, SRC_T, RD8)                                                          \
+    UCFP_XXH3_DEFINE_READERS(NAME, SRC_T, RD8)                                                      \
+    UCFP_XXH3_DEFINE_BODY(NAME, SRC_T, RD8)
+#define UCFP_XXH3_DEFINE_BODY(NAME, SRC_T, RD8)                                                     \
     UCFP_XXH3_FN uint64_t NAME##_mix16(SRC_T src, size_t o, int so) {                               \
         return ucfp_xxh_mul128_fold64(NAME##_rd64(src, o) ^ ucfp_xxh_sec64(so),                     \
                                       NAME##_rd64(src, o + 8) ^ ucfp_xxh_sec64(so + 8));            \

@@ -67,8 +67,25 @@ __device__ __forceinline__ bool inword(uint32_t p, uint32_t c, uint32_t q, bool 
     return cc == C_L || cc == C_N || mid_l || mid_n;
 }
 
+// XXH3 over the canonical token stream in LDS.  Unaligned 8 / 4-byte words come from ALIGNED dwords and
+// v_alignbyte (3 + 2 or 2 + 1 instructions instead of 8 / 4 byte loads and a shift/or ladder); the stream has
+// 72 bytes of slack behind it, so the dword past the end is readable.  The hash body is force-inlined, which
+// also keeps the pointer in the LDS address space (ds_read, not flat loads).
 #define UCFP_RD8_LDS(p, i) ((p)[(i)])
-UCFP_XXH3_DEFINE(xxh3_lds, const uint8_t*, UCFP_RD8_LDS)
+__device__ __forceinline__ uint64_t xxh3_lds_rd64(const uint8_t* src, size_t o) {
+    const uint8_t* q = src + o;
+    const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(q) & 3u;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(q - sh);   // pointer arithmetic keeps the LDS address space
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+}
+__device__ __forceinline__ uint32_t xxh3_lds_rd32(const uint8_t* src, size_t o) {
+    const uint8_t* q = src + o;
+    const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(q) & 3u;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(q - sh);
+    return __builtin_amdgcn_alignbyte(p[1], p[0], sh);
+}
+UCFP_XXH3_DEFINE_BODY(xxh3_lds, const uint8_t*, UCFP_RD8_LDS)
 
 __device__ __forceinline__ uint64_t mix_h2(uint64_t h1) {
     uint64_t z = h1 + 0x9E3779B97F4A7C15ull;

@@ -5,24 +5,23 @@
 // that route.  Semantics (DESIGN.md "Hamming spec"): distance d = popcount(q ^ x); results
 // ordered by (d ascending, record_id ascending); at most k per query.
 //
-// Mapping (wave64-first): ONE LANE = ONE QUERY, the corpus code is WAVE-UNIFORM.  A wave walks
-// its corpus slice with scalar loads (s_load_dwordx16 = 8 codes), so x sits in SGPRs and the
-// per-pair work is 4 VALU ops (2 x v_xor with an SGPR operand, 2 x v_bcnt_u32_b32 chained
-// through the accumulator) plus one compare against the lane's running threshold tau.  The
-// corpus is read once per 64 queries and is Infinity-Cache resident (<= 100 MB per GPU at
-// BASELINE sizes), so with a batch of queries the kernel is VALU-bound, not HBM-bound.
-//
-// Selection never touches the fast path: a lane appends (d, id) to a private LDS list only when
-// d <= tau, and tau starts from an upper bound tau0 obtained from a sample pre-pass (the k-th
-// smallest distance inside any subset bounds the k-th over the whole corpus from above), so
-// appends are rare.  Lists are pruned wave-synchronously (all lanes run the same selection code
-// on their own list), which keeps divergence out of the slow path too.
-//
-//   hamming_sample_hist   partial (d-histogram) of a corpus sample per query  -> global hist
-//   hamming_tau0          k-th smallest sampled distance per query            -> tau0[q]
-//   hamming_scan          per (slice, 64-query group): local top-k            -> partial lists
-//   topk_merge_u32        per query: merge partial lists by (d, id)           -> final top-k
-// The same merge kernel is the last step after the multi-GPU all-gather.
+// Three scans share one structure (an upper bound tau[q] on the final k-th distance turns the search into a
+// filter; bounds come from a 32k-code sample, then from the candidates found so far, over ranges growing 8x):
+//   > 64 queries   hamming_scan_mfma   the pair distance as a +-1 x 0/1 byte contraction on the int8 matrix
+//                                      cores; suspect blocks are logged and re-evaluated exactly by hamming_rescan
+//   <= 64 queries  hamming_scan_lanes  lane = code, queries in SGPRs: a pure HBM stream
+//   robust tier    hamming_scan        lane = query, corpus code wave-uniform (s_load_dwordx16), per-pair work
+//                                      2 v_xor + 2 v_bcnt + 1 compare, lane-private LDS candidate lists pruned
+//                                      wave-synchronously: small corpora, and -- gated device-side by a flag --
+//                                      any batch whose lists or logs overflowed.  Results never depend on the
+//                                      heuristics of the other two.
+// Kernels in pipeline order:
+//   hamming_sample_hist[_lanes] / hist_reduce / tau0   k-th smallest sampled distance per query
+//   hamming_query_image                                +-1 image of the batch in the MFMA scan's LDS layout
+//   per stage: hamming_scan_mfma + hamming_rescan  (or hamming_scan_lanes), hamming_list_tau
+//   hamming_final_select                               top-k of the candidate lists by (d, id)
+//   hamming_scan + topk_merge_u32                      robust tier / fallback
+// topk_merge_u32 is also the last step after the multi-GPU all-gather.
 
 #include <hip/hip_runtime.h>
 #include <math.h>

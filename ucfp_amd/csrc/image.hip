@@ -674,6 +674,12 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
     // emit destination row j: prefix sums of the accumulated row -> LDS -> 4 output pixels per lane
     auto emit = [&](uint32_t j) {
         if (SP == 1 && w == 256 && gridDim.z == 1) {   // destination column = source column: R = 256 T, no prefix needed
+            if (h == 256) {   // 256 x 256: the plane is the luma itself (acc = 256 luma, R = D luma)
+                *reinterpret_cast<uint32_t*>(norm + img * 65536 + (size_t)j * 256 + 4 * t) =
+                    (acc[0][0] >> 8) | ((acc[0][1] >> 8) << 8) | ((acc[0][2] >> 8) << 16) | ((acc[0][3] >> 8) << 24);
+                acc[0][0] = acc[0][1] = acc[0][2] = acc[0][3] = 0;
+                return;
+            }
             uint32_t q4 = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {

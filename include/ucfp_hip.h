@@ -91,6 +91,12 @@ typedef struct ucfp_image_preprocess {
  * 0 for an invalid mask). */
 size_t ucfp_image_record_bytes(uint32_t algo);
 
+/* 64-bit global hashes of n stored image records -> Hamming codes for ucfp_index_append_dev (byte
+ * offset 32 of a 168-byte record, 32 + {32, 200, 368} of the 536-byte bundle).  `algo` names the record type,
+ * `which` (AHASH / PHASH / DHASH) the member of a MULTI bundle; ignored otherwise. */
+int ucfp_image_record_codes_dev(ucfp_ctx* ctx, const uint8_t* d_records, size_t n, uint32_t algo, uint32_t which,
+                                uint64_t* d_codes, void* stream);
+
 /* Device-resident batch.
  *   frames      n frames; frame i starts at frames + i*frame_stride, row y at
  *               + y*row_stride; pixels packed per `pixfmt`. 16-byte aligned base and
@@ -266,6 +272,11 @@ int ucfp_index_delete(ucfp_index* idx, uint32_t tenant, const uint64_t* ids, siz
 int ucfp_index_size(ucfp_index* idx, uint32_t tenant, size_t* out);
 /* IndexBackend::flush (src/index/mod.rs:63): waits for queued device work. */
 int ucfp_index_flush(ucfp_index* idx);
+/* Snapshot of the device mirror (the sidecar flat file GPU shards are rebuilt from at start-up; redb,
+ * `src/index/embedded/mod.rs:37-43,104-125`, stays the reference's source of truth).  `load` upserts the
+ * snapshot's rows into an index of the same kind / dim. */
+int ucfp_index_save(ucfp_index* idx, const char* path);
+int ucfp_index_load(ucfp_index* idx, const char* path);
 
 /* IndexBackend::knn for a batch of queries (nq = 1 is the reference's call).
  *   queries     nq rows of the index kind (host memory)

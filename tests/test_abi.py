@@ -105,3 +105,24 @@ def test_host_only_entry_points_need_no_gpu():
     assert lib.ucfp_audio_wang(None, None, 0, 8000, None, None, 0, C.byref(n)) == -4
     assert lib.ucfp_index_create(None, 1, 0, 0, C.byref(C.c_void_p())) == -4
     assert lib.ucfp_blake3(None, 5, out) == -4
+
+
+def test_query_request_wire_format():
+    """POST /v1/query body (src/server/dto.rs:74-87, handlers.rs:153): the reference's body parses unchanged;
+    `hash` is the one additive field."""
+    from ucfp_amd.core import Hit, HitSource, Modality, QueryRequest, hit_to_json
+    from ucfp_amd.errors import InvalidArgument
+    r = QueryRequest.from_json({"tenant_id": 7, "modality": "Image", "vector": [0.6, 0.6, 0]})
+    assert (r.tenant_id, r.modality, r.k, r.vector, r.hash) == (7, Modality.Image, 10, [0.6, 0.6, 0.0], None)
+    assert QueryRequest.from_json({"tenant_id": 1, "modality": "Text", "k": 0, "vector": [1]}).k == 1
+    h = QueryRequest.from_json({"tenant_id": 1, "modality": "Image", "hash": list((0x1122334455667788).to_bytes(8, "little")),
+                                "algorithm": "imgfprint-phash-v1"})
+    assert h.hash == 0x1122334455667788 and h.vector is None and h.algorithm == "imgfprint-phash-v1"
+    for bad in ({"tenant_id": 1, "modality": "Image"}, {"modality": "Image", "vector": [1]},
+                {"tenant_id": 1, "modality": "image", "vector": [1]}, {"tenant_id": 1, "modality": "Image", "hash": [1, 2]}):
+        with pytest.raises(InvalidArgument):
+            QueryRequest.from_json(bad)
+    out = hit_to_json(Hit(tenant_id=1, record_id=9, score=0.5, source=HitSource.Vector, vector_score=0.5, vector_rank=1))
+    assert list(out) == ["tenant_id", "record_id", "score", "source", "vector_score", "bm25_score", "vector_rank",
+                         "bm25_rank", "term_hits"]                      # HitOut field order, dto.rs:94-116
+    assert "distance" in hit_to_json(Hit(tenant_id=1, record_id=9, score=0.9, source=HitSource.Hamming, distance=6))

@@ -371,3 +371,74 @@ def test_hamming_randomised_configs(gpu_ctx, oracle):
         assert np.array_equal(g_d, o_d), (trial, n, nq, k, style)
         assert np.array_equal(g_ids, o_ids), (trial, n, nq, k, style)
         ix.close()
+
+
+def test_snapshot_round_trip(gpu_ctx, oracle, tmp_path):
+    """ucfp_index_save / ucfp_index_load (SURVEY 8f N2 sidecar): a fresh index loaded from the file answers
+    exactly like the one it was saved from -- several tenants, both kinds, after deletes and overwrites."""
+    from ucfp_amd import index
+    from ucfp_amd.errors import UcfpError
+    rng = np.random.default_rng(5)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    for tenant, n in ((0, 30000), (7, 500), (9, 1)):
+        ix.upsert(tenant, np.arange(n, dtype=np.uint64) * 3 + tenant, rng.integers(0, 2**64, n, dtype=np.uint64))
+    ix.delete(0, np.arange(0, 3000, 3, dtype=np.uint64) * 3)
+    ix.upsert(7, np.array([7 + 3 * 10], np.uint64), np.array([0xABCDEF], np.uint64))       # overwrite
+    path = tmp_path / "ham.idx"
+    ix.save(path)
+    iy = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    iy.load(path)
+    q = rng.integers(0, 2**64, 33, dtype=np.uint64)
+    for tenant in (0, 7, 9, 4):
+        assert ix.size(tenant) == iy.size(tenant)
+        a, b = ix.search(tenant, q, 10), iy.search(tenant, q, 10)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    cx = index.DeviceIndex(index.COSINE_F32, 48, ctx=gpu_ctx)
+    rows = rng.standard_normal((2000, 48)).astype(np.float32)
+    cx.upsert(2, np.arange(2000, dtype=np.uint64), rows)
+    cpath = tmp_path / "cos.idx"
+    cx.save(cpath)
+    cy = index.DeviceIndex(index.COSINE_F32, 48, ctx=gpu_ctx)
+    cy.load(cpath)
+    qv = rng.standard_normal((5, 48)).astype(np.float32)
+    a, b = cx.search(2, qv, 7), cy.search(2, qv, 7)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(UcfpError):            # kind / dim mismatch is refused
+        index.DeviceIndex(index.COSINE_F32, 32, ctx=gpu_ctx).load(cpath)
+    with pytest.raises(UcfpError):
+        iy.load(tmp_path / "missing.idx")
+
+
+def test_record_codes_and_query_dispatch(gpu_ctx, oracle, torch_cuda):
+    """Stored image records -> Hamming codes on the device (SURVEY 8f N2 offsets), and POST /v1/query with the
+    additive `hash` field routed to the Hamming space (N3)."""
+    torch = torch_cuda
+    from ucfp_amd import image, index
+    from ucfp_amd.core import Modality, QueryRequest, Record
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (40, 512, 512), dtype=np.uint8)
+    multi, _ = image.fingerprint_frames(frames, algo=image.MULTI)
+    ph, _ = image.fingerprint_frames(frames, algo=image.PHASH)
+    d_multi = torch.from_numpy(multi.copy()).cuda()
+    codes = torch.empty(40, dtype=torch.int64, device="cuda")
+    for which, off in ((image.AHASH, 64), (image.PHASH, 232), (image.DHASH, 400)):
+        image.record_codes_dev(d_multi.data_ptr(), 40, codes.data_ptr(), algo=image.MULTI, which=which)
+        torch.cuda.synchronize()
+        want = np.ascontiguousarray(multi[:, off:off + 8]).view("<u8").reshape(-1)
+        assert np.array_equal(codes.cpu().numpy().view(np.uint64), want)
+    d_ph = torch.from_numpy(ph.copy()).cuda()
+    image.record_codes_dev(d_ph.data_ptr(), 40, codes.data_ptr(), algo=image.PHASH)
+    torch.cuda.synchronize()
+    assert np.array_equal(codes.cpu().numpy().view(np.uint64), np.ascontiguousarray(ph[:, 32:40]).view("<u8").reshape(-1))
+    # the same records through the IndexBackend-shaped facade and the query DTO
+    g = index.GpuIndex(gpu_ctx)
+    g.upsert([Record(tenant_id=3, record_id=100 + i, modality=Modality.Image, format_version=1,
+                     algorithm="imgfprint-multihash-v1", config_hash=0, fingerprint=multi[i].tobytes(),
+                     embedding=[float(i), 1.0, 0.5]) for i in range(40)])
+    want_hash = int.from_bytes(multi[17, 232:240].tobytes(), "little")
+    hits = g.query(QueryRequest.from_json({"tenant_id": 3, "modality": "Image", "k": 3, "hash": want_hash,
+                                           "algorithm": "imgfprint-phash-v1"}))
+    assert hits[0].record_id == 117 and hits[0].distance == 0 and hits[0].source == "hamming" and hits[0].score == 1.0
+    vh = g.query(QueryRequest.from_json({"tenant_id": 3, "modality": "Image", "vector": [5.0, 1.0, 0.5]}))
+    assert vh[0].record_id == 105 and vh[0].source == "vector" and vh[0].vector_rank == 1 and len(vh) == 10
+    assert g.query(QueryRequest.from_json({"tenant_id": 4, "modality": "Image", "vector": [5.0, 1.0, 0.5]})) == []

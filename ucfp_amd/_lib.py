@@ -75,6 +75,10 @@ SIGNATURES = {
     "ucfp_lsh_build_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_lsh_query_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "ucfp_image_record_codes_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p,
+                                              C.c_void_p]),
+    "ucfp_index_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ucfp_index_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ucfp_index_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ucfp_index_destroy": (None, [C.c_void_p]),
     "ucfp_index_upsert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -476,6 +476,25 @@ int ucfp_text_simhash_batch(ucfp_ctx* ctx, const uint8_t* utf8, const uint64_t* 
     return text_host(ctx, true, utf8, offsets, n, mode, 1, out, status);
 }
 
+int ucfp_image_record_codes_dev(ucfp_ctx* ctx, const uint8_t* d_records, size_t n, uint32_t algo, uint32_t which,
+                                uint64_t* d_codes, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (n && (!d_records || !d_codes)) return fail(UCFP_E_INVALID, "records/codes is NULL");
+    const size_t rec = ucfp_image_record_bytes(algo);
+    if (rec == 0) return fail(UCFP_E_INVALID, "algo mask %u is not a record type", algo);
+    uint32_t offset = 32;   // single-algorithm record: exact[32] | global_hash
+    if (algo == UCFP_IMG_MULTI) {
+        if (which == UCFP_IMG_AHASH) offset = 32 + 32;
+        else if (which == UCFP_IMG_PHASH) offset = 32 + 168 + 32;
+        else if (which == UCFP_IMG_DHASH) offset = 32 + 336 + 32;
+        else return fail(UCFP_E_INVALID, "`which` must name one algorithm of the bundle (got %u)", which);
+    }
+    if ((uintptr_t)d_records & 3) return fail(UCFP_E_INVALID, "records need a 4-byte aligned base");
+    ucfp::launch_image_record_codes(d_records, n, (uint32_t)rec, offset, d_codes, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UCFP_OK;
+}
+
 int ucfp_image_synth_dev(ucfp_ctx* ctx, uint8_t* frames, size_t n, uint32_t width, uint32_t height,
                          size_t first_index, void* stream) {
     if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");

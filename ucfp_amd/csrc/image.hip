@@ -914,6 +914,24 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
     return 0;
 }
 
+// 64-bit global hash of stored image records -> Hamming codes: byte offset 32 of a 168-byte
+// record, 32 + {32, 200, 368} inside the 536-byte bundle (ahash, phash, dhash).
+__global__ void image_record_codes_kernel(const uint8_t* __restrict__ records, size_t n, uint32_t rec_bytes,
+                                          uint32_t offset, uint64_t* __restrict__ codes) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(records + i * rec_bytes + offset);   // 4-byte aligned
+    codes[i] = (uint64_t)p[0] | ((uint64_t)p[1] << 32);
+}
+
+int launch_image_record_codes(const uint8_t* records, size_t n, uint32_t rec_bytes, uint32_t offset, uint64_t* codes,
+                              hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(image_record_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, records, n,
+                       rec_bytes, offset, codes);
+    return 0;
+}
+
 int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,
                        hipStream_t stream) {
     if (n == 0) return 0;

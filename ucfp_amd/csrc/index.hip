@@ -444,6 +444,91 @@ int ucfp_index_flush(ucfp_index* ix) {
     return UCFP_OK;
 }
 
+// ---- snapshot (the sidecar flat file a restart rebuilds the GPU shard from) ------------------
+// File: "UCFPIDX1" | kind u32 | dim u32 | row_bytes u64 | tenants u32 | 0 u32 |
+//       per tenant: tenant u32 | 0 u32 | n u64 | ids[n] u64 | rows[n * row_bytes]          (little-endian)
+// redb stays the reference's source of truth; this file is the device mirror's own checkpoint.
+int ucfp_index_save(ucfp_index* ix, const char* path) {
+    if (!ix || !path) return capi_fail(UCFP_E_INVALID, "index/path is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    FILE* f = fopen(path, "wb");
+    if (!f) return capi_fail(UCFP_E_INDEX, "cannot open %s for writing", path);
+    bool ok = fwrite("UCFPIDX1", 1, 8, f) == 8;
+    const uint32_t hdr[2] = {(uint32_t)ix->kind, ix->dim};
+    const uint64_t rb = ix->row_bytes;
+    uint32_t nt[2] = {0, 0};
+    for (auto& kv : ix->shards) nt[0] += kv.second.n ? 1u : 0u;
+    ok = ok && fwrite(hdr, 4, 2, f) == 2 && fwrite(&rb, 8, 1, f) == 1 && fwrite(nt, 4, 2, f) == 2;
+    std::vector<uint8_t> host;
+    const size_t chunk_rows = 1u << 20;
+    for (auto& kv : ix->shards) {
+        const Shard& s = kv.second;
+        if (!s.n || !ok) continue;
+        const uint32_t th[2] = {kv.first, 0};
+        const uint64_t n = s.n;
+        ok = ok && fwrite(th, 4, 2, f) == 2 && fwrite(&n, 8, 1, f) == 1;
+        for (int pass = 0; pass < 2 && ok; pass++) {   // ids, then rows
+            const size_t unit = pass == 0 ? 8 : ix->row_bytes;
+            const uint8_t* src = pass == 0 ? reinterpret_cast<const uint8_t*>(s.ids) : s.rows;
+            for (size_t r0 = 0; r0 < s.n && ok; r0 += chunk_rows) {
+                const size_t cnt = s.n - r0 < chunk_rows ? s.n - r0 : chunk_rows;
+                host.resize(cnt * unit);
+                if (hipMemcpy(host.data(), src + r0 * unit, cnt * unit, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+                ok = ok && fwrite(host.data(), 1, cnt * unit, f) == cnt * unit;
+            }
+        }
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? UCFP_OK : capi_fail(UCFP_E_INDEX, "short write to %s", path);
+}
+
+int ucfp_index_load(ucfp_index* ix, const char* path) {
+    if (!ix || !path) return capi_fail(UCFP_E_INVALID, "index/path is NULL");
+    FILE* f = fopen(path, "rb");
+    if (!f) return capi_fail(UCFP_E_INDEX, "cannot open %s", path);
+    char magic[8];
+    uint32_t hdr[2], nt[2];
+    uint64_t rb;
+    int rc = UCFP_OK;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "UCFPIDX1", 8) != 0 || fread(hdr, 4, 2, f) != 2 ||
+        fread(&rb, 8, 1, f) != 1 || fread(nt, 4, 2, f) != 2)
+        rc = capi_fail(UCFP_E_INDEX, "%s is not an index snapshot", path);
+    else if ((int)hdr[0] != ix->kind || hdr[1] != ix->dim || rb != ix->row_bytes)
+        rc = capi_fail(UCFP_E_INVALID, "snapshot kind/dim (%u/%u) does not match the index (%d/%u)", hdr[0], hdr[1],
+                       ix->kind, ix->dim);
+    std::vector<uint64_t> ids;
+    std::vector<uint8_t> rows;
+    const size_t chunk_rows = 1u << 20;
+    for (uint32_t t = 0; rc == UCFP_OK && t < nt[0]; t++) {
+        uint32_t th[2];
+        uint64_t n;
+        if (fread(th, 4, 2, f) != 2 || fread(&n, 8, 1, f) != 1) {
+            rc = capi_fail(UCFP_E_INDEX, "truncated snapshot %s", path);
+            break;
+        }
+        // ids precede rows in the file: remember where each section starts and read both in step
+        const long ids_at = ftell(f);
+        const long rows_at = ids_at + (long)(n * 8);
+        for (uint64_t r0 = 0; rc == UCFP_OK && r0 < n; r0 += chunk_rows) {
+            const size_t cnt = n - r0 < chunk_rows ? (size_t)(n - r0) : chunk_rows;
+            ids.resize(cnt);
+            rows.resize(cnt * rb);
+            if (fseek(f, ids_at + (long)(r0 * 8), SEEK_SET) != 0 || fread(ids.data(), 8, cnt, f) != cnt ||
+                fseek(f, rows_at + (long)(r0 * rb), SEEK_SET) != 0 || fread(rows.data(), 1, cnt * rb, f) != cnt * rb) {
+                rc = capi_fail(UCFP_E_INDEX, "truncated snapshot %s", path);
+                break;
+            }
+            rc = ucfp_index_upsert(ix, th[0], ids.data(), rows.data(), cnt);
+        }
+        if (rc == UCFP_OK && fseek(f, rows_at + (long)(n * rb), SEEK_SET) != 0)
+            rc = capi_fail(UCFP_E_INDEX, "truncated snapshot %s", path);
+    }
+    fclose(f);
+    return rc;
+}
+
 int ucfp_index_search_dev(ucfp_index* ix, uint32_t tenant, const void* d_queries, size_t nq, uint32_t k,
                           uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_dist, uint32_t* d_out_counts,
                           void* stream) {

@@ -75,6 +75,14 @@ def fingerprint_frames_dev(frames_ptr: int, n: int, width: int, height: int, *, 
         exact_ptr or None, out_ptr, status_ptr or None, stream or None))
 
 
+def record_codes_dev(records_ptr: int, n: int, codes_ptr: int, *, algo: int = MULTI, which: int = PHASH,
+                     stream: int = 0, ctx=None) -> None:
+    """Device records (168 / 536 B each) -> their 64-bit global hashes, ready for DeviceIndex.append_dev."""
+    ctx = ctx or _lib.default_context()
+    _lib.check(_lib.load().ucfp_image_record_codes_dev(ctx.handle, records_ptr, n, algo, which, codes_ptr,
+                                                       stream or None))
+
+
 def fingerprint_frames(frames: np.ndarray, *, algo: int = MULTI, pixfmt: int = PIX_GRAY8,
                        exact: Optional[np.ndarray] = None,
                        preprocess: Optional[PreprocessConfig] = None, ctx=None):

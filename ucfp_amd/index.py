@@ -65,6 +65,14 @@ class DeviceIndex:
         _lib.check(self._lib.ucfp_index_upsert(self.handle, tenant, ids.ctypes.data, rows.ctypes.data,
                                                ids.shape[0]))
 
+    def save(self, path: str) -> None:
+        """Snapshot every tenant's ids + rows to a flat file (the device mirror's checkpoint)."""
+        _lib.check(self._lib.ucfp_index_save(self.handle, str(path).encode()))
+
+    def load(self, path: str) -> None:
+        """Upsert a snapshot written by `save` (same kind / dim)."""
+        _lib.check(self._lib.ucfp_index_load(self.handle, str(path).encode()))
+
     def append_dev(self, tenant: int, ids_ptr: int, rows_ptr: int, n: int, stream: int = 0) -> None:
         _lib.check(self._lib.ucfp_index_append_dev(self.handle, tenant, ids_ptr, rows_ptr, n, stream or None))
 
@@ -179,6 +187,23 @@ class GpuIndex:
             tenant_id, np.array([query_hash], np.uint64), min(k, MAX_K))
         return [Hit(tenant_id=tenant_id, record_id=int(ids[0, i]), score=float(scores[0, i]),
                     source=HitSource.Hamming, distance=int(dist[0, i])) for i in range(int(counts[0]))]
+
+    def query(self, req) -> List[Hit]:
+        """POST /v1/query (handlers.rs:143-187) with the additive `hash` field: a vector goes to the cosine kNN,
+        a hash to the Hamming space `algorithm` (default: the only hash space present)."""
+        if req.hash is not None:
+            space = req.algorithm
+            if space is None:
+                if len(self._ham) != 1:
+                    raise InvalidArgument("`algorithm` is required when several hash spaces exist")
+                space = next(iter(self._ham))
+            hits = self.hamming(req.tenant_id, space, req.hash, req.k)
+        else:
+            hits = self.knn(req.tenant_id, req.vector or [], req.k)
+        for rank, h in enumerate(hits):   # Matcher::search fills the rank of the only list it fused (matcher/mod.rs:140-207)
+            if h.source == HitSource.Vector:
+                h.vector_score, h.vector_rank = h.score, rank + 1
+        return hits
 
     def flush(self) -> None:
         for ix in list(self._cos.values()) + list(self._ham.values()):

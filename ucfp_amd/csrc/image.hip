@@ -372,7 +372,33 @@ __device__ __forceinline__ void hash_phase_and_store(ImageLds& L, uint32_t algo,
 
 // ---- fused kernel: GRAY8 frames with width = height = 256*S ---------------------------------
 // tile = 8x8 normalised px = (8S)x(8S) source px; thread t handles tiles t + 256k, k = 0..3.
-template <int S>
+// 8 consecutive pixels of a colour row -> 8 lumas (spec I1) with v_dot4_u32_u8 on the raw dwords: RGB = 6 dwords
+// (R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 | ...), RGBA = 8.  `p` is 8-byte aligned (launcher).
+template <int BPP>
+__device__ __forceinline__ void luma8(const uint8_t* __restrict__ p, uint32_t (&l)[8]) {
+    constexpr uint32_t W = 0x001D964Du;  // bytes: R*77, G*150, B*29, (4th)*0
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+    if (BPP == 3) {
+        const uint2 a = q[0], b = q[1], c = q[2];
+        const uint32_t w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t w0 = w[3 * h], w1 = w[3 * h + 1], w2 = w[3 * h + 2];
+            l[4 * h + 0] = __builtin_amdgcn_udot4(w0, W, 128u, false) >> 8;
+            l[4 * h + 1] = __builtin_amdgcn_udot4(w1, W >> 8, __builtin_amdgcn_udot4(w0, W << 24, 128u, false), false) >> 8;
+            l[4 * h + 2] = __builtin_amdgcn_udot4(w2, W >> 16, __builtin_amdgcn_udot4(w1, W << 16, 128u, false), false) >> 8;
+            l[4 * h + 3] = __builtin_amdgcn_udot4(w2, W << 8, 128u, false) >> 8;
+        }
+    } else {
+        const uint2 a = q[0], b = q[1], c = q[2], d = q[3];
+        const uint32_t w[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = __builtin_amdgcn_udot4(w[i], W, 128u, false) >> 8;
+    }
+}
+
+// BPP > 1 (colour) is built for S = 1 only: 256 x 256 RGB8 / RGBA8 frames hashed straight from the source
+template <int S, int BPP = 1>
 __global__ __launch_bounds__(kNT) void image_hash_gray_kernel(
     const uint8_t* __restrict__ frames, size_t n, size_t row_stride, size_t frame_stride,
     uint32_t algo, const uint8_t* __restrict__ exact, uint8_t* __restrict__ out,
@@ -386,9 +412,10 @@ __global__ __launch_bounds__(kNT) void image_hash_gray_kernel(
 
     for (int k = 0; k < 1024 / kNT; k++) {
         const int ty = (tid >> 5) + 2 * kNW * k;
-        const uint8_t* base = f + (size_t)(8 * S * ty) * row_stride + (size_t)(8 * S * tx);
+        const uint8_t* base = f + (size_t)(8 * S * ty) * row_stride + (size_t)(8 * S * tx) * BPP;
         TileAcc acc;
         acc.init();
+        static_assert(BPP == 1 || S == 1, "colour frames are fused at 256 x 256 (here) and 512 x 512 (strip kernel)");
         if constexpr (S == 2) {
             uint4 rows[16];
 #pragma unroll
@@ -399,6 +426,14 @@ __global__ __launch_bounds__(kNT) void image_hash_gray_kernel(
                 uint32_t nA[8], nB[8];
                 norm_row_s2(rows[4 * j2], rows[4 * j2 + 1], nA);
                 norm_row_s2(rows[4 * j2 + 2], rows[4 * j2 + 3], nB);
+                acc.push_rowpair(L, ty, tx, j2, nA, nB);
+            }
+        } else if constexpr (S == 1 && BPP != 1) {
+#pragma unroll
+            for (int j2 = 0; j2 < 4; j2++) {
+                uint32_t nA[8], nB[8];
+                luma8<BPP>(base + (size_t)(2 * j2) * row_stride, nA);
+                luma8<BPP>(base + (size_t)(2 * j2 + 1) * row_stride, nB);
                 acc.push_rowpair(L, ty, tx, j2, nA, nB);
             }
         } else if constexpr (S == 1) {
@@ -846,6 +881,16 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
         else
             hipLaunchKernelGGL(image_hash_gray_kernel<4>, grid, block, 0, stream, frames, n,
                                row_stride, frame_stride, algo, exact, out, status);
+        return 0;
+    }
+    if (S == 1 && pixfmt != 0 && (((uintptr_t)frames | row_stride | frame_stride) & 7u) == 0) {
+        dim3 grid((unsigned)n), block(kNT);
+        if (pixfmt == 1)
+            hipLaunchKernelGGL((image_hash_gray_kernel<1, 3>), grid, block, 0, stream, frames, n, row_stride, frame_stride,
+                               algo, exact, out, status);
+        else
+            hipLaunchKernelGGL((image_hash_gray_kernel<1, 4>), grid, block, 0, stream, frames, n, row_stride, frame_stride,
+                               algo, exact, out, status);
         return 0;
     }
     if (S == 2 && ((pixfmt == 2 && aligned16(frames, row_stride, frame_stride)) ||

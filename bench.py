@@ -589,6 +589,34 @@ def main():
                "achieved_GBs": nr * (FRAME_SIDE * FRAME_SIDE * 3 + REC_BYTES) / rms / 1e6,
                "frac_of_hbm_peak": nr * (FRAME_SIDE * FRAME_SIDE * 3 + REC_BYTES) / rms / 1e6 / HBM_PEAK_GBS}
         del rgbf, rout
+    # ---- the same launch followed by what an ingest does with the records: the three 64-bit global hashes of every
+    # bundle go into per-algorithm Hamming shards, all on the device (hash -> ucfp_image_record_codes_dev ->
+    # ucfp_index_append_dev); the main line above stays the bare fingerprint rate BASELINE names ----
+    from ucfp_amd import index as _index
+    shards = [_index.DeviceIndex(_index.HAMMING64, 0, _index.APPEND_ONLY, ctx) for _ in range(3)]
+    codes = torch.empty((3, n), dtype=torch.int64, device=dev)
+    rec_ids = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64, device=dev)
+
+    def ingest_step():
+        step()
+        for a, which in enumerate((image.AHASH, image.PHASH, image.DHASH)):
+            image.record_codes_dev(out.data_ptr(), n, codes[a].data_ptr(), algo=image.MULTI, which=which, stream=stream,
+                                   ctx=ctx)
+            shards[a].append_dev(0, rec_ids.data_ptr(), codes[a].data_ptr(), n, stream)
+    ingest_step()
+    torch.cuda.synchronize()
+    i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    i0.record()
+    for _ in range(5):
+        ingest_step()
+    i1.record()
+    torch.cuda.synchronize()
+    ingest_ms = i0.elapsed_time(i1) / 5
+    ingest = {"ms_per_batch": ingest_ms, "fingerprints_per_s": n / ingest_ms * 1e3 * world,
+              "indexed_codes_per_gpu": int(shards[0].size(0)), "what": "hash + 3 x (record -> code, append to a Hamming shard)"}
+    for sh in shards:
+        sh.close()
+    del shards, codes, rec_ids
     if rank == 0:
         total_frames = n * world * args.steps
         value = total_frames / elapsed
@@ -625,6 +653,7 @@ def main():
             },
         }
         res["rgb8_variant"] = rgb
+        res["ingest_to_index"] = ingest
         res["ann"] = None
         if args.cpu_sample > 0 and world == 1:
             head = out[:min(args.cpu_sample, n)].cpu().numpy()

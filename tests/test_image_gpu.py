@@ -305,3 +305,25 @@ def test_micro_batcher_coalesces_concurrent_requests(gpu_ctx, oracle):
         assert rec == ref[0].tobytes()
     finally:
         b.close()
+
+
+def test_random_geometries_match_oracle(gpu_ctx, oracle):
+    """Thirty random (width, height, pixel format) draws through the streaming normaliser and its fallbacks:
+    widths around the strip / column-part boundaries, extreme aspect ratios, both scaling directions."""
+    rng = np.random.default_rng(424242)
+    special_w = [32, 36, 252, 256, 260, 508, 1004, 1008, 1012, 2016, 2020, 4096]
+    for trial in range(30):
+        w = int(rng.choice(special_w)) if trial % 3 == 0 else int(rng.integers(8, 700)) * 4
+        h = int(rng.integers(32, 1400)) if trial % 5 else int(rng.choice([32, 33, 255, 256, 257, 512]))
+        if trial % 7 == 6:
+            w += int(rng.integers(1, 4))          # not a multiple of 4: gather fallback
+        pixfmt = int(rng.integers(0, 3))
+        c = (1, 3, 4)[pixfmt]
+        shape = (2, h, w) if c == 1 else (2, h, w, c)
+        fr = rng.integers(0, 256, shape, dtype=np.uint8)
+        fr[1] = (fr[1].astype(np.uint16) // 8 + (np.arange(w, dtype=np.uint16)[None, :, None] if c > 1
+                                                 else np.arange(w, dtype=np.uint16)[None, :]) % 200).astype(np.uint8)
+        gpu, st = _gpu_host(fr, 7, pixfmt=pixfmt)
+        ref, _ = oracle.image_hash_batch(fr, 7, pixfmt=pixfmt)
+        assert not st.any(), (w, h, pixfmt)
+        _assert_same(gpu, ref, f"random geometry {w}x{h} pixfmt {pixfmt}")

@@ -67,10 +67,13 @@ struct FftLds {
 // per lane per instruction, so 6 instructions instead of 10).  Same operations in the same order as the
 // oracle: t1 = xr c, t2 = xi s, t3 = xr s, t4 = xi c, v = (t1 - t2, t3 + t4), u' = u + v, x' = u - v.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void bfly(f32x2& u, f32x2& x, float c, float sn) {
-    const f32x2 a = x * f32x2{c, c};                    // (t1, t4)
-    const f32x2 b = f32x2{x.y, x.x} * f32x2{sn, sn};    // (t2, t3)
-    const f32x2 v = a + f32x2{-b.x, b.y};               // (t1 - t2, t4 + t3)
+__device__ __forceinline__ void bfly(f32x2& u, f32x2& x, f32x2 tw) {   // tw = (c, s)
+    const f32x2 a = x * f32x2{tw.x, tw.x};              // (t1, t4): broadcast by op_sel, no move
+    // (-t2, t3) = (xi * -s, xr * s) in ONE instruction: swapped x halves by op_sel, the low product's sign by the
+    // source modifier (xi * (-s) == -(xi * s) exactly); the compiler spends a negate + a move on this otherwise
+    f32x2 b;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(b) : "v"(x), "v"(tw));
+    const f32x2 v = a + b;                              // (t1 - t2, t4 + t3)
     const f32x2 w = u;
     u = w + v;
     x = w - v;
@@ -103,7 +106,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         for (int i0 = 0; i0 < E; i0++) {
             if (i0 & half) continue;
             const int jj = i0 & (half - 1);
-            bfly(x[i0], x[i0 + half], c_tw[jj * tstep][0], c_tw[jj * tstep][1]);
+            bfly(x[i0], x[i0 + half], f32x2{c_tw[jj * tstep][0], c_tw[jj * tstep][1]});
         }
     }
     // ---- transpose 1 ----
@@ -125,7 +128,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         for (int m0 = 0; m0 < E; m0++) {
             if (m0 & halfm) continue;
             const int jj = ((m0 & (halfm - 1)) << B) | lo;
-            bfly(x[m0], x[m0 + halfm], tw[jj * tstep][0], tw[jj * tstep][1]);
+            bfly(x[m0], x[m0 + halfm], *reinterpret_cast<const f32x2*>(tw[jj * tstep]));
         }
     }
     // ---- transpose 2 (own slots back, then gather p = e*64 + lane) ----
@@ -149,7 +152,7 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
         for (int e0 = 0; e0 < E; e0++) {
             if (e0 & halfe) continue;
             const int jj = ((e0 & (halfe - 1)) << 6) | lane;
-            bfly(x[e0], x[e0 + halfe], tw[jj * tstep][0], tw[jj * tstep][1]);
+            bfly(x[e0], x[e0 + halfe], *reinterpret_cast<const f32x2*>(tw[jj * tstep]));
         }
     }
     wave_lds_sync();

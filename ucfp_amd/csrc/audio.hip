@@ -424,6 +424,59 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* __
     if (tid == 0) out[n] = carry;
 }
 
+// Multi-block exclusive scan: blocks of 4096 elements scan locally and publish their totals, one block scans
+// the totals, a third pass adds the block offsets.  (The single-block kernel above walks 10^6 pair counts in
+// 66 serial trips: 0.9 ms of an 12 ms job.)
+constexpr int kScanBlock = 4096;
+__global__ __launch_bounds__(256) void scan_blocks_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t i0 = (size_t)blockIdx.x * kScanBlock + (size_t)tid * 16;
+    uint32_t v[16], tot = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        v[e] = i0 + e < n ? in[i0 + e] : 0u;
+        tot += v[e];
+    }
+    uint32_t inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    uint32_t run = woff + inc - tot;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        if (i0 + e < n) out[i0 + e] = run;
+        run += v[e];
+    }
+    if (tid == 255) totals[blockIdx.x] = run;
+}
+__global__ void scan_add_kernel(uint32_t* __restrict__ out, size_t n, const uint32_t* __restrict__ block_off) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += block_off[i / kScanBlock];
+    if (i == 0) out[n] = block_off[(n + kScanBlock - 1) / kScanBlock];   // grand total behind the last element
+}
+// out[0..n] (n + 1 entries); tmp holds 2 x (blocks + 1) words
+void launch_exclusive_scan(const uint32_t* in, size_t n, uint32_t* out, uint32_t* tmp, hipStream_t stream) {
+    const size_t blocks = (n + kScanBlock - 1) / kScanBlock;
+    if (blocks <= 1) {
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, in, n, out);
+        return;
+    }
+    uint32_t* totals = tmp;
+    uint32_t* offs = tmp + blocks + 1;
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, n, out, totals);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)totals, blocks, offs);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n,
+                       (const uint32_t*)offs);
+}
+
 __global__ void wang_compact_kernel(const uint32_t* __restrict__ sel_cnt, const uint32_t* __restrict__ sel_off,
                                     const uint32_t* __restrict__ sel_t, const uint32_t* __restrict__ sel_k,
                                     const float* __restrict__ sel_p, uint32_t n_sec, uint32_t pps,
@@ -537,6 +590,7 @@ WangWs wang_ws_layout(size_t n_samples, uint32_t pps) {
     w.pp = off;       off = align(off + maxp * 4);
     w.pair_cnt = off; off = align(off + (maxp + 1) * 4);
     w.pair_off = off; off = align(off + (maxp + 1) * 4);
+    w.scan_tmp = off; off = align(off + 2 * (maxp / 4096 + 4) * 4);
     w.total = off + 256;
     return w;
 }
@@ -558,8 +612,7 @@ int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t,
                        w.frames, u32(w.cand_cnt), u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
     hipLaunchKernelGGL(wang_select_kernel, dim3(w.n_sec), dim3(64), 0, stream, u32(w.cand_cnt), u32(w.cand_t),
                        u32(w.cand_k), f32(w.cand_p), pps, u32(w.sel_cnt), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p));
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, u32(w.sel_cnt), (size_t)w.n_sec,
-                       u32(w.sel_off));
+    launch_exclusive_scan(u32(w.sel_cnt), (size_t)w.n_sec, u32(w.sel_off), u32(w.scan_tmp), stream);
     hipLaunchKernelGGL(wang_compact_kernel, dim3(blocks_for((size_t)w.n_sec * pps, 256)), dim3(256), 0, stream,
                        u32(w.sel_cnt), u32(w.sel_off), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p), w.n_sec, pps,
                        u32(w.pt), u32(w.pk), f32(w.pp));
@@ -569,8 +622,7 @@ int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t,
     hipLaunchKernelGGL(wang_pair_kernel<false>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
                        u32(w.pk), f32(w.pp), np_ptr, fan_out, zone_t, zone_f, floor_power, u32(w.pair_cnt),
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, u32(w.pair_cnt), maxp,
-                       u32(w.pair_off));
+    launch_exclusive_scan(u32(w.pair_cnt), maxp, u32(w.pair_off), u32(w.scan_tmp), stream);
     hipLaunchKernelGGL(wang_pair_kernel<true>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
                        u32(w.pk), f32(w.pp), np_ptr, fan_out, zone_t, zone_f, floor_power, (uint32_t*)nullptr,
                        (const uint32_t*)u32(w.pair_off), out, cap);

@@ -89,7 +89,7 @@ struct WangWs {
     size_t frames = 0;
     uint32_t n_sec = 0;
     size_t P, rowmax, cand_cnt, cand_t, cand_k, cand_p, sel_cnt, sel_off, sel_t, sel_k, sel_p, pt, pk, pp, pair_cnt,
-        pair_off, total = 0;
+        pair_off, scan_tmp, total = 0;
 };
 size_t audio_resample_len(size_t n, uint32_t sr_in, uint32_t sr_out);
 int launch_resample_linear(const float* in, size_t n, uint32_t sr_in, uint32_t sr_out, float* out,

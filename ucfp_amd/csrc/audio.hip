@@ -57,11 +57,26 @@ __global__ void resample_linear_kernel(const float* __restrict__ in, size_t n, u
 //   phase 2  lane (hi, lo) holds p = hi*E*E + m*E + lo  -> stages B+1..2B
 //   phase 3  lane l holds p = e*64 + l          -> stages 2B+1..log2 N
 // Two LDS transposes (padded: p + p/E) replace the ten LDS round trips of a stage-by-stage FFT.
+// Twiddles of the stages that run after a transpose live in LDS STAGE-MAJOR: stage st (2^(st-1) distinct
+// twiddles W^(jj * 2048 >> st)) occupies entries [2^(st-1) - E, 2^st - E), so a read at jj = const | lane-low-bits
+// touches consecutive 8-byte entries.  (Read from the natural 1024-entry table at stride 2048 >> st, the 16 distinct
+// addresses of a stage-5 read all fall on one bank: 59 % of the LDS cycles of the first version were conflicts.)
+constexpr int kFftWaves = 8;   // one workgroup per CU: 16 KiB of twiddles + 8 x 16.5 KiB (N = 2048)
 template <int N>
 struct FftLds {
-    float tw[1024][2];
-    float2 buf[4][N + 64];   // per wave; reused as the power spectrum (float[N/2]) afterwards
+    float2 stw[N - N / 64];
+    float2 buf[kFftWaves][N + 64];   // per wave; reused as the power spectrum (float[N/2]) afterwards
 };
+template <int N>
+__device__ __forceinline__ void fill_stage_twiddles(float2* __restrict__ stw, int tid, int nthreads) {
+    constexpr int E = N / 64;
+    for (int idx = tid; idx < N - E; idx += nthreads) {
+        const int g = idx + E;                       // 2^(st-1) + jj
+        const int st = 32 - __clz(g);
+        const int jj = g - (1 << (st - 1));
+        stw[idx] = make_float2(c_tw[jj * (2048 >> st)][0], c_tw[jj * (2048 >> st)][1]);
+    }
+}
 
 // One radix-2 butterfly on (re, im) pairs in packed f32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations
 // per lane per instruction, so 6 instructions instead of 10).  Same operations in the same order as the
@@ -79,25 +94,44 @@ __device__ __forceinline__ void bfly(f32x2& u, f32x2& x, f32x2 tw) {   // tw = (
     x = w - v;
 }
 
+// element i of lane L is p = E*L + i = bit-reversed sample index n = (rev(i) << 6) | rev(L); the sample
+// positions of a lane are the same for every frame, so a caller may keep the window in registers
 template <int N>
-__device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, int lane, float (*tw)[2],
-                                               float2* __restrict__ buf) {
+__device__ __forceinline__ void frame_load(const float* __restrict__ src, int lane, float (&s)[N / 64]) {
     constexpr int E = N / 64;
     constexpr int B = E == 16 ? 4 : 5;
-    constexpr int BITS = N == 1024 ? 10 : 11;
-    constexpr int TWS = 2048 / N;
-    f32x2 x[E];
-    // ---- load + window, element i of lane L is p = E*L + i = bit-reversed sample index ----
     const uint32_t rl = __brev((uint32_t)lane) >> 26;  // 6-bit reversal of the lane
 #pragma unroll
     for (int i = 0; i < E; i++) {
         const uint32_t ri = __brev((uint32_t)i) >> (32 - B);   // compile-time after unrolling
-        const uint32_t n = (ri << 6) | rl;
-        float c = tw[(n * TWS) & 1023][0];
-        if (n * TWS >= 1024) c = -c;
-        const float w = 0.5f - 0.5f * c;
-        x[i] = f32x2{src[n] * w, 0.0f};
+        s[i] = src[(ri << 6) | rl];
     }
+}
+template <int N>
+__device__ __forceinline__ void frame_window(int lane, float (&w)[N / 64]) {
+    constexpr int E = N / 64;
+    constexpr int B = E == 16 ? 4 : 5;
+    constexpr int TWS = 2048 / N;
+    const uint32_t rl = __brev((uint32_t)lane) >> 26;
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const uint32_t ri = __brev((uint32_t)i) >> (32 - B);
+        const uint32_t n = (ri << 6) | rl;
+        float c = c_tw[(n * TWS) & 1023][0];
+        if (n * TWS >= 1024) c = -c;
+        w[i] = 0.5f - 0.5f * c;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], const float (&win)[N / 64], int lane,
+                                                    const float2* __restrict__ stw, float2* __restrict__ buf) {
+    constexpr int E = N / 64;
+    constexpr int B = E == 16 ? 4 : 5;
+    constexpr int BITS = N == 1024 ? 10 : 11;
+    f32x2 x[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) x[i] = f32x2{smp[i] * win[i], 0.0f};
     // ---- phase 1: stages 1..B on bits 0..B-1 (register index), twiddles are table constants ----
 #pragma unroll
     for (int st = 1; st <= B; st++) {
@@ -123,36 +157,35 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
     // ---- phase 2: stages B+1..2B on bits B..2B-1 (register index m) ----
 #pragma unroll
     for (int st = B + 1; st <= 2 * B; st++) {
-        const int halfm = 1 << (st - B - 1), tstep = 2048 >> st;
+        const int halfm = 1 << (st - B - 1);
 #pragma unroll
         for (int m0 = 0; m0 < E; m0++) {
             if (m0 & halfm) continue;
             const int jj = ((m0 & (halfm - 1)) << B) | lo;
-            bfly(x[m0], x[m0 + halfm], *reinterpret_cast<const f32x2*>(tw[jj * tstep]));
+            const float2 t2 = stw[(1 << (st - 1)) - E + jj];
+            bfly(x[m0], x[m0 + halfm], f32x2{t2.x, t2.y});
         }
     }
-    // ---- transpose 2 (own slots back, then gather p = e*64 + lane) ----
+    // ---- transpose 2 (scatter by p, gather p = e*64 + lane): both sides touch runs of consecutive entries, so
+    // this one needs no padding (the padded image costs the gather a 2-way conflict between lanes 0 and 31) ----
 #pragma unroll
-    for (int m = 0; m < E; m++) {
-        const int pp = hi * E * E + m * E + lo;
-        buf[pp + (pp >> B)] = make_float2(x[m].x, x[m].y);
-    }
+    for (int m = 0; m < E; m++) buf[hi * E * E + m * E + lo] = make_float2(x[m].x, x[m].y);
     wave_lds_sync();
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int pp = e * 64 + lane;
-        const float2 v = buf[pp + (pp >> B)];
+        const float2 v = buf[e * 64 + lane];
         x[e] = f32x2{v.x, v.y};
     }
     // ---- phase 3: stages 2B+1..BITS on bits 2B.. (register index e, bit st-1-6) ----
 #pragma unroll
     for (int st = 2 * B + 1; st <= BITS; st++) {
-        const int halfe = 1 << (st - 1 - 6), tstep = 2048 >> st;
+        const int halfe = 1 << (st - 1 - 6);
 #pragma unroll
         for (int e0 = 0; e0 < E; e0++) {
             if (e0 & halfe) continue;
             const int jj = ((e0 & (halfe - 1)) << 6) | lane;
-            bfly(x[e0], x[e0 + halfe], *reinterpret_cast<const f32x2*>(tw[jj * tstep]));
+            const float2 t2 = stw[(1 << (st - 1)) - E + jj];
+            bfly(x[e0], x[e0 + halfe], f32x2{t2.x, t2.y});
         }
     }
     wave_lds_sync();
@@ -167,23 +200,24 @@ __device__ __forceinline__ void wave_fft_power(const float* __restrict__ src, in
 }
 
 template <int N, bool HAITSMA>
-__global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict__ x, size_t first_frame,
+__global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float* __restrict__ x, size_t first_frame,
                                                          size_t n_frames, int hop, float* __restrict__ out,
                                                          const uint32_t* __restrict__ edges,
                                                          float* __restrict__ rowmax_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     FftLds<N>& L = *reinterpret_cast<FftLds<N>*>(lds_raw);
-    for (int i = threadIdx.x; i < 1024; i += 256) {
-        L.tw[i][0] = c_tw[i][0];
-        L.tw[i][1] = c_tw[i][1];
-    }
+    fill_stage_twiddles<N>(L.stw, threadIdx.x, kFftWaves * 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float2* buf = L.buf[wave];
     const float* pw = reinterpret_cast<const float*>(buf);
+    float win[N / 64];   // a lane windows the same sample positions in every frame
+    frame_window<N>(lane, win);
     // frames are dealt to waves round-robin over the whole grid
-    for (size_t f = (size_t)blockIdx.x * 4 + wave; f < n_frames; f += (size_t)gridDim.x * 4) {
-        wave_fft_power<N>(x + (first_frame + f) * (size_t)hop, lane, L.tw, buf);
+    for (size_t f = (size_t)blockIdx.x * kFftWaves + wave; f < n_frames; f += (size_t)gridDim.x * kFftWaves) {
+        float smp[N / 64];
+        frame_load<N>(x + (first_frame + f) * (size_t)hop, lane, smp);
+        wave_fft_power_core<N>(smp, win, lane, L.stw, buf);
         {
             // lane b sums band b sequentially (same order as the oracle)
             if (lane < kHkBands) {
@@ -208,12 +242,12 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict
 // (t, k) order wins the tie; rows outside [0, total) duplicate rows inside the window, so they are simply
 // skipped).  HBM sees the samples once and the peaks -- not 2 x 4 B x 512 bins per frame of spilled spectrum.
 constexpr int kSeg = 256;    // frames per workgroup segment
-constexpr int kSW = 10;      // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
-constexpr int kRing = 26;    // >= 2 kRT + 1 + kSW frames in flight
+constexpr int kSW = 8;       // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
+constexpr int kRing = 24;    // >= 2 kRT + 1 + kSW frames in flight
 constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
 
 struct WangStreamLds {
-    float tw[1024][2];
+    float2 stw[kWangN - kWangN / 64];
     float2 buf[kSW][kWangN + 64];
     float ring[kRing][kWangBins];
     uint32_t pl_cnt[kRing];
@@ -227,12 +261,10 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                                                           uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     WangStreamLds& L = *reinterpret_cast<WangStreamLds*>(lds_raw);
-    for (int i = threadIdx.x; i < 1024; i += kSW * 64) {
-        L.tw[i][0] = c_tw[i][0];
-        L.tw[i][1] = c_tw[i][1];
-    }
+    fill_stage_twiddles<kWangN>(L.stw, threadIdx.x, kSW * 64);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // frame and ring arithmetic stays scalar
     float2* buf = L.buf[wave];
     const float* pw = reinterpret_cast<const float*>(buf);
     const long total = (long)total_frames;
@@ -240,17 +272,41 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
     const long s1 = s0 + kSeg < total ? s0 + kSeg : total;
     const long f_lo = s0 - kRT < 0 ? 0 : s0 - kRT;                 // frames [f_lo, f_hi) are computed
     const long f_hi = s1 + kRT < total ? s1 + kRT : total;
+    // the Hann window of this lane's 16 sample positions, and the NEXT frame's samples: loaded one round ahead, so
+    // the HBM/L2 latency hides behind the current FFT instead of stalling every wave at the top of a round
+    float win[kWangN / 64], nxt[kWangN / 64];
+    frame_window<kWangN>(lane, win);
+#pragma unroll
+    for (int i = 0; i < kWangN / 64; i++) nxt[i] = 0.0f;
+    if (f_lo + wave < f_hi) frame_load<kWangN>(x + (size_t)(f_lo + wave) * kWangHop, lane, nxt);
+    int slot = (int)((f_lo + wave) % kRing);                       // ring row of frame base + wave
+    // a found peak waits one round for its slot: the atomic's round trip overlaps the next FFT
+    bool pend = false;
+    uint32_t pend_pos = 0, pend_sec = 0, pend_t = 0, pend_k = 0;
+    float pend_v = 0.0f;
+    auto flush = [&]() {
+        if (pend && pend_pos < (uint32_t)kCandCap) {
+            cand_t[(size_t)pend_sec * kCandCap + pend_pos] = pend_t;
+            cand_k[(size_t)pend_sec * kCandCap + pend_pos] = pend_k;
+            cand_p[(size_t)pend_sec * kCandCap + pend_pos] = pend_v;
+        }
+        pend = false;
+    };
     for (long base = f_lo; base < f_hi + kRT; base += kSW) {
         // ---- produce frame base + wave ----
         const long f = base + wave;
         if (f < f_hi) {
-            wave_fft_power<kWangN>(x + (size_t)f * kWangHop, lane, L.tw, buf);
+            float smp[kWangN / 64];
+#pragma unroll
+            for (int i = 0; i < kWangN / 64; i++) smp[i] = nxt[i];
+            if (f + kSW < f_hi) frame_load<kWangN>(x + (size_t)(f + kSW) * kWangHop, lane, nxt);
+            wave_fft_power_core<kWangN>(smp, win, lane, L.stw, buf);
             // Row maximum over +-kRK bins and the same-row tie test, blocked: lane L owns bins 8L .. 8L+7.  The
             // window [k-15, k+15] of bin k = 8L + j is  suffix_{L-2}[j+1] u block_{L-1} u block_L u block_{L+1} u
             // prefix_{L+2}[j-1], and the 15 bins below k are  suffix_{L-2}[j+1] u block_{L-1} u prefix_L[j-1]:
             // 14 maxima per lane for the prefix / suffix tables, two LDS exchanges, instead of 31 taps per bin.
             // P >= 0, so -1 stands for "no bin there" (a clamped duplicate never changes a maximum either).
-            float* row = L.ring[f % kRing];
+            float* row = L.ring[slot];
             float* sx = reinterpret_cast<float*>(buf) + kWangBins;   // scratch behind the spectrum: [lane][8] suffix,
             float* px = sx + 64 * 9;                                 // [lane][8] prefix (row stride 9: conflict-free)
             float b8[8], pre[8], suf[8];
@@ -287,53 +343,63 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
             }
             *reinterpret_cast<float4*>(row + 8 * lane) = make_float4(rm[0], rm[1], rm[2], rm[3]);
             *reinterpret_cast<float4*>(row + 8 * lane + 4) = make_float4(rm[4], rm[5], rm[6], rm[7]);
-            uint32_t npl = 0;   // wave-uniform
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const bool c = (cbits >> j) & 1;
-                const uint64_t mask = __ballot(c);
-                if (mask) {
-                    const uint32_t pos = npl + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (c && pos < (uint32_t)kPl) {
-                        L.pl_k[f % kRing][pos] = (uint32_t)(8 * lane + j);
-                        L.pl_v[f % kRing][pos] = b8[j];
-                    }
-                    npl += (uint32_t)__popcll(mask);
+            // two row-local candidates are >= 16 bins apart, a lane owns 8 bins: at most ONE bit of cbits is set,
+            // and one ballot compacts the row (the list's order is irrelevant: wang_select ranks the peaks)
+            const bool c = cbits != 0;
+            const uint64_t mask = __ballot(c);
+            if (c) {
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const uint32_t kk = 8u * (uint32_t)lane + (uint32_t)(__ffs((int)cbits) - 1);
+                if (pos < (uint32_t)kPl) {
+                    L.pl_k[slot][pos] = kk;
+                    L.pl_v[slot][pos] = pw[kk];
                 }
             }
-            if (lane == 0) L.pl_cnt[f % kRing] = npl < (uint32_t)kPl ? npl : (uint32_t)kPl;
+            if (lane == 0) {
+                const uint32_t npl = (uint32_t)__popcll(mask);
+                L.pl_cnt[slot] = npl < (uint32_t)kPl ? npl : (uint32_t)kPl;
+            }
         }
         __syncthreads();
         // ---- judge frame base + wave - kRT: its whole window [t - kRT, t + kRT] is now in the ring ----
-        const long t = base + wave - kRT;
+        flush();
+        const long t = f - kRT;
         if (t >= s0 && t < s1) {
-            const uint32_t n = L.pl_cnt[t % kRing];
-            for (uint32_t e = lane; e < n; e += 64) {
-                const uint32_t k = L.pl_k[t % kRing][e];
-                const float v = L.pl_v[t % kRing][e];
+            int st = slot - kRT;
+            if (st < 0) st += kRing;
+            const uint32_t n = L.pl_cnt[st];
+            if ((uint32_t)lane < n) {
+                const uint32_t k = L.pl_k[st][lane];
+                const float v = L.pl_v[st][lane];
                 float m = v;
                 bool lose = false;
+                int rs = st - kRT;
+                if (rs < 0) rs += kRing;
 #pragma unroll
                 for (int d = -kRT; d <= kRT; d++) {
                     const long tt = t + d;
-                    if (tt < 0 || tt >= total) continue;   // duplicates of in-window rows
-                    const float r = L.ring[tt % kRing][k];
-                    m = fmaxf(m, r);
-                    lose |= d < 0 && r == v;
+                    if (tt >= 0 && tt < total) {               // rows outside duplicate in-window rows
+                        const float r = L.ring[rs][k];
+                        m = fmaxf(m, r);
+                        lose |= d < 0 && r == v;
+                    }
+                    rs = rs + 1 == kRing ? 0 : rs + 1;
                 }
-                if (lose || v != m) continue;
-                const uint32_t sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
-                const uint32_t pos = atomicAdd(&cand_cnt[sec], 1u);
-                if (pos < (uint32_t)kCandCap) {
-                    cand_t[(size_t)sec * kCandCap + pos] = (uint32_t)t;
-                    cand_k[(size_t)sec * kCandCap + pos] = k;
-                    cand_p[(size_t)sec * kCandCap + pos] = v;
+                if (!lose && v == m) {
+                    pend = true;
+                    pend_sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
+                    pend_t = (uint32_t)t;
+                    pend_k = k;
+                    pend_v = v;
+                    pend_pos = atomicAdd(&cand_cnt[pend_sec], 1u);
                 }
             }
         }
         __syncthreads();
+        slot = slot + kSW >= kRing ? slot + kSW - kRing : slot + kSW;
     }
+    flush();
 }
 
 // one wave per second: keep the `pps` strongest, ordered by (t, k)
@@ -653,9 +719,9 @@ int launch_haitsma(const float* pcm5k, size_t n, const uint32_t* h_edges, uint8_
         const size_t e1 = e0 + chunk < frames ? e0 + chunk : frames;
         const size_t w0 = e0 > 0 ? e0 - 1 : 0;  // one frame of history for the time difference
         const size_t wn = e1 - w0;
-        unsigned grid = blocks_for(wn, 4);
-        if (grid > 256 * 4) grid = 256 * 4;
-        hipLaunchKernelGGL((stft_power_kernel<kHkN, true>), dim3(grid), dim3(256), lds, stream, pcm5k, w0, wn, kHkHop,
+        unsigned grid = blocks_for(wn, kFftWaves);
+        if (grid > 256 * 2) grid = 256 * 2;
+        hipLaunchKernelGGL((stft_power_kernel<kHkN, true>), dim3(grid), dim3(kFftWaves * 64), lds, stream, pcm5k, w0, wn, kHkHop,
                            E, (const uint32_t*)d_edges, (float*)nullptr);
         hipLaunchKernelGGL(haitsma_bits_kernel, dim3(blocks_for(e1 - e0, 256)), dim3(256), 0, stream, E, e0, e1 - e0,
                            out);

@@ -26,7 +26,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         m = os.path.getmtime(SO)
         if all(os.path.getmtime(d) <= m for d in _deps()):
             return SO
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", SO]
+    extra = os.environ.get("UCFP_HIPCC_EXTRA", "").split()   # e.g. -D switches of a tuning experiment
+    cmd = [HIPCC] + FLAGS + extra + sources() + ["-o", SO]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

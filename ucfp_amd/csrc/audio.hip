@@ -123,7 +123,10 @@ __device__ __forceinline__ void frame_window(int lane, float (&w)[N / 64]) {
     }
 }
 
-template <int N>
+// SPLIT: the transposes move the real and the imaginary halves one after the other through a buffer of N + 64
+// FLOATS (4.25 KiB at N = 1024) instead of N + 64 float2 -- twice the LDS instructions for half the LDS, which is
+// what lets 16 frames be in flight per CU in wang_stream_kernel.
+template <int N, bool SPLIT = false>
 __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], const float (&win)[N / 64], int lane,
                                                     const float2* __restrict__ stw, float2* __restrict__ buf) {
     constexpr int E = N / 64;
@@ -144,15 +147,37 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
         }
     }
     // ---- transpose 1 ----
-#pragma unroll
-    for (int i = 0; i < E; i++) buf[(E + 1) * lane + i] = make_float2(x[i].x, x[i].y);   // p + p/E, p = E*lane + i
-    wave_lds_sync();
     const int lo = lane & (E - 1), hi = lane >> B;
+    float* fb = reinterpret_cast<float*>(buf);
+    if constexpr (SPLIT) {
+        float nr[E];
 #pragma unroll
-    for (int m = 0; m < E; m++) {
-        const int pp = hi * E * E + m * E + lo;
-        const float2 v = buf[pp + (pp >> B)];
-        x[m] = f32x2{v.x, v.y};
+        for (int i = 0; i < E; i++) fb[(E + 1) * lane + i] = x[i].x;
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const int pp = hi * E * E + m * E + lo;
+            nr[m] = fb[pp + (pp >> B)];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < E; i++) fb[(E + 1) * lane + i] = x[i].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const int pp = hi * E * E + m * E + lo;
+            x[m] = f32x2{nr[m], fb[pp + (pp >> B)]};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; i++) buf[(E + 1) * lane + i] = make_float2(x[i].x, x[i].y);   // p + p/E, p = E*lane + i
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const int pp = hi * E * E + m * E + lo;
+            const float2 v = buf[pp + (pp >> B)];
+            x[m] = f32x2{v.x, v.y};
+        }
     }
     // ---- phase 2: stages B+1..2B on bits B..2B-1 (register index m) ----
 #pragma unroll
@@ -168,13 +193,29 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
     }
     // ---- transpose 2 (scatter by p, gather p = e*64 + lane): both sides touch runs of consecutive entries, so
     // this one needs no padding (the padded image costs the gather a 2-way conflict between lanes 0 and 31) ----
+    wave_lds_fence();
+    if constexpr (SPLIT) {
+        float nr[E];
 #pragma unroll
-    for (int m = 0; m < E; m++) buf[hi * E * E + m * E + lo] = make_float2(x[m].x, x[m].y);
-    wave_lds_sync();
+        for (int m = 0; m < E; m++) fb[hi * E * E + m * E + lo] = x[m].x;
+        wave_lds_fence();
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const float2 v = buf[e * 64 + lane];
-        x[e] = f32x2{v.x, v.y};
+        for (int e = 0; e < E; e++) nr[e] = fb[e * 64 + lane];
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < E; m++) fb[hi * E * E + m * E + lo] = x[m].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < E; e++) x[e] = f32x2{nr[e], fb[e * 64 + lane]};
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; m++) buf[hi * E * E + m * E + lo] = make_float2(x[m].x, x[m].y);
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const float2 v = buf[e * 64 + lane];
+            x[e] = f32x2{v.x, v.y};
+        }
     }
     // ---- phase 3: stages 2B+1..BITS on bits 2B.. (register index e, bit st-1-6) ----
 #pragma unroll
@@ -188,7 +229,7 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
             bfly(x[e0], x[e0 + halfe], f32x2{t2.x, t2.y});
         }
     }
-    wave_lds_sync();
+    wave_lds_fence();
     // ---- power spectrum, bins k = e*64 + lane < N/2, into the (now free) buffer as float[N/2] ----
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
@@ -196,7 +237,7 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
         const f32x2 sq = x[e] * x[e];
         pw[e * 64 + lane] = sq.x + sq.y;
     }
-    wave_lds_sync();
+    wave_lds_fence();
 }
 
 template <int N, bool HAITSMA>
@@ -226,7 +267,7 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
                 out[f * (size_t)kHkBands + lane] = e;
             }
         }
-        wave_lds_sync();
+        wave_lds_fence();
     }
 }
 
@@ -242,13 +283,14 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
 // (t, k) order wins the tie; rows outside [0, total) duplicate rows inside the window, so they are simply
 // skipped).  HBM sees the samples once and the peaks -- not 2 x 4 B x 512 bins per frame of spilled spectrum.
 constexpr int kSeg = 256;    // frames per workgroup segment
-constexpr int kSW = 8;       // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
-constexpr int kRing = 24;    // >= 2 kRT + 1 + kSW frames in flight
+constexpr int kSW = 12;      // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
+constexpr int kRing = 28;    // >= 2 kRT + 1 + kSW frames in flight
 constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
 
 struct WangStreamLds {
     float2 stw[kWangN - kWangN / 64];
-    float2 buf[kSW][kWangN + 64];
+    float buf[kSW][kWangN + 64];
+    float win[kWangN / 64][64];   // Hann window at this lane's 16 sample positions (registers are for the FFT)
     float ring[kRing][kWangBins];
     uint32_t pl_cnt[kRing];
     uint32_t pl_k[kRing][kPl];
@@ -261,12 +303,18 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                                                           uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     WangStreamLds& L = *reinterpret_cast<WangStreamLds*>(lds_raw);
-    fill_stage_twiddles<kWangN>(L.stw, threadIdx.x, kSW * 64);
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // frame and ring arithmetic stays scalar
-    float2* buf = L.buf[wave];
-    const float* pw = reinterpret_cast<const float*>(buf);
+    fill_stage_twiddles<kWangN>(L.stw, threadIdx.x, kSW * 64);
+    if (wave == 0) {
+        float w0[kWangN / 64];
+        frame_window<kWangN>(lane, w0);
+#pragma unroll
+        for (int i = 0; i < kWangN / 64; i++) L.win[i][lane] = w0[i];
+    }
+    __syncthreads();
+    float2* buf = reinterpret_cast<float2*>(L.buf[wave]);
+    const float* pw = L.buf[wave];
     const long total = (long)total_frames;
     const long s0 = (long)blockIdx.x * kSeg;                       // frames [s0, s1) are this segment's to judge
     const long s1 = s0 + kSeg < total ? s0 + kSeg : total;
@@ -274,41 +322,51 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
     const long f_hi = s1 + kRT < total ? s1 + kRT : total;
     // the Hann window of this lane's 16 sample positions, and the NEXT frame's samples: loaded one round ahead, so
     // the HBM/L2 latency hides behind the current FFT instead of stalling every wave at the top of a round
-    float win[kWangN / 64], nxt[kWangN / 64];
-    frame_window<kWangN>(lane, win);
+    float nxt[kWangN / 64];
 #pragma unroll
     for (int i = 0; i < kWangN / 64; i++) nxt[i] = 0.0f;
     if (f_lo + wave < f_hi) frame_load<kWangN>(x + (size_t)(f_lo + wave) * kWangHop, lane, nxt);
+#pragma unroll
+    for (int i = 0; i < kWangN / 64; i++) asm volatile("" : "+v"(nxt[i]));   // taken in before the loop (see below)
     int slot = (int)((f_lo + wave) % kRing);                       // ring row of frame base + wave
     // a found peak waits one round for its slot: the atomic's round trip overlaps the next FFT
-    bool pend = false;
-    uint32_t pend_pos = 0, pend_sec = 0, pend_t = 0, pend_k = 0;
+    bool pend = false, pend_wave = false;      // pend_wave: wave-uniform "an atomic is in flight"
+    uint32_t pend_base = 0, pend_rank = 0, pend_sec = 0, pend_t = 0, pend_k = 0;
+    int pend_leader = 0;
     float pend_v = 0.0f;
     auto flush = [&]() {
-        if (pend && pend_pos < (uint32_t)kCandCap) {
-            cand_t[(size_t)pend_sec * kCandCap + pend_pos] = pend_t;
-            cand_k[(size_t)pend_sec * kCandCap + pend_pos] = pend_k;
-            cand_p[(size_t)pend_sec * kCandCap + pend_pos] = pend_v;
+        if (pend_wave) {
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pend_base, pend_leader);
+            const uint32_t pos = base + pend_rank;
+            if (pend && pos < (uint32_t)kCandCap) {
+                cand_t[(size_t)pend_sec * kCandCap + pos] = pend_t;
+                cand_k[(size_t)pend_sec * kCandCap + pos] = pend_k;
+                cand_p[(size_t)pend_sec * kCandCap + pos] = pend_v;
+            }
         }
         pend = false;
+        pend_wave = false;
     };
     for (long base = f_lo; base < f_hi + kRT; base += kSW) {
         // ---- produce frame base + wave ----
         const long f = base + wave;
         if (f < f_hi) {
-            float smp[kWangN / 64];
+            float smp[kWangN / 64], win[kWangN / 64];
 #pragma unroll
-            for (int i = 0; i < kWangN / 64; i++) smp[i] = nxt[i];
+            for (int i = 0; i < kWangN / 64; i++) {
+                smp[i] = nxt[i];
+                win[i] = L.win[i][lane];
+            }
             if (f + kSW < f_hi) frame_load<kWangN>(x + (size_t)(f + kSW) * kWangHop, lane, nxt);
-            wave_fft_power_core<kWangN>(smp, win, lane, L.stw, buf);
+            wave_fft_power_core<kWangN, true>(smp, win, lane, L.stw, buf);
             // Row maximum over +-kRK bins and the same-row tie test, blocked: lane L owns bins 8L .. 8L+7.  The
             // window [k-15, k+15] of bin k = 8L + j is  suffix_{L-2}[j+1] u block_{L-1} u block_L u block_{L+1} u
             // prefix_{L+2}[j-1], and the 15 bins below k are  suffix_{L-2}[j+1] u block_{L-1} u prefix_L[j-1]:
             // 14 maxima per lane for the prefix / suffix tables, two LDS exchanges, instead of 31 taps per bin.
             // P >= 0, so -1 stands for "no bin there" (a clamped duplicate never changes a maximum either).
             float* row = L.ring[slot];
-            float* sx = reinterpret_cast<float*>(buf) + kWangBins;   // scratch behind the spectrum: [lane][8] suffix,
-            float* px = sx + 64 * 9;                                 // [lane][8] prefix (row stride 9: conflict-free)
+            float* sx = L.buf[wave];      // scratch OVER the spectrum (b8 is read first; the LDS keeps a wave's order):
+            float* px = sx + 64 * 7;      // [lane][7] suffix 1..7, [lane][8] prefix (row strides 7 and 9: conflict-free)
             float b8[8], pre[8], suf[8];
             {
                 const float4 lo4 = *reinterpret_cast<const float4*>(pw + 8 * lane);
@@ -322,20 +380,33 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
             suf[7] = b8[7];
 #pragma unroll
             for (int j = 6; j >= 0; j--) suf[j] = fmaxf(suf[j + 1], b8[j]);
+            wave_lds_fence();
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                sx[9 * lane + j] = suf[j];
-                px[9 * lane + j] = pre[j];
+                if (j > 0) sx[7 * lane + j - 1] = suf[j];
+                if (j < 7) px[9 * lane + j] = pre[j];
             }
-            wave_lds_sync();
-            const float blk_m1 = lane >= 1 ? px[9 * (lane - 1) + 7] : -1.0f;    // block maxima of the neighbours
-            const float blk_p1 = lane <= 62 ? px[9 * (lane + 1) + 7] : -1.0f;
+            px[9 * lane + 7] = pre[7];
+            wave_lds_fence();
+            // every neighbour read is unconditional at a clamped lane (one burst of 16 LDS reads, one wait) and the
+            // out-of-range ones are replaced afterwards: a read under a lane condition becomes a branch of its own
+            const int lm1 = lane >= 1 ? lane - 1 : 0, lp1 = lane <= 62 ? lane + 1 : 63;
+            const int lm2 = lane >= 2 ? lane - 2 : 0, lp2 = lane <= 61 ? lane + 2 : 63;
+            float nb_m1 = px[9 * lm1 + 7], nb_p1 = px[9 * lp1 + 7];     // block maxima of the neighbours
+            float s2v[7], p2v[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                s2v[j] = sx[7 * lm2 + j];          // suffix_{L-2}[j+1]
+                p2v[j] = px[9 * lp2 + j];          // prefix_{L+2}[j]
+            }
+            const float blk_m1 = lane >= 1 ? nb_m1 : -1.0f;
+            const float blk_p1 = lane <= 62 ? nb_p1 : -1.0f;
             float rm[8];
             uint32_t cbits = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float s2 = (lane >= 2 && j < 7) ? sx[9 * (lane - 2) + j + 1] : -1.0f;   // suffix_{L-2}[j+1]
-                const float p2 = (lane <= 61 && j > 0) ? px[9 * (lane + 2) + j - 1] : -1.0f;  // prefix_{L+2}[j-1]
+                const float s2 = (lane >= 2 && j < 7) ? s2v[j < 7 ? j : 0] : -1.0f;       // suffix_{L-2}[j+1]
+                const float p2 = (lane <= 61 && j > 0) ? p2v[j > 0 ? j - 1 : 0] : -1.0f;  // prefix_{L+2}[j-1]
                 const float below = fmaxf(fmaxf(s2, blk_m1), j > 0 ? pre[j - 1] : -1.0f);
                 const float m = fmaxf(fmaxf(below, pre[7]), fmaxf(blk_p1, p2));
                 rm[j] = m;
@@ -353,7 +424,7 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                 const uint32_t kk = 8u * (uint32_t)lane + (uint32_t)(__ffs((int)cbits) - 1);
                 if (pos < (uint32_t)kPl) {
                     L.pl_k[slot][pos] = kk;
-                    L.pl_v[slot][pos] = pw[kk];
+                    L.pl_v[slot][pos] = row[kk];   // a candidate equals its row maximum, just stored
                 }
             }
             if (lane == 0) {
@@ -364,11 +435,18 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
         __syncthreads();
         // ---- judge frame base + wave - kRT: its whole window [t - kRT, t + kRT] is now in the ring ----
         flush();
+        // The prefetched samples are taken in HERE (they landed during the FFT): returns come back in order, so a
+        // wait for them placed after the judge's atomic would wait for the atomic as well.
+#pragma unroll
+        for (int i = 0; i < kWangN / 64; i++) asm volatile("" : "+v"(nxt[i]));
         const long t = f - kRT;
         if (t >= s0 && t < s1) {
             int st = slot - kRT;
             if (st < 0) st += kRing;
             const uint32_t n = L.pl_cnt[st];
+            bool is_peak = false;
+            uint32_t pk = 0;
+            float pv = 0.0f;
             if ((uint32_t)lane < n) {
                 const uint32_t k = L.pl_k[st][lane];
                 const float v = L.pl_v[st][lane];
@@ -376,23 +454,44 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                 bool lose = false;
                 int rs = st - kRT;
                 if (rs < 0) rs += kRing;
+                float rr[2 * kRT + 1];
+#pragma unroll
+                for (int d = -kRT; d <= kRT; d++) {               // 15 reads in one burst, then the scalar row tests
+                    rr[d + kRT] = L.ring[rs][k];
+                    rs = rs + 1 == kRing ? 0 : rs + 1;
+                }
 #pragma unroll
                 for (int d = -kRT; d <= kRT; d++) {
                     const long tt = t + d;
-                    if (tt >= 0 && tt < total) {               // rows outside duplicate in-window rows
-                        const float r = L.ring[rs][k];
-                        m = fmaxf(m, r);
-                        lose |= d < 0 && r == v;
-                    }
-                    rs = rs + 1 == kRing ? 0 : rs + 1;
+                    const float r = (tt >= 0 && tt < total) ? rr[d + kRT] : -1.0f;   // rows outside duplicate rows inside
+                    m = fmaxf(m, r);
+                    lose |= d < 0 && r == v;
                 }
-                if (!lose && v == m) {
-                    pend = true;
-                    pend_sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
-                    pend_t = (uint32_t)t;
-                    pend_k = k;
-                    pend_v = v;
-                    pend_pos = atomicAdd(&cand_cnt[pend_sec], 1u);
+                is_peak = !lose && v == m;
+                pk = k;
+                pv = v;
+            }
+            // one counter bump per wave (all its peaks share the frame, hence the second); the returned base is
+            // consumed a round later by flush(), so the L2 round trip overlaps the next FFT.  The address is hidden
+            // from the compiler: for a uniform address it aggregates by itself and reads the result back at once
+            // (s_waitcnt vmcnt(0) + v_readfirstlane right behind the atomic), which parks every wave for the trip.
+            const uint64_t pm = __ballot(is_peak);
+            if (pm) {
+                const uint32_t sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
+                pend = is_peak;
+                pend_sec = sec;
+                pend_t = (uint32_t)t;
+                pend_k = pk;
+                pend_v = pv;
+                pend_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                pend_leader = __builtin_ctzll(pm);
+                pend_wave = true;
+                if (lane == pend_leader) {
+                    const uint32_t cnt = (uint32_t)__popcll(pm);
+                    typedef __attribute__((address_space(1))) uint32_t* global_u32;
+                    global_u32 addr = (global_u32)(cand_cnt + sec);
+                    asm volatile("" : "+v"(addr));
+                    pend_base = __hip_atomic_fetch_add(addr, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }

@@ -15,6 +15,13 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Same-wave LDS hand-off without the drain: the LDS executes one wave's instructions in order, so a ds_read issued
+// after a ds_write of the same wave sees the data; only the compiler has to keep the order.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // image.hip
 int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w, uint32_t h,
                       size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim,

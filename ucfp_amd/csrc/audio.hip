@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
 // skipped).  HBM sees the samples once and the peaks -- not 2 x 4 B x 512 bins per frame of spilled spectrum.
 constexpr int kSeg = 256;    // frames per workgroup segment
 constexpr int kSW = 12;      // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
-constexpr int kRing = 28;    // >= 2 kRT + 1 + kSW frames in flight
+constexpr int kRing = 38;    // >= 2 kRT + 2 kSW: the rows being judged (one round behind) + the rows being produced
 constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
 
 struct WangStreamLds {
@@ -347,9 +347,72 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
         pend = false;
         pend_wave = false;
     };
-    for (long base = f_lo; base < f_hi + kRT; base += kSW) {
-        // ---- produce frame base + wave ----
+    for (long base = f_lo; base < s1 + kRT + kSW; base += kSW) {
         const long f = base + wave;
+        // ---- judge frame base + wave - kSW - kRT: its window [t - kRT, t + kRT] was complete at the last barrier, so
+        // this overlaps the other waves' FFTs instead of standing between two barriers of its own ----
+        flush();
+        // The prefetched samples are taken in HERE (they landed during the last FFT): returns come back in order, so
+        // a wait for them placed after the judge's atomic would wait for the atomic as well.
+#pragma unroll
+        for (int i = 0; i < kWangN / 64; i++) asm volatile("" : "+v"(nxt[i]));
+        const long t = f - kSW - kRT;
+        if (t >= s0 && t < s1) {
+            int st = slot - kSW - kRT;
+            if (st < 0) st += kRing;
+            const uint32_t n = L.pl_cnt[st];
+            bool is_peak = false;
+            uint32_t pk = 0;
+            float pv = 0.0f;
+            if ((uint32_t)lane < n) {
+                const uint32_t k = L.pl_k[st][lane];
+                const float v = L.pl_v[st][lane];
+                float m = v;
+                bool lose = false;
+                int rs = st - kRT;
+                if (rs < 0) rs += kRing;
+                float rr[2 * kRT + 1];
+#pragma unroll
+                for (int d = -kRT; d <= kRT; d++) {               // 15 reads in one burst, then the scalar row tests
+                    rr[d + kRT] = L.ring[rs][k];
+                    rs = rs + 1 == kRing ? 0 : rs + 1;
+                }
+#pragma unroll
+                for (int d = -kRT; d <= kRT; d++) {
+                    const long tt = t + d;
+                    const float r = (tt >= 0 && tt < total) ? rr[d + kRT] : -1.0f;   // rows outside duplicate rows inside
+                    m = fmaxf(m, r);
+                    lose |= d < 0 && r == v;
+                }
+                is_peak = !lose && v == m;
+                pk = k;
+                pv = v;
+            }
+            // one counter bump per wave (all its peaks share the frame, hence the second); the returned base is
+            // consumed a round later by flush(), so the L2 round trip overlaps the next FFT.  The address is hidden
+            // from the compiler: for a uniform address it aggregates by itself and reads the result back at once
+            // (s_waitcnt vmcnt(0) + v_readfirstlane right behind the atomic), which parks every wave for the trip.
+            const uint64_t pm = __ballot(is_peak);
+            if (pm) {
+                const uint32_t sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
+                pend = is_peak;
+                pend_sec = sec;
+                pend_t = (uint32_t)t;
+                pend_k = pk;
+                pend_v = pv;
+                pend_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                pend_leader = __builtin_ctzll(pm);
+                pend_wave = true;
+                if (lane == pend_leader) {
+                    const uint32_t cnt = (uint32_t)__popcll(pm);
+                    typedef __attribute__((address_space(1))) uint32_t* global_u32;
+                    global_u32 addr = (global_u32)(cand_cnt + sec);
+                    asm volatile("" : "+v"(addr));
+                    pend_base = __hip_atomic_fetch_add(addr, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // ---- produce frame base + wave ----
         if (f < f_hi) {
             float smp[kWangN / 64], win[kWangN / 64];
 #pragma unroll
@@ -432,70 +495,7 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                 L.pl_cnt[slot] = npl < (uint32_t)kPl ? npl : (uint32_t)kPl;
             }
         }
-        __syncthreads();
-        // ---- judge frame base + wave - kRT: its whole window [t - kRT, t + kRT] is now in the ring ----
-        flush();
-        // The prefetched samples are taken in HERE (they landed during the FFT): returns come back in order, so a
-        // wait for them placed after the judge's atomic would wait for the atomic as well.
-#pragma unroll
-        for (int i = 0; i < kWangN / 64; i++) asm volatile("" : "+v"(nxt[i]));
-        const long t = f - kRT;
-        if (t >= s0 && t < s1) {
-            int st = slot - kRT;
-            if (st < 0) st += kRing;
-            const uint32_t n = L.pl_cnt[st];
-            bool is_peak = false;
-            uint32_t pk = 0;
-            float pv = 0.0f;
-            if ((uint32_t)lane < n) {
-                const uint32_t k = L.pl_k[st][lane];
-                const float v = L.pl_v[st][lane];
-                float m = v;
-                bool lose = false;
-                int rs = st - kRT;
-                if (rs < 0) rs += kRing;
-                float rr[2 * kRT + 1];
-#pragma unroll
-                for (int d = -kRT; d <= kRT; d++) {               // 15 reads in one burst, then the scalar row tests
-                    rr[d + kRT] = L.ring[rs][k];
-                    rs = rs + 1 == kRing ? 0 : rs + 1;
-                }
-#pragma unroll
-                for (int d = -kRT; d <= kRT; d++) {
-                    const long tt = t + d;
-                    const float r = (tt >= 0 && tt < total) ? rr[d + kRT] : -1.0f;   // rows outside duplicate rows inside
-                    m = fmaxf(m, r);
-                    lose |= d < 0 && r == v;
-                }
-                is_peak = !lose && v == m;
-                pk = k;
-                pv = v;
-            }
-            // one counter bump per wave (all its peaks share the frame, hence the second); the returned base is
-            // consumed a round later by flush(), so the L2 round trip overlaps the next FFT.  The address is hidden
-            // from the compiler: for a uniform address it aggregates by itself and reads the result back at once
-            // (s_waitcnt vmcnt(0) + v_readfirstlane right behind the atomic), which parks every wave for the trip.
-            const uint64_t pm = __ballot(is_peak);
-            if (pm) {
-                const uint32_t sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
-                pend = is_peak;
-                pend_sec = sec;
-                pend_t = (uint32_t)t;
-                pend_k = pk;
-                pend_v = pv;
-                pend_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                pend_leader = __builtin_ctzll(pm);
-                pend_wave = true;
-                if (lane == pend_leader) {
-                    const uint32_t cnt = (uint32_t)__popcll(pm);
-                    typedef __attribute__((address_space(1))) uint32_t* global_u32;
-                    global_u32 addr = (global_u32)(cand_cnt + sec);
-                    asm volatile("" : "+v"(addr));
-                    pend_base = __hip_atomic_fetch_add(addr, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        __syncthreads();
+        __syncthreads();   // the only one per round: rows base .. base + kSW - 1 are complete
         slot = slot + kSW >= kRing ? slot + kSW - kRing : slot + kSW;
     }
     flush();

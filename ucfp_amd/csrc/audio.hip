@@ -360,34 +360,42 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
         if (t >= s0 && t < s1) {
             int st = slot - kSW - kRT;
             if (st < 0) st += kRing;
+            // The whole wave pays for every instruction here, so the test is kept short: v is the row maximum of its
+            // own row at k, hence "v equals the window maximum and no earlier row reaches it" is
+            //   max(7 earlier rows at k) < v  and  max(7 later rows at k) <= v.
+            // All reads are unconditional (lanes past the list read a stale entry and are masked at the end).
             const uint32_t n = L.pl_cnt[st];
-            bool is_peak = false;
-            uint32_t pk = 0;
-            float pv = 0.0f;
-            if ((uint32_t)lane < n) {
-                const uint32_t k = L.pl_k[st][lane];
-                const float v = L.pl_v[st][lane];
-                float m = v;
-                bool lose = false;
-                int rs = st - kRT;
-                if (rs < 0) rs += kRing;
-                float rr[2 * kRT + 1];
+            const uint32_t pk = L.pl_k[st][lane & (kPl - 1)] & (uint32_t)(kWangBins - 1);
+            const float pv = L.pl_v[st][lane & (kPl - 1)];
+            int rs = st - kRT;
+            if (rs < 0) rs += kRing;
+            float rr[2 * kRT + 1];
+            const float* cell = &L.ring[0][pk];
+            if (rs + 2 * kRT < kRing) {                    // the window does not wrap: one address, 15 offsets
+                const float* c0 = cell + rs * kWangBins;
 #pragma unroll
-                for (int d = -kRT; d <= kRT; d++) {               // 15 reads in one burst, then the scalar row tests
-                    rr[d + kRT] = L.ring[rs][k];
-                    rs = rs + 1 == kRing ? 0 : rs + 1;
-                }
+                for (int d = 0; d <= 2 * kRT; d++) rr[d] = c0[d * kWangBins];
+            } else {
 #pragma unroll
-                for (int d = -kRT; d <= kRT; d++) {
-                    const long tt = t + d;
-                    const float r = (tt >= 0 && tt < total) ? rr[d + kRT] : -1.0f;   // rows outside duplicate rows inside
-                    m = fmaxf(m, r);
-                    lose |= d < 0 && r == v;
+                for (int d = 0; d <= 2 * kRT; d++) {
+                    const int r = rs + d >= kRing ? rs + d - kRing : rs + d;
+                    rr[d] = cell[r * kWangBins];
                 }
-                is_peak = !lose && v == m;
-                pk = k;
-                pv = v;
             }
+            if (t < kRT || t + kRT >= total) {             // rows outside [0, total) duplicate rows inside: drop them
+#pragma unroll
+                for (int d = 0; d <= 2 * kRT; d++) {
+                    const long tt = t + d - kRT;
+                    if (tt < 0 || tt >= total) rr[d] = -1.0f;
+                }
+            }
+            float mb = rr[0], ma = rr[kRT + 1];
+#pragma unroll
+            for (int d = 1; d < kRT; d++) {
+                mb = fmaxf(mb, rr[d]);
+                ma = fmaxf(ma, rr[kRT + 1 + d]);
+            }
+            const bool is_peak = (uint32_t)lane < n && mb < pv && ma <= pv;
             // one counter bump per wave (all its peaks share the frame, hence the second); the returned base is
             // consumed a round later by flush(), so the L2 round trip overlaps the next FFT.  The address is hidden
             // from the compiler: for a uniform address it aggregates by itself and reads the result back at once

@@ -46,6 +46,35 @@ def test_wang_matches_oracle(gpu_ctx, oracle, kind, seconds):
         assert (np.diff(g[:, 1].astype(np.int64)) >= 0).all()   # anchors in time order
 
 
+@pytest.mark.parametrize("frames", [1, 7, 8, 12, 13, 24, 25, 255, 256, 257, 263, 264, 275, 531])
+def test_wang_frame_counts_around_segment_and_round_edges(gpu_ctx, oracle, frames):
+    """The streaming kernel walks segments of 256 frames in rounds of 12 with a +-7-frame halo and judges a frame
+    one round after its window completes: every count near those edges must still give the oracle's landmarks."""
+    from ucfp_amd import audio
+    x = _signal("noise", (1024 + 128 * (frames - 1) + 5) / 8000.0, 8000, seed=frames)
+    assert 1 + (x.size - 1024) // 128 == frames
+    g = audio.wang_hashes(x, 8000, ctx=gpu_ctx)
+    o = oracle.wang(x)
+    assert g.shape == o.shape and np.array_equal(g, o)
+
+
+@pytest.mark.parametrize("frames", [90, 300])
+def test_wang_ties_across_rows(gpu_ctx, oracle, frames):
+    """A signal with the hop as its period under a staircase envelope (runs of 20 hops, levels apart by powers of
+    two) gives runs of frames with bit-identical spectra: cells tie with their time neighbours, so which of them is
+    the peak is decided by the earliest-cell-wins rule."""
+    from ucfp_amd import audio
+    rng = np.random.default_rng(7)
+    n = 1024 + 128 * (frames - 1)
+    x = np.tile((0.3 * rng.standard_normal(128)).astype(np.float32), frames + 8)[:n]
+    env = np.repeat(np.array([1.0, 0.5, 1.0, 1.0, 0.25, 1.0, 0.5], np.float32), 128 * 20)
+    x = (x * np.tile(env, 1 + n // env.size)[:n]).astype(np.float32)
+    g = audio.wang_hashes(x, 8000, ctx=gpu_ctx)
+    o = oracle.wang(x)
+    assert o.shape[0] > 40
+    assert g.shape == o.shape and np.array_equal(g, o)
+
+
 def test_wang_config_variants(gpu_ctx, oracle):
     from ucfp_amd import audio
     x = _signal("chirps", 8.0, 8000, seed=3)

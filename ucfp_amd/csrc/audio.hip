@@ -96,6 +96,20 @@ __device__ __forceinline__ void bfly(f32x2& u, f32x2& x, f32x2 tw) {   // tw = (
 
 // element i of lane L is p = E*L + i = bit-reversed sample index n = (rev(i) << 6) | rev(L); the sample
 // positions of a lane are the same for every frame, so a caller may keep the window in registers
+// first-stage forms for real input (see wave_fft_power_core)
+__device__ __forceinline__ void bfly_real(f32x2& u, f32x2& x) {          // twiddle (1, -0), imaginary parts zero
+    const float a = u.x, b = x.x;
+    u.x = a + b;
+    x.x = a - b;
+}
+__device__ __forceinline__ void bfly_real_in(f32x2& u, f32x2& x, f32x2 tw) {   // imaginary INPUTS zero
+    f32x2 m;                                                                  // (xr c, xr s)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m) : "v"(x), "v"(tw));
+    const f32x2 w = u;
+    u = w + m;
+    x = w - m;
+}
+
 template <int N>
 __device__ __forceinline__ void frame_load(const float* __restrict__ src, int lane, float (&s)[N / 64]) {
     constexpr int E = N / 64;
@@ -136,8 +150,20 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
 #pragma unroll
     for (int i = 0; i < E; i++) x[i] = f32x2{smp[i] * win[i], 0.0f};
     // ---- phase 1: stages 1..B on bits 0..B-1 (register index), twiddles are table constants ----
+    // The input is real, so the first two stages are cheaper than general butterflies without changing a bit of
+    // the power spectrum: with twiddle (1, -0) and zero imaginary parts a butterfly is one add and one subtract of
+    // the real parts (x*1 and 0*s are exact, the imaginary outputs stay zero); with zero imaginary INPUTS and any
+    // twiddle, v = (xr c - 0 s, xr s + 0 c) = (xr c, xr s) exactly.  (Only the sign of exact zeros can differ from
+    // the five-instruction form, and (+-0)^2 is +0.)
 #pragma unroll
-    for (int st = 1; st <= B; st++) {
+    for (int i0 = 0; i0 < E; i0 += 2) bfly_real(x[i0], x[i0 + 1]);
+#pragma unroll
+    for (int i0 = 0; i0 < E; i0 += 4) {
+        bfly_real(x[i0], x[i0 + 2]);
+        bfly_real_in(x[i0 + 1], x[i0 + 3], f32x2{c_tw[512][0], c_tw[512][1]});
+    }
+#pragma unroll
+    for (int st = 3; st <= B; st++) {
         const int half = 1 << (st - 1), tstep = 2048 >> st;
 #pragma unroll
         for (int i0 = 0; i0 < E; i0++) {

@@ -96,6 +96,24 @@ __device__ __forceinline__ void bfly(f32x2& u, f32x2& x, f32x2 tw) {   // tw = (
 
 // element i of lane L is p = E*L + i = bit-reversed sample index n = (rev(i) << 6) | rev(L); the sample
 // positions of a lane are the same for every frame, so a caller may keep the window in registers
+// gfx950 half / row exchange between two registers (see transpose 2 in wave_fft_power_core)
+template <int W>
+__device__ __forceinline__ void swap_lanes(f32x2& a, f32x2& b) {   // both components
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint32_t ua = __float_as_uint(a[c]), ub = __float_as_uint(b[c]);
+        if constexpr (W == 32) {
+            const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+            a[c] = __uint_as_float(r[0]);
+            b[c] = __uint_as_float(r[1]);
+        } else {
+            const auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);
+            a[c] = __uint_as_float(r[0]);
+            b[c] = __uint_as_float(r[1]);
+        }
+    }
+}
+
 // first-stage forms for real input (see wave_fft_power_core)
 __device__ __forceinline__ void bfly_real(f32x2& u, f32x2& x) {          // twiddle (1, -0), imaginary parts zero
     const float a = u.x, b = x.x;
@@ -217,23 +235,29 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
             bfly(x[m0], x[m0 + halfm], f32x2{t2.x, t2.y});
         }
     }
-    // ---- transpose 2 (scatter by p, gather p = e*64 + lane): both sides touch runs of consecutive entries, so
-    // this one needs no padding (the padded image costs the gather a 2-way conflict between lanes 0 and 31) ----
-    wave_lds_fence();
-    if constexpr (SPLIT) {
-        float nr[E];
+    // ---- transpose 2: p = hi*E*E + m*E + lo  ->  p = e*64 + lane.  For E = 16 this only exchanges the two lane-row
+    // bits (hi) with the two low bits of the register index: two rounds of gfx950's row/half swaps, no LDS at all.
+    // v_permlane32_swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B, i.e. (register bit, lane bit 5) transposed;
+    // v_permlane16_swap: odd rows of A <-> even rows of B, i.e. (register bit, lane bit 4).  Afterwards register
+    // r = (m_hi, hi) holds e = (hi, m_hi) of this lane: a renaming. ----
+    if constexpr (E == 16) {
 #pragma unroll
-        for (int m = 0; m < E; m++) fb[hi * E * E + m * E + lo] = x[m].x;
-        wave_lds_fence();
+        for (int r = 0; r < E; r++) {
+            if (r & 2) continue;
+            swap_lanes<32>(x[r], x[r + 2]);
+        }
 #pragma unroll
-        for (int e = 0; e < E; e++) nr[e] = fb[e * 64 + lane];
-        wave_lds_fence();
+        for (int r = 0; r < E; r++) {
+            if (r & 1) continue;
+            swap_lanes<16>(x[r], x[r + 1]);
+        }
+        f32x2 y[E];
 #pragma unroll
-        for (int m = 0; m < E; m++) fb[hi * E * E + m * E + lo] = x[m].y;
-        wave_lds_fence();
+        for (int r = 0; r < E; r++) y[((r & 3) << 2) | (r >> 2)] = x[r];
 #pragma unroll
-        for (int e = 0; e < E; e++) x[e] = f32x2{nr[e], fb[e * 64 + lane]};
+        for (int e = 0; e < E; e++) x[e] = y[e];
     } else {
+        wave_lds_fence();
 #pragma unroll
         for (int m = 0; m < E; m++) buf[hi * E * E + m * E + lo] = make_float2(x[m].x, x[m].y);
         wave_lds_fence();

@@ -236,7 +236,8 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
         }
     }
     // ---- transpose 2: p = hi*E*E + m*E + lo  ->  p = e*64 + lane.  For E = 16 this only exchanges the two lane-row
-    // bits (hi) with the two low bits of the register index: two rounds of gfx950's row/half swaps, no LDS at all.
+    // bits (hi) with the two low bits of the register index: two rounds of gfx950's row/half swaps, no LDS at all
+    // (E = 32: one lane bit and one register bit, one round).
     // v_permlane32_swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B, i.e. (register bit, lane bit 5) transposed;
     // v_permlane16_swap: odd rows of A <-> even rows of B, i.e. (register bit, lane bit 4).  Afterwards register
     // r = (m_hi, hi) holds e = (hi, m_hi) of this lane: a renaming. ----
@@ -257,15 +258,14 @@ __device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], 
 #pragma unroll
         for (int e = 0; e < E; e++) x[e] = y[e];
     } else {
-        wave_lds_fence();
+        // E = 32: hi is lane bit 5 alone and trades places with register bit 0; e = (hi, m >> 1)
 #pragma unroll
-        for (int m = 0; m < E; m++) buf[hi * E * E + m * E + lo] = make_float2(x[m].x, x[m].y);
-        wave_lds_fence();
+        for (int r = 0; r < E; r += 2) swap_lanes<32>(x[r], x[r + 1]);
+        f32x2 y[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const float2 v = buf[e * 64 + lane];
-            x[e] = f32x2{v.x, v.y};
-        }
+        for (int r = 0; r < E; r++) y[((r & 1) << 4) | (r >> 1)] = x[r];
+#pragma unroll
+        for (int e = 0; e < E; e++) x[e] = y[e];
     }
     // ---- phase 3: stages 2B+1..BITS on bits 2B.. (register index e, bit st-1-6) ----
 #pragma unroll

@@ -304,18 +304,31 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
     const float* pw = reinterpret_cast<const float*>(buf);
     float win[N / 64];   // a lane windows the same sample positions in every frame
     frame_window<N>(lane, win);
-    // frames are dealt to waves round-robin over the whole grid
-    for (size_t f = (size_t)blockIdx.x * kFftWaves + wave; f < n_frames; f += (size_t)gridDim.x * kFftWaves) {
+    // frames are dealt to waves round-robin over the whole grid; the next frame's samples are loaded a frame ahead
+    const uint32_t k0 = lane < kHkBands ? edges[lane] : 0u, k1 = lane < kHkBands ? edges[lane + 1] : 0u;
+    const size_t step = (size_t)gridDim.x * kFftWaves;
+    size_t f = (size_t)blockIdx.x * kFftWaves + wave;
+    float nxt[N / 64];
+    if (f < n_frames) frame_load<N>(x + (first_frame + f) * (size_t)hop, lane, nxt);
+    for (; f < n_frames; f += step) {
         float smp[N / 64];
-        frame_load<N>(x + (first_frame + f) * (size_t)hop, lane, smp);
+#pragma unroll
+        for (int i = 0; i < N / 64; i++) smp[i] = nxt[i];
+        if (f + step < n_frames) frame_load<N>(x + (first_frame + f + step) * (size_t)hop, lane, nxt);
         wave_fft_power_core<N>(smp, win, lane, L.stw, buf);
         {
-            // lane b sums band b sequentially (same order as the oracle)
-            if (lane < kHkBands) {
-                float e = 0.0f;
-                for (uint32_t k = edges[lane]; k < edges[lane + 1]; k++) e = e + pw[k];
-                out[f * (size_t)kHkBands + lane] = e;
+            // lane b sums band b sequentially (same order as the oracle); eight spectrum reads are in flight at a time
+            float e = 0.0f;
+            uint32_t k = k0;
+            for (; k + 8 <= k1; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = pw[k + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) e = e + v[j];
             }
+            for (; k < k1; k++) e = e + pw[k];
+            if (lane < kHkBands) out[f * (size_t)kHkBands + lane] = e;
         }
         wave_lds_fence();
     }

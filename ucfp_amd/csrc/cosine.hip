@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nn = lane & 15, q4 = lane >> 4;
     const uint32_t nks = dim / kGK;
+    const int rd[2] = {q4 * 16 + (nn ^ (q4 & 7)), q4 * 16 + (nn ^ ((4 + q4) & 7))};   // this lane's operand slot per chunk
     // staging: float4 number f of a slice = (query f / 8, dims 4 (f % 8) .. +4); a thread moves NG * 128 / 512 of them
     constexpr int kSt = NG * 16 * 8 / (kGW * 64);
     static_assert(kSt >= 1, "slice smaller than the workgroup");
@@ -295,7 +296,10 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
         for (int i = 0; i < kSt; i++) {
             const uint32_t f = threadIdx.x + i * kGW * 64, q = f >> 3, c4 = f & 7;
-            qsl[buf][q >> 4][c4 >> 2][(c4 & 3) * 16 + (q & 15)] = st[i];   // lane (nn = q % 16, q4 = c4 % 4)
+            // lane (nn = q % 16, q4 = c4 % 4) of chunk c4 / 4, swizzled by the chunk column: the 8 lanes that hold
+            // one query's 128 bytes would otherwise write 256 B apart (one bank group, 8-way: 58 % of this
+            // kernel's LDS cycles were conflicts); the readers' 16-lane groups stay conflict-free under the XOR
+            qsl[buf][q >> 4][c4 >> 2][(c4 & 3) * 16 + ((q & 15) ^ (c4 & 7))] = st[i];
         }
     };
     const size_t tiles = (n + 15) / 16;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
                 for (int g0 = 0; g0 < NG; g0 += 4) {
                     float4 qa[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) qa[i] = qsl[buf][g0 + i][ch][lane];
+                    for (int i = 0; i < 4; i++) qa[i] = qsl[buf][g0 + i][ch][rd[ch]];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int g = g0 + i;

@@ -16,7 +16,9 @@ ALGO_BYTES_PER_FRAME = 512 * 512 + 536
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
+    # rocprofv3 names its files by PID and gpurun merges every call's files into the same local directory:
+    # the newest one is this round's, not the lexicographically last
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     if not hits:
         sys.exit(f"missing: {pattern}")
     return hits[-1]

@@ -244,13 +244,13 @@ def test_strided_and_unaligned_frames_dev(gpu_ctx, oracle, torch_cuda):
 
 
 def test_large_generic_batch_crosses_workspace_chunks(gpu_ctx, oracle):
-    """More frames than the 256-plane normalise workspace holds (generic path chunks the batch)."""
+    """More frames than the 2048-plane normalise workspace holds (generic path chunks the batch)."""
     rng = np.random.default_rng(22)
-    fr = _frames(rng, 300, 96, 80)
+    fr = _frames(rng, 2100, 96, 80)
     gpu, st = _gpu_host(fr, 7)
     ref, _ = oracle.image_hash_batch(fr, 7)
     assert not st.any()
-    _assert_same(gpu, ref, "generic 300 frames")
+    _assert_same(gpu, ref, "generic 2100 frames")
 
 
 def test_encoded_image_adapters(gpu_ctx, oracle):

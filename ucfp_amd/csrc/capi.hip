@@ -39,7 +39,8 @@ namespace {
             return fail(UCFP_E_INDEX, "%s failed: %s", #expr, hipGetErrorString(e_));      \
     } while (0)
 
-constexpr size_t kNormWsFrames = 256;  // generic-geometry normalised planes held at once (16 MiB)
+constexpr size_t kNormWsFrames = 2048;  // generic-geometry normalised planes held at once (128 MiB: inside the 256 MB
+                                       // Infinity Cache, and enough frames per launch to fill the chip with small frames)
 
 }  // namespace
 

@@ -269,6 +269,17 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
 constexpr int kGW = 8;      // waves per workgroup
 constexpr int kGK = 32;     // dims per K slice
 
+// hand-issued LDS operand read and its counted wait (see cosine_keys_gemm)
+__device__ __forceinline__ void lds_read128(f32x4v& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x4v& reg) {
+    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(reg));
+    else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(reg));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(reg));
+}
+
 template <int NG>
 __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cosine_keys_gemm(const float* __restrict__ rows,
                                                              const float* __restrict__ norms, size_t n, uint32_t dim,
@@ -280,87 +291,102 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nn = lane & 15, q4 = lane >> 4;
     const uint32_t nks = dim / kGK;
-    const int rd[2] = {q4 * 16 + (nn ^ (q4 & 7)), q4 * 16 + (nn ^ ((4 + q4) & 7))};   // this lane's operand slot per chunk
-    // staging: float4 number f of a slice = (query f / 8, dims 4 (f % 8) .. +4); a thread moves NG * 128 / 512 of them
-    constexpr int kSt = NG * 16 * 8 / (kGW * 64);
-    static_assert(kSt >= 1, "slice smaller than the workgroup");
-    auto stage_load = [&](float4 (&st)[kSt], uint32_t ks) {
+    // staging: the slice of (group g, chunk ch) is one global_load_lds_dwordx4 -- 64 lanes x 16 B land lane-linear
+    // in qsl[buf][g][ch][], straight from L2, with no register in between -- issued at the TOP of the slice before
+    // the one that reads it, so its latency sits under 128 MFMAs.  (Staged through registers at the END of a
+    // slice, every wave of both resident workgroups met the L2 round trip and the barrier at the same moment:
+    // the matrix pipes idled a third of the time, SQ_VALU_MFMA_BUSY_CYCLES.)  Queries past the batch re-read the
+    // last one; their columns are never stored.
+    constexpr int kDma = NG * 2 / kGW;
+    static_assert(kDma >= 1, "fewer (group, chunk) pairs than waves");
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lds_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&qsl[0][0][0][lane];
+    auto stage_dma = [&](uint32_t ks, int buf) {
 #pragma unroll
-        for (int i = 0; i < kSt; i++) {
-            const uint32_t f = threadIdx.x + i * kGW * 64, q = f >> 3, c4 = f & 7;
-            st[i] = q < nq_pass ? *reinterpret_cast<const float4*>(queries + (size_t)q * dim + ks * kGK + 4 * c4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto stage_store = [&](const float4 (&st)[kSt], int buf) {
-#pragma unroll
-        for (int i = 0; i < kSt; i++) {
-            const uint32_t f = threadIdx.x + i * kGW * 64, q = f >> 3, c4 = f & 7;
-            // lane (nn = q % 16, q4 = c4 % 4) of chunk c4 / 4, swizzled by the chunk column: the 8 lanes that hold
-            // one query's 128 bytes would otherwise write 256 B apart (one bank group, 8-way: 58 % of this
-            // kernel's LDS cycles were conflicts); the readers' 16-lane groups stay conflict-free under the XOR
-            qsl[buf][q >> 4][c4 >> 2][(c4 & 3) * 16 + ((q & 15) ^ (c4 & 7))] = st[i];
+        for (int i = 0; i < kDma; i++) {
+            const int idx = wv * kDma + i, g = idx >> 1, ch = idx & 1;
+            uint32_t q = (uint32_t)(g * 16 + nn);
+            q = q < nq_pass ? q : nq_pass - 1;
+            const float* src = queries + (size_t)q * dim + ks * kGK + 16 * ch + 4 * q4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)&qsl[buf][g][ch][0], 16, 0, 0);
         }
     };
     const size_t tiles = (n + 15) / 16;
-    for (size_t tb = (size_t)blockIdx.x * kGW; tb < tiles; tb += (size_t)gridDim.x * kGW) {
-        const size_t tile = tb + wave;
-        const size_t row = tile * 16 + nn;
+    const size_t tstep = (size_t)gridDim.x * kGW;
+    size_t tb = (size_t)blockIdx.x * kGW;
+    if (tb >= tiles) return;
+    auto row_ptr = [&](size_t t) {
+        const size_t r = (t + wave) * 16 + nn;
+        return rows + (r < n ? r : 0) * (size_t)dim + 4 * q4;   // dead rows read row 0; their results are not stored
+    };
+    // row chunks of slices ks and ks + 1 in flight
+    float4 xc[2], xn[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    auto load_x = [&](float4 (&x)[2], const float* __restrict__ v, uint32_t ks) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v + ks * kGK + 16 * ch));
+            x[ch] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    };
+    // The slices of all tiles form ONE pipeline: the buffer parity runs on across tiles and the last slice of a tile
+    // already requests the first slice of the next one (its query slice and this wave's next rows), so the epilogue
+    // and the tile change cost no HBM round trip and no extra barrier.
+    uint32_t gs = 0;
+    const float* __restrict__ v = row_ptr(tb);
+    stage_dma(0, 0);
+    load_x(xc, v, 0);
+    __syncthreads();
+    for (; tb < tiles; tb += tstep) {
+        const size_t row = (tb + wave) * 16 + nn;
         const bool live = row < n;
-        const float* __restrict__ v = rows + (live ? row : 0) * (size_t)dim + 4 * q4;
         const float vn = norms[live ? row : 0];
+        const bool more = tb + tstep < tiles;
+        const float* __restrict__ vnext = row_ptr(more ? tb + tstep : tb);
         f32x4v acc[NG];
 #pragma unroll
         for (int g = 0; g < NG; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        float4 st[kSt];
-        stage_load(st, 0);
-        // row chunks of slices ks and ks + 1 in flight
-        float4 xc[2], xn[2];
-        auto load_x = [&](float4 (&x)[2], uint32_t ks) {
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v + ks * kGK + 16 * ch));
-                x[ch] = make_float4(t[0], t[1], t[2], t[3]);
+        for (uint32_t ks = 0; ks < nks; ks++, gs++) {
+            const int buf = gs & 1;
+            if (ks + 1 < nks) {
+                stage_dma(ks + 1, buf ^ 1);   // last read during the previous slice; every wave passed the barrier since
+                load_x(xn, v, ks + 1);
+            } else if (more) {
+                stage_dma(0, buf ^ 1);
+                load_x(xn, vnext, 0);
             }
-        };
-        load_x(xc, 0);
-        __syncthreads();             // everyone is done with both LDS buffers of the previous tile block
-        stage_store(st, 0);
-        __syncthreads();
-        for (uint32_t ks = 0; ks < nks; ks++) {
-            const int buf = ks & 1;
-            if (ks + 1 < nks) load_x(xn, ks + 1);
+            // The 2 NG operand reads of the slice are hand-issued two ahead of their MFMAs (a ring of three
+            // registers) with counted lgkmcnt waits.  Left to the compiler (128-VGPR budget) every read was followed
+            // by lgkmcnt(0) and its four MFMAs -- an LDS round trip per 128 matrix cycles -- and, being visible LDS
+            // reads behind an LDS-DMA, each slice opened with vmcnt(0) on the prefetch just issued: the matrix pipes
+            // ran 2/3 of the time (SQ_VALU_MFMA_BUSY_CYCLES).  No scalar loads happen inside (lgkmcnt is LDS-only).
+            {
+                const uint32_t a0 = lds_lane + (uint32_t)buf * (uint32_t)(NG * 2 * 64 * 16);
+                f32x4v q3[3];
+                constexpr int kSteps = 2 * NG;               // step s = (chunk s / NG, group s % NG)
+                auto off = [](int st) { return (uint32_t)((st % NG) * 2048 + (st / NG) * 1024); };
+                lds_read128(q3[0], a0 + off(0));
+                lds_read128(q3[1], a0 + off(1));
 #pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                const float4 xv = xc[ch];
-                // groups in batches of four: four operand reads in flight, sixteen MFMAs; the scheduling barrier keeps
-                // the compiler from hoisting all 2 NG reads of the slice (64 registers at NG = 16) to the top
-#pragma unroll
-                for (int g0 = 0; g0 < NG; g0 += 4) {
-                    float4 qa[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) qa[i] = qsl[buf][g0 + i][ch][rd[ch]];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int g = g0 + i;
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].x, xv.x, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].y, xv.y, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].z, xv.z, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i].w, xv.w, acc[g], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int st = 0; st < kSteps; st++) {
+                    if (st + 2 < kSteps) lds_read128(q3[(st + 2) % 3], a0 + off(st + 2));
+                    if (st + 2 < kSteps) lds_wait<2>(q3[st % 3]);
+                    else if (st + 1 < kSteps) lds_wait<1>(q3[st % 3]);
+                    else lds_wait<0>(q3[st % 3]);
+                    const float4 xv = xc[st / NG];
+                    const int g = st % NG;
+                    const f32x4v qa = q3[st % 3];
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0], xv.x, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1], xv.y, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[2], xv.z, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[3], xv.w, acc[g], 0, 0, 0);
                 }
             }
-            if (ks + 1 < nks) {
-                // the next slice goes global (L2) -> registers -> LDS only now: holding it across the MFMAs would cost
-                // 4 NG registers' worth of spills; the other waves of the SIMD cover this latency
-                stage_load(st, ks + 1);
-                stage_store(st, buf ^ 1);   // last read during slice ks - 1; every wave passed the barrier since
-                xc[0] = xn[0];
-                xc[1] = xn[1];
-            }
+            xc[0] = xn[0];
+            xc[1] = xn[1];
             __syncthreads();
         }
+        v = vnext;
         if (live) {
 #pragma unroll
             for (int g = 0; g < NG; g++) {

@@ -94,9 +94,8 @@ __global__ __launch_bounds__(64) void select_topk_u32(const uint32_t* __restrict
         if (cnt >= k) tau = l_key[cur][k - 1];
     };
 
-    for (size_t base = s0; base < s1; base += kWave) {
-        const size_t row = base + lane;
-        const uint32_t key = row < s1 ? kq[row] : 0xffffffffu;
+    // one candidate per lane (wave-wide step): append the hits, prune when the list nears its capacity
+    auto offer = [&](uint32_t key, size_t row) {
         const bool hit = key != 0xffffffffu && key <= tau;
         const uint64_t mask = __ballot(hit);
         if (mask) {
@@ -110,6 +109,46 @@ __global__ __launch_bounds__(64) void select_topk_u32(const uint32_t* __restrict
             wave_lds_sync();
             if (cnt > (uint32_t)(kSelCap - kWave)) prune();
         }
+    };
+    // The scan is a chain of dependent HBM round trips if every step loads 4 bytes per lane and then decides:
+    // the body reads 16 bytes per lane, two steps ahead, and looks at a quad only if one of its keys can still
+    // enter the list (after the first prune almost none does).  Head and tail run key by key up to the 16-byte
+    // alignment of this query's row of keys.
+    size_t base = s0;
+    {
+        const size_t mis = ((reinterpret_cast<uintptr_t>(kq + s0) + 15) & ~(uintptr_t)15) - reinterpret_cast<uintptr_t>(kq + s0);
+        size_t head = mis / 4;                                   // keys before the first aligned quad
+        if (head > s1 - s0) head = s1 - s0;
+        if (head) {
+            const size_t row = base + lane;
+            offer((size_t)lane < head ? kq[row] : 0xffffffffu, row);
+            base += head;
+        }
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const size_t quads = (s1 - base) / (4 * kWave);              // whole wave-steps of 4 keys per lane
+    if (quads) {
+        const u32x4* __restrict__ vq = reinterpret_cast<const u32x4*>(kq + base) + lane;
+        u32x4 v0 = __builtin_nontemporal_load(vq);
+        u32x4 v1 = quads > 1 ? __builtin_nontemporal_load(vq + kWave) : v0;
+        for (size_t i = 0; i < quads; i++) {
+            const u32x4 v = v0;
+            v0 = v1;
+            if (i + 2 < quads) v1 = __builtin_nontemporal_load(vq + (i + 2) * kWave);
+            uint32_t best = v[0] < v[1] ? v[0] : v[1];
+            const uint32_t b2 = v[2] < v[3] ? v[2] : v[3];
+            best = best < b2 ? best : b2;
+            if (__ballot(best <= tau && best != 0xffffffffu)) {
+                const size_t r0 = base + i * (4 * kWave) + 4 * (size_t)lane;
+#pragma unroll
+                for (int c = 0; c < 4; c++) offer(v[c], r0 + c);
+            }
+        }
+        base += quads * (4 * kWave);
+    }
+    for (; base < s1; base += kWave) {
+        const size_t row = base + lane;
+        offer(row < s1 ? kq[row] : 0xffffffffu, row);
     }
     prune();
     const size_t obase = ((size_t)blockIdx.x * nq + q) * k;

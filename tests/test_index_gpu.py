@@ -191,6 +191,67 @@ def test_cosine_matches_oracle(gpu_ctx, oracle, n, dim, nq, k):
     ix.close()
 
 
+def _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k):
+    r64 = rows.astype(np.float64)
+    rn = np.sqrt((r64 * r64).sum(1))
+    for q in range(queries.shape[0]):
+        q64 = queries[q].astype(np.float64)
+        sc = (r64 @ q64) / np.maximum(rn * np.sqrt((q64 * q64).sum()), 1e-300)
+        sc[rn == 0] = -np.inf
+        order = np.lexsort((ids, -sc))[:k]
+        o_sc, o_ids = sc[order], ids[order]
+        m = int(np.isfinite(o_sc).sum())
+        assert g_c[q] == m, (q, g_c[q], m)
+        assert np.abs(g_sc[q, :m] - o_sc[:m]).max() <= COS_TOL, (q, g_sc[q, :m], o_sc[:m])
+        gap_ok = np.ones(m, bool)
+        if m > 1:
+            close = np.abs(np.diff(o_sc[:m])) <= 2 * COS_TOL
+            gap_ok[:-1] &= ~close
+            gap_ok[1:] &= ~close
+        if m == k and m > 0:
+            gap_ok[-1] = False
+        assert np.array_equal(g_ids[q, :m][gap_ok], o_ids[:m][gap_ok]), q
+
+
+@pytest.mark.parametrize("nq,k", [(100, 10), (300, 1), (64, 50)])
+def test_cosine_filtered_batch_pass(gpu_ctx, nq, k):
+    """Batches over a shard of >= 2^18 rows take the thresholded GEMM pass (sample answer -> per-query threshold ->
+    candidate lists); 300 queries are a full pass of 256 and a short one that goes the dense way."""
+    from ucfp_amd import index
+    n, dim = 300_000, 64
+    rng = np.random.default_rng(nq * 31 + k)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[rng.integers(0, n, 50)] = 0.0
+    rows[100_000:100_020] = rows[5]              # exact duplicates across the sample boundary: ties by id
+    ids = rng.permutation(n).astype(np.uint64) + np.uint64(3)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    queries[1] = rows[5] * 0.5
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+    ix.close()
+
+
+def test_cosine_filtered_pass_overflow_falls_back(gpu_ctx):
+    """The best rows sit behind the sample: thousands of rows beat the sample's k-th score for some queries, their
+    candidate lists overflow, and the flag-gated dense pass has to produce the answer."""
+    from ucfp_amd import index
+    n, dim, nq, k = 280_000, 32, 80, 10
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    rows[-4000:] = queries[3] + 0.05 * rng.standard_normal((4000, dim)).astype(np.float32)
+    rows[-8000:-4000] = -queries[7] * 2.0 + 0.3 * rng.standard_normal((4000, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+    assert (g_ids[3] >= n - 4000).all()
+    ix.close()
+
+
 def test_cosine_reference_index_tests(gpu_ctx):
     """src/index/embedded/mod.rs:522-589 replayed on GpuIndex with Records."""
     from ucfp_amd import index

@@ -67,7 +67,13 @@ struct SelectPlan {
 SelectPlan select_plan(size_t n, uint32_t nq);
 int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, const SelectPlan& p,
                            uint32_t nq, uint32_t k, uint64_t* part_ids, uint32_t* part_key,
-                           uint32_t* part_cnt, hipStream_t stream);
+                           uint32_t* part_cnt, hipStream_t stream, const uint32_t* run_flag = nullptr);
+// best k of (a base list of k entries + a list of candidate row numbers) per query; see topk.hip
+int launch_topk_select_lists_u32(const uint64_t* base_ids, const uint32_t* base_key, const uint32_t* ckey,
+                                 const uint32_t* crow, const uint32_t* ccnt, uint32_t cap, const uint64_t* ids,
+                                 uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt,
+                                 uint32_t* overflow, hipStream_t stream);
+constexpr uint32_t kCosineListCap = 1024;   // candidates kept per query by the filtered cosine pass
 // run_flag: optional device word; when non-null the merge only runs if it is non-zero
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts,
                           uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key,
@@ -76,13 +82,23 @@ int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, ui
 size_t topk_merge_tmp_entries(uint32_t parts, uint32_t nq, uint32_t k);
 int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,
                                uint32_t k, uint64_t* tmp_ids, uint32_t* tmp_key, uint64_t* out_ids, uint32_t* out_key,
-                               uint32_t* out_cnt, hipStream_t stream);
+                               uint32_t* out_cnt, hipStream_t stream, const uint32_t* run_flag = nullptr);
 
 // cosine.hip
 int launch_cosine_norms(const float* rows, size_t n, uint32_t dim, float* norms, hipStream_t stream);
 int cosine_queries_per_pass(uint32_t dim, size_t nq);
 int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
-                       const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream);
+                       const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream,
+                       const uint32_t* run_flag = nullptr);
+// the batch (GEMM) path with a per-query key threshold: rows whose key is <= tau[q] are appended to q's candidate
+// list instead of writing the nq x n key matrix; false if this (rows, dim, batch) does not take the GEMM path
+bool cosine_filter_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n);
+int launch_cosine_tau(const uint32_t* base_key, uint32_t k, const float* qnorm, uint32_t nq, uint32_t* tau, float* uq,
+                      uint32_t* ccnt, hipStream_t stream);
+int launch_cosine_keys_filtered(const float* rows, const float* norms, size_t n, size_t row_base, uint32_t dim,
+                                const float* queries, const float* qnorm, uint32_t nq_pass, const uint32_t* tau,
+                                const float* uq, uint32_t* ccnt, uint32_t* ckey, uint32_t* crow, uint32_t cap,
+                                hipStream_t stream);
 int launch_cosine_scores_from_keys(const uint32_t* keys, size_t total, float* scores, hipStream_t stream);
 
 // text.hip

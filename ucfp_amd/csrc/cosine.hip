@@ -280,12 +280,27 @@ __device__ __forceinline__ void lds_wait(f32x4v& reg) {
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(reg));
 }
 
-template <int NG>
+// FILT: instead of the nq x n key matrix, a row whose key is <= tau[q] joins q's candidate list (row number + key).
+// tau is the k-th best key of a sample of the corpus, so about k n / sample rows per query pass; the test costs four
+// VALU operations per result (acc against uq[q] * |row|, uq = score(tau) * |q|, with a 2^-21 relative slack for the
+// roundings of the exact path) and only the passers pay for the division and the exact key.
+struct CosineFilter {
+    const uint32_t* tau;
+    const float* uq;
+    uint32_t* ccnt;
+    uint32_t* ckey;
+    uint32_t* crow;
+    uint32_t cap;
+    uint32_t row_base;
+};
+template <int NG, bool FILT>
 __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cosine_keys_gemm(const float* __restrict__ rows,
                                                              const float* __restrict__ norms, size_t n, uint32_t dim,
                                                              const float* __restrict__ queries,
                                                              const float* __restrict__ qnorm, uint32_t nq_pass,
-                                                             uint32_t* __restrict__ keys) {
+                                                             uint32_t* __restrict__ keys, CosineFilter flt,
+                                                             const uint32_t* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
     // [buffer][group][chunk][lane] float4: 2 x NG x 2 KiB
     __shared__ __attribute__((aligned(16))) float4 qsl[2][NG][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -394,13 +409,31 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
                 for (int r = 0; r < 4; r++) {
                     const uint32_t qt = g * 16 + 4 * q4 + r;
                     if (qt < nq_pass) {
-                        const float qn = qnorm[qt];   // once per 16 rows x 768 dims of matrix work: not worth 4 NG registers
-                        uint32_t key = 0xffffffffu;
-                        if (vn != 0.f && qn != 0.f) {
-                            const float sc = acc[g][r] / (qn * vn);
-                            if (sc == sc) key = score_to_key(sc);
+                        if constexpr (FILT) {
+                            const float t = flt.uq[qt] * vn;
+                            if (acc[g][r] >= t - fabsf(t) * 0x1p-21f - 0x1p-120f) {
+                                const float qn = qnorm[qt];
+                                if (vn != 0.f && qn != 0.f) {
+                                    const float sc = acc[g][r] / (qn * vn);
+                                    const uint32_t key = sc == sc ? score_to_key(sc) : 0xffffffffu;
+                                    if (key != 0xffffffffu && key <= flt.tau[qt]) {
+                                        const uint32_t pos = atomicAdd(&flt.ccnt[qt], 1u);
+                                        if (pos < flt.cap) {
+                                            flt.ckey[(size_t)qt * flt.cap + pos] = key;
+                                            flt.crow[(size_t)qt * flt.cap + pos] = flt.row_base + (uint32_t)row;
+                                        }
+                                    }
+                                }
+                            }
+                        } else {
+                            const float qn = qnorm[qt];   // once per 16 rows x 768 dims of matrix work: not worth 4 NG registers
+                            uint32_t key = 0xffffffffu;
+                            if (vn != 0.f && qn != 0.f) {
+                                const float sc = acc[g][r] / (qn * vn);
+                                if (sc == sc) key = score_to_key(sc);
+                            }
+                            keys[(size_t)qt * n + row] = key;
                         }
-                        keys[(size_t)qt * n + row] = key;
                     }
                 }
             }
@@ -443,23 +476,69 @@ int cosine_queries_per_pass(uint32_t dim, size_t nq) {
     return (int)(fit < (size_t)kQT ? fit : (size_t)kQT);
 }
 
-int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
-                       const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream) {
+namespace {
+bool gemm_path(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass) {
+    return mfma_ok(rows, dim) && dim % kGK == 0 && nq_pass > (uint32_t)16 * mfma_groups(dim) &&
+           (reinterpret_cast<uintptr_t>(queries) & 15u) == 0;
+}
+template <bool FILT>
+void launch_gemm(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
+                 uint32_t nq_pass, uint32_t* keys, const CosineFilter& flt, const uint32_t* run_flag, hipStream_t stream) {
+    const size_t tiles = (n + 15) / 16;
+    unsigned grid = (unsigned)((tiles + kGW - 1) / kGW);
+    if (grid > 256 * 2) grid = 256 * 2;
+    if (nq_pass <= 64)
+        hipLaunchKernelGGL((cosine_keys_gemm<4, FILT>), dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
+                           qnorm, nq_pass, keys, flt, run_flag);
+    else if (nq_pass <= 128)
+        hipLaunchKernelGGL((cosine_keys_gemm<8, FILT>), dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
+                           qnorm, nq_pass, keys, flt, run_flag);
+    else
+        hipLaunchKernelGGL((cosine_keys_gemm<16, FILT>), dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
+                           qnorm, nq_pass, keys, flt, run_flag);
+}
+
+// tau[q] = the k-th key of the sample's answer (0xffffffff while the sample holds fewer than k scored rows: then
+// everything passes, the lists overflow and the dense path answers); uq = score(tau) * |q|; candidate counters zeroed
+__global__ void cosine_tau_kernel(const uint32_t* __restrict__ base_key, uint32_t k, const float* __restrict__ qnorm,
+                                  uint32_t nq, uint32_t* __restrict__ tau, float* __restrict__ uq,
+                                  uint32_t* __restrict__ ccnt) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t t = base_key[(size_t)q * k + k - 1];
+    tau[q] = t;
+    uq[q] = (t == 0xffffffffu ? -2.0f : key_to_score(t)) * qnorm[q];
+    ccnt[q] = 0;
+}
+}  // namespace
+
+bool cosine_filter_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n) {
+    return gemm_path(rows, dim, queries, nq_pass) && n >= ((size_t)1 << 18) && n < ((size_t)1 << 32);
+}
+
+int launch_cosine_tau(const uint32_t* base_key, uint32_t k, const float* qnorm, uint32_t nq, uint32_t* tau, float* uq,
+                      uint32_t* ccnt, hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(cosine_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, base_key, k, qnorm, nq, tau, uq, ccnt);
+    return 0;
+}
+
+int launch_cosine_keys_filtered(const float* rows, const float* norms, size_t n, size_t row_base, uint32_t dim,
+                                const float* queries, const float* qnorm, uint32_t nq_pass, const uint32_t* tau,
+                                const float* uq, uint32_t* ccnt, uint32_t* ckey, uint32_t* crow, uint32_t cap,
+                                hipStream_t stream) {
     if (n == 0 || nq_pass == 0) return 0;
-    if (mfma_ok(rows, dim) && dim % kGK == 0 && nq_pass > (uint32_t)16 * mfma_groups(dim) &&
-        (reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {
-        const size_t tiles = (n + 15) / 16;
-        unsigned grid = (unsigned)((tiles + kGW - 1) / kGW);
-        if (grid > 256 * 2) grid = 256 * 2;
-        if (nq_pass <= 64)
-            hipLaunchKernelGGL(cosine_keys_gemm<4>, dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
-                               qnorm, nq_pass, keys);
-        else if (nq_pass <= 128)
-            hipLaunchKernelGGL(cosine_keys_gemm<8>, dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
-                               qnorm, nq_pass, keys);
-        else
-            hipLaunchKernelGGL(cosine_keys_gemm<16>, dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
-                               qnorm, nq_pass, keys);
+    const CosineFilter flt{tau, uq, ccnt, ckey, crow, cap, (uint32_t)row_base};
+    launch_gemm<true>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, flt, nullptr, stream);
+    return 0;
+}
+
+int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                       const float* qnorm, uint32_t nq_pass, uint32_t* keys, hipStream_t stream,
+                       const uint32_t* run_flag) {
+    if (n == 0 || nq_pass == 0) return 0;
+    if (gemm_path(rows, dim, queries, nq_pass)) {
+        launch_gemm<false>(rows, norms, n, dim, queries, qnorm, nq_pass, keys, CosineFilter{}, run_flag, stream);
         return 0;
     }
     if (mfma_ok(rows, dim)) {

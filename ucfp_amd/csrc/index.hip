@@ -211,6 +211,25 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     off = align256(off + tmp_e * 8);
     const size_t o_tk = off;
     off = align256(off + tmp_e * 4);
+    // filtered batch passes (see below): sample answer, thresholds, candidate lists, overflow flag
+    const uint32_t cap = ucfp::kCosineListCap;
+    const size_t fq = (size_t)qpp < chunk ? (size_t)qpp : chunk;
+    const size_t o_bid = off;
+    off = align256(off + fq * k * 8);
+    const size_t o_bk = off;
+    off = align256(off + fq * k * 4);
+    const size_t o_tau = off;
+    off = align256(off + fq * 4);
+    const size_t o_uq = off;
+    off = align256(off + fq * 4);
+    const size_t o_cc = off;
+    off = align256(off + fq * 4);
+    const size_t o_ck = off;
+    off = align256(off + fq * cap * 4);
+    const size_t o_cr = off;
+    off = align256(off + fq * cap * 4);
+    const size_t o_flag = off;
+    off = align256(off + 256);
     int rc = ix->ws.ensure(off);
     if (rc) return rc;
     uint8_t* w = ix->ws.p;
@@ -218,22 +237,74 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     uint32_t* keymat = reinterpret_cast<uint32_t*>(w + o_keys);
     uint32_t* okeys = d_out_keys ? d_out_keys : reinterpret_cast<uint32_t*>(w + o_ok);
     const float* q = reinterpret_cast<const float*>(d_queries);
+    const float* rows = reinterpret_cast<const float*>(s->rows);
+    uint64_t* pid = reinterpret_cast<uint64_t*>(w + o_pid);
+    uint32_t* pk = reinterpret_cast<uint32_t*>(w + o_pk);
+    uint32_t* pc = reinterpret_cast<uint32_t*>(w + o_pc);
+    uint64_t* tid = reinterpret_cast<uint64_t*>(w + o_tid);
+    uint32_t* tk = reinterpret_cast<uint32_t*>(w + o_tk);
+    // select + merge of `m` rows of keys for `cnt` queries, within the partial space reserved for the chunk
+    auto select_merge = [&](size_t m, uint32_t cnt, uint64_t* o_ids, uint32_t* o_keys, uint32_t* o_cnt,
+                            const uint32_t* run_flag) {
+        ucfp::SelectPlan pl = ucfp::select_plan(m, cnt);
+        if (pl.slices > sp.slices) {
+            pl.per_slice = (((m + sp.slices - 1) / sp.slices) + 63) & ~(size_t)63;
+            pl.slices = (uint32_t)((m + pl.per_slice - 1) / pl.per_slice);
+        }
+        ucfp::launch_select_topk_u32(keymat, s->ids, m, pl, cnt, k, pid, pk, pc, st, run_flag);
+        ucfp::launch_topk_merge_tree_u32(pid, pk, pl.slices, cnt, k, tid, tk, o_ids, o_keys, o_cnt, st, run_flag);
+    };
     ucfp::launch_cosine_norms(q, nq, dim, qn, st);
     for (size_t q0 = 0; q0 < nq; q0 += chunk) {
         const size_t qc = nq - q0 < chunk ? nq - q0 : chunk;
+        // Batch passes over a large shard do not write the np x n key matrix: the exact answer over the first
+        // kSample rows gives every query a threshold (its k-th best key there), the pass over the other rows keeps
+        // only the rows that beat it (about k n / kSample per query) in per-query lists, and a wave per query picks
+        // the best k of sample answer + list.  A list that overflows (an adversarial row order) raises a flag and
+        // the dense pass, select and merge below -- gated on that flag -- answer instead.
+        // sample size: the lists expect k n / kSample entries each; an eighth of their capacity keeps an overflow
+        // out of reach for rows in random order
+        size_t kSample = ((size_t)8 * k * n / cap + 15) & ~(size_t)15;
+        if (kSample < 32768) kSample = 32768;
+        const uint32_t np0 = (uint32_t)(qc < (size_t)qpp ? qc : (size_t)qpp);
+        if (k >= 1 && n >= 8 * kSample && ucfp::cosine_filter_ok(rows, dim, q + q0 * dim, np0, n)) {
+            uint32_t* flag = reinterpret_cast<uint32_t*>(w + o_flag);
+            uint64_t* bid = reinterpret_cast<uint64_t*>(w + o_bid);
+            uint32_t* bk = reinterpret_cast<uint32_t*>(w + o_bk);
+            uint32_t* tau = reinterpret_cast<uint32_t*>(w + o_tau);
+            float* uq = reinterpret_cast<float*>(w + o_uq);
+            uint32_t* cc = reinterpret_cast<uint32_t*>(w + o_cc);
+            uint32_t* ck = reinterpret_cast<uint32_t*>(w + o_ck);
+            uint32_t* cr = reinterpret_cast<uint32_t*>(w + o_cr);
+            for (size_t p0 = 0; p0 < qc; p0 += qpp) {
+                const uint32_t np = (uint32_t)(qc - p0 < (size_t)qpp ? qc - p0 : qpp);
+                const float* qp = q + (q0 + p0) * dim;
+                const float* qnp = qn + q0 + p0;
+                uint64_t* oi = d_out_ids + (q0 + p0) * k;
+                uint32_t* ok = okeys + (q0 + p0) * k;
+                uint32_t* oc = d_out_cnt + q0 + p0;
+                if (!ucfp::cosine_filter_ok(rows, dim, qp, np, n)) {   // a short last pass
+                    ucfp::launch_cosine_keys(rows, s->norms, n, dim, qp, qnp, np, keymat, st);
+                    select_merge(n, np, oi, ok, oc, nullptr);
+                    continue;
+                }
+                HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+                ucfp::launch_cosine_keys(rows, s->norms, kSample, dim, qp, qnp, np, keymat, st);
+                select_merge(kSample, np, bid, bk, cc, nullptr);          // cc: scratch for the sample's counts
+                ucfp::launch_cosine_tau(bk, k, qnp, np, tau, uq, cc, st);
+                ucfp::launch_cosine_keys_filtered(rows + kSample * dim, s->norms + kSample, n - kSample, kSample, dim, qp,
+                                                  qnp, np, tau, uq, cc, ck, cr, cap, st);
+                ucfp::launch_topk_select_lists_u32(bid, bk, ck, cr, cc, cap, s->ids, np, k, oi, ok, oc, flag, st);
+                ucfp::launch_cosine_keys(rows, s->norms, n, dim, qp, qnp, np, keymat, st, flag);
+                select_merge(n, np, oi, ok, oc, flag);
+            }
+            continue;
+        }
         for (size_t p0 = 0; p0 < qc; p0 += qpp) {
             const uint32_t np = (uint32_t)(qc - p0 < (size_t)qpp ? qc - p0 : qpp);
-            ucfp::launch_cosine_keys(reinterpret_cast<const float*>(s->rows), s->norms, n, dim,
-                                     q + (q0 + p0) * dim, qn + q0 + p0, np, keymat + p0 * n, st);
+            ucfp::launch_cosine_keys(rows, s->norms, n, dim, q + (q0 + p0) * dim, qn + q0 + p0, np, keymat + p0 * n, st);
         }
-        ucfp::SelectPlan spc = ucfp::select_plan(n, (uint32_t)qc);
-        if (spc.slices > sp.slices) spc = sp;  // never exceed the reserved partial space
-        ucfp::launch_select_topk_u32(keymat, s->ids, n, spc, (uint32_t)qc, k, reinterpret_cast<uint64_t*>(w + o_pid),
-                                     reinterpret_cast<uint32_t*>(w + o_pk), reinterpret_cast<uint32_t*>(w + o_pc), st);
-        ucfp::launch_topk_merge_tree_u32(reinterpret_cast<uint64_t*>(w + o_pid), reinterpret_cast<uint32_t*>(w + o_pk),
-                                         spc.slices, (uint32_t)qc, k, reinterpret_cast<uint64_t*>(w + o_tid),
-                                         reinterpret_cast<uint32_t*>(w + o_tk), d_out_ids + q0 * k, okeys + q0 * k,
-                                         d_out_cnt + q0, st);
+        select_merge(n, (uint32_t)qc, d_out_ids + q0 * k, okeys + q0 * k, d_out_cnt + q0, nullptr);
     }
     if (d_out_scores) ucfp::launch_cosine_scores_from_keys(okeys, nq * k, d_out_scores, st);
     HIP_TRY(hipGetLastError());

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(64) void select_topk_u32(const uint32_t* __restrict
                                                       size_t per_slice, uint32_t nq, uint32_t k,
                                                       uint64_t* __restrict__ part_ids,
                                                       uint32_t* __restrict__ part_key,
-                                                      uint32_t* __restrict__ part_cnt) {
+                                                      uint32_t* __restrict__ part_cnt,
+                                                      const uint32_t* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
     __shared__ uint64_t l_id[2][kSelCap];
     __shared__ uint32_t l_key[2][kSelCap];
     const int lane = threadIdx.x;
@@ -234,10 +236,85 @@ SelectPlan select_plan(size_t n, uint32_t nq) {
 
 int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, const SelectPlan& p,
                            uint32_t nq, uint32_t k, uint64_t* part_ids, uint32_t* part_key,
-                           uint32_t* part_cnt, hipStream_t stream) {
+                           uint32_t* part_cnt, hipStream_t stream, const uint32_t* run_flag) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(select_topk_u32, dim3(p.slices, nq), dim3(64), 0, stream, keys, ids, n, p.per_slice, nq,
-                       k, part_ids, part_key, part_cnt);
+                       k, part_ids, part_key, part_cnt, run_flag);
+    return 0;
+}
+
+// One wave per query: the best k by (key, id) of a base list (k entries, invalid ones carry key 0xffffffff) and a
+// candidate list of row numbers (at most cap of the cnt[q] produced are stored).  A query whose candidates did not
+// all fit raises *overflow (the caller then re-runs the dense path); it still writes its incomplete answer.
+constexpr int kListCap = 1024;
+__global__ __launch_bounds__(64) void topk_select_lists_u32(const uint64_t* __restrict__ base_ids,
+                                                            const uint32_t* __restrict__ base_key,
+                                                            const uint32_t* __restrict__ ckey,
+                                                            const uint32_t* __restrict__ crow,
+                                                            const uint32_t* __restrict__ ccnt, uint32_t cap,
+                                                            const uint64_t* __restrict__ ids, uint32_t k,
+                                                            uint64_t* __restrict__ out_ids,
+                                                            uint32_t* __restrict__ out_key,
+                                                            uint32_t* __restrict__ out_cnt,
+                                                            uint32_t* __restrict__ overflow) {
+    __shared__ uint64_t l_id[kListCap + 64];
+    __shared__ uint32_t l_key[kListCap + 64];
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    uint32_t c = ccnt[q];
+    if (c > cap) {
+        if (lane == 0) atomicOr(overflow, 1u);
+        c = cap;
+    }
+    for (uint32_t e = lane; e < c; e += kWave) {
+        l_key[e] = ckey[(size_t)q * cap + e];
+        l_id[e] = ids[crow[(size_t)q * cap + e]];
+    }
+    for (uint32_t e = lane; e < k; e += kWave) {
+        l_key[c + e] = base_key[(size_t)q * k + e];
+        l_id[c + e] = base_ids[(size_t)q * k + e];
+    }
+    const uint32_t total = c + k;
+    wave_lds_sync();
+    uint32_t ld = 0, kept = 0;
+    uint64_t li = 0;
+    bool first = true;
+    for (uint32_t r = 0; r < k; r++) {
+        uint32_t bd = 0xffffffffu;
+        uint64_t bi = ~0ull;
+        for (uint32_t e = lane; e < total; e += kWave) {
+            const uint32_t dd = l_key[e];
+            const uint64_t ii = l_id[e];
+            if (dd != 0xffffffffu && (first || key_less(ld, li, dd, ii)) && key_less(dd, ii, bd, bi)) {
+                bd = dd;
+                bi = ii;
+            }
+        }
+        wave_argmin(bd, bi);
+        if (bd == 0xffffffffu && bi == ~0ull) break;
+        if (lane == 0) {
+            out_key[(size_t)q * k + r] = bd;
+            out_ids[(size_t)q * k + r] = bi;
+        }
+        ld = bd;
+        li = bi;
+        first = false;
+        kept++;
+    }
+    for (uint32_t e = kept + lane; e < k; e += kWave) {
+        out_key[(size_t)q * k + e] = 0xffffffffu;
+        out_ids[(size_t)q * k + e] = ~0ull;
+    }
+    if (lane == 0) out_cnt[q] = kept;
+}
+
+int launch_topk_select_lists_u32(const uint64_t* base_ids, const uint32_t* base_key, const uint32_t* ckey,
+                                 const uint32_t* crow, const uint32_t* ccnt, uint32_t cap, const uint64_t* ids,
+                                 uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt,
+                                 uint32_t* overflow, hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(topk_select_lists_u32, dim3(nq), dim3(64), 0, stream, base_ids, base_key, ckey, crow, ccnt,
+                       cap < (uint32_t)kListCap ? cap : (uint32_t)kListCap, ids, k, out_ids, out_key, out_cnt, overflow);
     return 0;
 }
 
@@ -259,15 +336,15 @@ size_t topk_merge_tmp_entries(uint32_t parts, uint32_t nq, uint32_t k) {
 }
 int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,
                                uint32_t k, uint64_t* tmp_ids, uint32_t* tmp_key, uint64_t* out_ids, uint32_t* out_key,
-                               uint32_t* out_cnt, hipStream_t stream) {
+                               uint32_t* out_cnt, hipStream_t stream, const uint32_t* run_flag) {
     if (nq == 0) return 0;
     if (parts <= kMergeFan)
-        return launch_topk_merge_u32(part_ids, part_key, parts, nq, k, out_ids, out_key, out_cnt, nullptr, stream);
+        return launch_topk_merge_u32(part_ids, part_key, parts, nq, k, out_ids, out_key, out_cnt, run_flag, stream);
     const uint32_t groups = (parts + kMergeFan - 1) / kMergeFan;
     hipLaunchKernelGGL(topk_merge_u32, dim3(nq, groups), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, tmp_ids,
-                       tmp_key, (uint32_t*)nullptr, (const uint32_t*)nullptr, kMergeFan);
+                       tmp_key, (uint32_t*)nullptr, run_flag, kMergeFan);
     return launch_topk_merge_tree_u32(tmp_ids, tmp_key, groups, nq, k, tmp_ids + (size_t)groups * nq * k,
-                                      tmp_key + (size_t)groups * nq * k, out_ids, out_key, out_cnt, stream);
+                                      tmp_key + (size_t)groups * nq * k, out_ids, out_key, out_cnt, stream, run_flag);
 }
 
 }  // namespace ucfp

@@ -60,27 +60,59 @@ class ShardedIndex:
         stream = torch.cuda.current_stream().cuda_stream
         self.local.append_dev(self.tenant, ids.data_ptr(), rows.data_ptr(), ids.numel(), stream)
 
-    def _buffers(self, nq: int, k: int, device):
-        key = (nq, k)
+    def _buffers(self, nq: int, k: int, device, slot: int = 0):
+        key = (nq, k, slot)
         b = self._bufs.get(key)
         if b is None:
             mk = lambda dt: torch.empty((nq, k), dtype=dt, device=device)  # noqa: E731
             b = self._bufs[key] = dict(
                 ids=mk(torch.int64), keys=mk(torch.int32), cnt=torch.empty((nq,), dtype=torch.int32, device=device),
                 out_ids=mk(torch.int64), out_keys=mk(torch.int32), out_scores=mk(torch.float32),
-                out_cnt=torch.empty((nq,), dtype=torch.int32, device=device))
+                out_cnt=torch.empty((nq,), dtype=torch.int32, device=device), done=None)
         return b
+
+    def submit(self, queries: torch.Tensor, k: int) -> Tuple[int, int, int]:
+        """Start one batch: the local search runs on the current stream; the exchange (all-gather of
+        the per-shard top-k + merge) runs on a side stream of this index, so it overlaps the NEXT
+        batch's local search (two buffer sets; at most two batches in flight).  The query tensor must
+        stay untouched until the ticket is collected.  Returns a ticket for `collect`."""
+        nq = queries.shape[0]
+        slot = self._slot = getattr(self, "_slot", 1) ^ 1
+        b = self._buffers(nq, k, queries.device, slot)
+        cur = torch.cuda.current_stream()
+        if b["done"] is not None:
+            cur.wait_event(b["done"])          # the exchange that last used this buffer set has finished
+        self.local.search_dev(self.tenant, queries.data_ptr(), nq, k, b["ids"].data_ptr(), 0,
+                              b["keys"].data_ptr(), b["cnt"].data_ptr(), cur.cuda_stream)
+        if self.world == 1:
+            xs = cur
+        else:
+            if getattr(self, "_xs", None) is None:
+                self._xs = torch.cuda.Stream(device=queries.device)
+            xs = self._xs
+            searched = torch.cuda.Event()
+            searched.record(cur)
+            xs.wait_event(searched)
+        with torch.cuda.stream(xs):
+            g_ids, g_keys = all_gather_topk(b["ids"], b["keys"], self.group)
+            _index.topk_merge_dev(self.kind, g_ids.data_ptr(), g_keys.data_ptr(), g_ids.shape[0], nq, k,
+                                  b["out_ids"].data_ptr(), b["out_scores"].data_ptr(), b["out_keys"].data_ptr(),
+                                  b["out_cnt"].data_ptr(), xs.cuda_stream, ctx=self.ctx)
+            b["gathered"] = (g_ids, g_keys)    # keep the gather buffers alive until the merge has run
+            done = torch.cuda.Event()
+            done.record(xs)
+            b["done"] = done
+        return (nq, k, slot)
+
+    def collect(self, ticket: Tuple[int, int, int]):
+        """Make the current stream wait for a submitted batch; returns (ids, scores, keys, counts)."""
+        nq, k, slot = ticket
+        b = self._bufs[(nq, k, slot)]
+        torch.cuda.current_stream().wait_event(b["done"])
+        return b["out_ids"], b["out_scores"], b["out_keys"], b["out_cnt"]
 
     def search(self, queries: torch.Tensor, k: int):
         """queries: device tensor, [nq] int64 (u64 hashes) or [nq, dim] float32, identical on
-        every rank. Returns (ids int64 [nq,k], scores f32 [nq,k], keys int32 [nq,k], counts [nq])."""
-        nq = queries.shape[0]
-        b = self._buffers(nq, k, queries.device)
-        stream = torch.cuda.current_stream().cuda_stream
-        self.local.search_dev(self.tenant, queries.data_ptr(), nq, k, b["ids"].data_ptr(), 0,
-                              b["keys"].data_ptr(), b["cnt"].data_ptr(), stream)
-        g_ids, g_keys = all_gather_topk(b["ids"], b["keys"], self.group)
-        _index.topk_merge_dev(self.kind, g_ids.data_ptr(), g_keys.data_ptr(), g_ids.shape[0], nq, k,
-                              b["out_ids"].data_ptr(), b["out_scores"].data_ptr(), b["out_keys"].data_ptr(),
-                              b["out_cnt"].data_ptr(), stream, ctx=self.ctx)
-        return b["out_ids"], b["out_scores"], b["out_keys"], b["out_cnt"]
+        every rank. Returns (ids int64 [nq,k], scores f32 [nq,k], keys int32 [nq,k], counts [nq]).
+        The returned tensors belong to the index and are overwritten two searches later."""
+        return self.collect(self.submit(queries, k))

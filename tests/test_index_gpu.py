@@ -503,3 +503,30 @@ def test_record_codes_and_query_dispatch(gpu_ctx, oracle, torch_cuda):
     vh = g.query(QueryRequest.from_json({"tenant_id": 3, "modality": "Image", "vector": [5.0, 1.0, 0.5]}))
     assert vh[0].record_id == 105 and vh[0].source == "vector" and vh[0].vector_rank == 1 and len(vh) == 10
     assert g.query(QueryRequest.from_json({"tenant_id": 4, "modality": "Image", "vector": [5.0, 1.0, 0.5]})) == []
+
+
+def test_sharded_submit_collect_two_in_flight(gpu_ctx, oracle, torch_cuda):
+    """ShardedIndex.submit/collect (the pipelined form of search): two batches in flight use separate buffer
+    sets and both answers equal the oracle's (single process: world = 1, the exchange is the merge alone)."""
+    torch = torch_cuda
+    from ucfp_amd import index, sharded
+    rng = np.random.default_rng(77)
+    n, nq, k = 50_000, 70, 10
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    ids = rng.permutation(n).astype(np.uint64)
+    qa = codes[:nq] ^ np.uint64(0b101)
+    qb = rng.integers(0, 2**64, nq, dtype=np.uint64)
+    six = sharded.ShardedIndex(index.HAMMING64, ctx=gpu_ctx)
+    six.append_local(torch.from_numpy(ids.view(np.int64)).cuda(), torch.from_numpy(codes.view(np.int64)).cuda())
+    da = torch.from_numpy(qa.view(np.int64)).cuda()
+    db = torch.from_numpy(qb.view(np.int64)).cuda()
+    ta = six.submit(da, k)
+    tb = six.submit(db, k)
+    ra = [t.clone() for t in six.collect(ta)]
+    rb = [t.clone() for t in six.collect(tb)]
+    torch.cuda.synchronize()
+    for (g_ids, _, g_keys, g_cnt), q in ((ra, qa), (rb, qb)):
+        o_ids, o_d, _ = oracle.hamming_topk(ids, codes, q, k)
+        assert np.array_equal(g_ids.cpu().numpy().view(np.uint64), o_ids)
+        assert np.array_equal(g_keys.cpu().numpy().view(np.uint32), o_d)
+        assert (g_cnt.cpu().numpy() == k).all()

@@ -6,7 +6,7 @@
 // ordered by (d ascending, record_id ascending); at most k per query.
 //
 // Three scans share one structure (an upper bound tau[q] on the final k-th distance turns the search into a
-// filter; bounds come from a 32k-code sample, then from the candidates found so far, over ranges growing 8x):
+// filter; bounds come from a 32k-code sample, then from the candidates found so far, over ranges growing 4x):
 //   > 64 queries   hamming_scan_mfma   the pair distance as a +-1 x 0/1 byte contraction on the int8 matrix
 //                                      cores; suspect blocks are logged and re-evaluated exactly by hamming_rescan
 //   <= 64 queries  hamming_scan_lanes  lane = code, queries in SGPRs: a pure HBM stream
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void hamming_scan(
 //           result layout) and appends the true candidates to the per-query lists.
 // The scan runs in stages over geometrically growing ranges: tau0 (k-th distance inside a 32k-code
 // sample) filters [0, 8 x 32k); the k-th smallest distance of the candidates so far filters the next
-// 8x larger range, and so on, so every stage admits only ~8k..40k candidates per query.  The final
+// 4x larger range, and so on, so every stage admits only ~4k..20k candidates per query.  The final
 // top-k is selected from the lists.  If a log or a list overflows (adversarial order) a flag routes
 // the batch through the robust tier, device-side -- results never depend on the heuristic.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -807,19 +807,22 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     p.sample_n = s;
     p.sample_parts = (uint32_t)((s + 1023) / 1024);  // short parts: the pre-pass is latency-bound per wave
     p.per_part = (s + p.sample_parts - 1) / p.sample_parts;
-    // matrix-core filter once the corpus dwarfs the sample: stages over ranges growing 8x, so a stage
-    // admits ~ c k 8 candidates per query (c <= ~5: the boundary distance bin is fat)
+    // matrix-core filter once the corpus dwarfs the sample: stages over ranges growing 4x, so a stage
+    // admits ~ c k 4 candidates per query (c <= ~5: the boundary distance bin is fat)
     p.fast = n >= (size_t)1 << 18 && n - 1 <= 0xfffffff0u;
     p.robust_n = n;
     if (p.fast) {
         size_t e = p.sample_n;
+        // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
+        // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs)
+        constexpr size_t growth = 4;
         while (e < n && p.nstages < 12) {
-            e = e * 8 < n ? e * 8 : n;
+            e = e * growth < n ? e * growth : n;
             p.stage_end[p.nstages++] = e;
         }
         p.stage_end[p.nstages - 1] = n;
         p.robust_n = 0;
-        size_t cc = (size_t)k * 8 * 5 * p.nstages * 2;   // 2x headroom
+        size_t cc = (size_t)k * growth * 5 * p.nstages * 2;   // 2x headroom
         if (cc < 2048) cc = 2048;
         if (cc > 65536) cc = 65536;
         p.cand_cap = (uint32_t)cc;

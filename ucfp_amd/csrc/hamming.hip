@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void hamming_scan(
 //           (query, 16-code half) combinations with plain popcounts (exact, independent of the MFMA
 //           result layout) and appends the true candidates to the per-query lists.
 // The scan runs in stages over geometrically growing ranges: tau0 (k-th distance inside a 32k-code
-// sample) filters [0, 8 x 32k); the k-th smallest distance of the candidates so far filters the next
+// sample) filters [0, 4 x 32k); the k-th smallest distance of the candidates so far filters the next
 // 4x larger range, and so on, so every stage admits only ~4k..20k candidates per query.  The final
 // top-k is selected from the lists.  If a log or a list overflows (adversarial order) a flag routes
 // the batch through the robust tier, device-side -- results never depend on the heuristic.

@@ -61,11 +61,12 @@ __global__ void resample_linear_kernel(const float* __restrict__ in, size_t n, u
 // twiddles W^(jj * 2048 >> st)) occupies entries [2^(st-1) - E, 2^st - E), so a read at jj = const | lane-low-bits
 // touches consecutive 8-byte entries.  (Read from the natural 1024-entry table at stride 2048 >> st, the 16 distinct
 // addresses of a stage-5 read all fall on one bank: 59 % of the LDS cycles of the first version were conflicts.)
-constexpr int kFftWaves = 8;   // one workgroup per CU: 16 KiB of twiddles + 8 x 16.5 KiB (N = 2048)
+constexpr int kFftWaves = 12;  // one workgroup per CU, 3 waves per SIMD: 16 KiB of twiddles + 12 x 8.25 KiB (N = 2048)
 template <int N>
 struct FftLds {
     float2 stw[N - N / 64];
-    float2 buf[kFftWaves][N + 64];   // per wave; reused as the power spectrum (float[N/2]) afterwards
+    float buf[kFftWaves][N + 64];    // per wave (split-component transpose); reused as the power spectrum float[N/2]
+    float win[N / 64][64];           // Hann window at a lane's sample positions
 };
 template <int N>
 __device__ __forceinline__ void fill_stage_twiddles(float2* __restrict__ stw, int tid, int nthreads) {
@@ -297,25 +298,26 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
                                                          float* __restrict__ rowmax_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     FftLds<N>& L = *reinterpret_cast<FftLds<N>*>(lds_raw);
-    fill_stage_twiddles<N>(L.stw, threadIdx.x, kFftWaves * 64);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float2* buf = L.buf[wave];
-    const float* pw = reinterpret_cast<const float*>(buf);
-    float win[N / 64];   // a lane windows the same sample positions in every frame
-    frame_window<N>(lane, win);
-    // frames are dealt to waves round-robin over the whole grid; the next frame's samples are loaded a frame ahead
+    fill_stage_twiddles<N>(L.stw, threadIdx.x, kFftWaves * 64);
+    if (wave == 0) {   // a lane windows the same sample positions in every frame
+        float w0[N / 64];
+        frame_window<N>(lane, w0);
+#pragma unroll
+        for (int i = 0; i < N / 64; i++) L.win[i][lane] = w0[i];
+    }
+    __syncthreads();
+    float2* buf = reinterpret_cast<float2*>(L.buf[wave]);
+    const float* pw = L.buf[wave];
+    // frames are dealt to waves round-robin over the whole grid (three waves per SIMD cover the sample loads)
     const uint32_t k0 = lane < kHkBands ? edges[lane] : 0u, k1 = lane < kHkBands ? edges[lane + 1] : 0u;
     const size_t step = (size_t)gridDim.x * kFftWaves;
-    size_t f = (size_t)blockIdx.x * kFftWaves + wave;
-    float nxt[N / 64];
-    if (f < n_frames) frame_load<N>(x + (first_frame + f) * (size_t)hop, lane, nxt);
-    for (; f < n_frames; f += step) {
-        float smp[N / 64];
+    for (size_t f = (size_t)blockIdx.x * kFftWaves + wave; f < n_frames; f += step) {
+        float smp[N / 64], win[N / 64];
+        frame_load<N>(x + (first_frame + f) * (size_t)hop, lane, smp);
 #pragma unroll
-        for (int i = 0; i < N / 64; i++) smp[i] = nxt[i];
-        if (f + step < n_frames) frame_load<N>(x + (first_frame + f + step) * (size_t)hop, lane, nxt);
-        wave_fft_power_core<N>(smp, win, lane, L.stw, buf);
+        for (int i = 0; i < N / 64; i++) win[i] = L.win[i][lane];
+        wave_fft_power_core<N, true>(smp, win, lane, L.stw, buf);
         {
             // lane b sums band b sequentially (same order as the oracle); eight spectrum reads are in flight at a time
             float e = 0.0f;
@@ -890,7 +892,7 @@ int launch_haitsma(const float* pcm5k, size_t n, const uint32_t* h_edges, uint8_
         const size_t w0 = e0 > 0 ? e0 - 1 : 0;  // one frame of history for the time difference
         const size_t wn = e1 - w0;
         unsigned grid = blocks_for(wn, kFftWaves);
-        if (grid > 256 * 2) grid = 256 * 2;
+        if (grid > 256) grid = 256;
         hipLaunchKernelGGL((stft_power_kernel<kHkN, true>), dim3(grid), dim3(kFftWaves * 64), lds, stream, pcm5k, w0, wn, kHkHop,
                            E, (const uint32_t*)d_edges, (float*)nullptr);
         hipLaunchKernelGGL(haitsma_bits_kernel, dim3(blocks_for(e1 - e0, 256)), dim3(256), 0, stream, E, e0, e1 - e0,

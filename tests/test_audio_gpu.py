@@ -46,10 +46,11 @@ def test_wang_matches_oracle(gpu_ctx, oracle, kind, seconds):
         assert (np.diff(g[:, 1].astype(np.int64)) >= 0).all()   # anchors in time order
 
 
-@pytest.mark.parametrize("frames", [1, 7, 8, 12, 13, 24, 25, 255, 256, 257, 263, 264, 275, 531])
+@pytest.mark.parametrize("frames", [1, 7, 8, 12, 13, 24, 25, 47, 48, 49, 55, 56, 96, 255, 256, 257, 264, 531])
 def test_wang_frame_counts_around_segment_and_round_edges(gpu_ctx, oracle, frames):
-    """The streaming kernel walks segments of 256 frames in rounds of 12 with a +-7-frame halo and judges a frame
-    one round after its window completes: every count near those edges must still give the oracle's landmarks."""
+    """The streaming kernel walks segments (48 frames for inputs this short, up to 512 for hours of audio) in rounds
+    of 12 with a +-7-frame halo and judges a frame one round after its window completes: every count near those
+    edges must still give the oracle's landmarks."""
     from ucfp_amd import audio
     x = _signal("noise", (1024 + 128 * (frames - 1) + 5) / 8000.0, 8000, seed=frames)
     assert 1 + (x.size - 1024) // 128 == frames

@@ -337,8 +337,8 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
 }
 
 // ---- A3 + A5 fused: STFT frames streamed through LDS, peaks picked without spilling the spectrogram ----
-// A workgroup (kSW waves) owns a segment of kSeg consecutive frames and walks it in rounds of kSW frames, one
-// FFT per wave (plus kRT halo frames on each side, recomputed: 14 / kSeg extra).  Of every frame only two
+// A workgroup (kSW waves) owns a segment of `seg` consecutive frames and walks it in rounds of kSW frames, one
+// FFT per wave (plus kRT halo frames on each side, recomputed: 14 / seg extra).  Of every frame only two
 // things survive in LDS:
 //   ring    its +-kRK-bin running maximum ("row maximum"), 2 KiB, in a ring of kRing frames
 //   plist   its row-local peak candidates: bins with P == row maximum > 0 and no equal value among the kRK
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
 // of those 15 row maxima at bin k and none of the EARLIER rows' maxima equals v (an equal cell earlier in
 // (t, k) order wins the tie; rows outside [0, total) duplicate rows inside the window, so they are simply
 // skipped).  HBM sees the samples once and the peaks -- not 2 x 4 B x 512 bins per frame of spilled spectrum.
-constexpr int kSeg = 256;    // frames per workgroup segment
+constexpr int kSegMax = 512;    // frames per workgroup segment: long inputs (halo 14 / 512 = 2.7 %); short ones get
+                                // shorter segments so that ~1000 workgroups exist (wang_segment)
 constexpr int kSW = 12;      // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
 constexpr int kRing = 38;    // >= 2 kRT + 2 kSW: the rows being judged (one round behind) + the rows being produced
 constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
@@ -362,8 +363,15 @@ struct WangStreamLds {
     float pl_v[kRing][kPl];
 };
 
+inline uint32_t wang_segment(size_t frames) {
+    size_t seg = (frames + 1023) / 1024;
+    if (seg < 48) seg = 48;
+    if (seg > (size_t)kSegMax) seg = kSegMax;
+    return (uint32_t)seg;
+}
+
 __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __restrict__ x, size_t total_frames,
-                                                          uint32_t* __restrict__ cand_cnt,
+                                                          uint32_t seg, uint32_t* __restrict__ cand_cnt,
                                                           uint32_t* __restrict__ cand_t,
                                                           uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -381,8 +389,8 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
     float2* buf = reinterpret_cast<float2*>(L.buf[wave]);
     const float* pw = L.buf[wave];
     const long total = (long)total_frames;
-    const long s0 = (long)blockIdx.x * kSeg;                       // frames [s0, s1) are this segment's to judge
-    const long s1 = s0 + kSeg < total ? s0 + kSeg : total;
+    const long s0 = (long)blockIdx.x * seg;                        // frames [s0, s1) are this segment's to judge
+    const long s1 = s0 + seg < total ? s0 + seg : total;
     const long f_lo = s0 - kRT < 0 ? 0 : s0 - kRT;                 // frames [f_lo, f_hi) are computed
     const long f_hi = s1 + kRT < total ? s1 + kRT : total;
     // the Hann window of this lane's 16 sample positions, and the NEXT frame's samples: loaded one round ahead, so
@@ -846,8 +854,9 @@ int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t,
     const size_t lds = sizeof(WangStreamLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wang_stream_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wang_stream_kernel, dim3((unsigned)((w.frames + kSeg - 1) / kSeg)), dim3(kSW * 64), lds, stream, pcm8k,
-                       w.frames, u32(w.cand_cnt), u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
+    const uint32_t seg = wang_segment(w.frames);
+    hipLaunchKernelGGL(wang_stream_kernel, dim3((unsigned)((w.frames + seg - 1) / seg)), dim3(kSW * 64), lds, stream, pcm8k,
+                       w.frames, seg, u32(w.cand_cnt), u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
     hipLaunchKernelGGL(wang_select_kernel, dim3(w.n_sec), dim3(64), 0, stream, u32(w.cand_cnt), u32(w.cand_t),
                        u32(w.cand_k), f32(w.cand_p), pps, u32(w.sel_cnt), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p));
     launch_exclusive_scan(u32(w.sel_cnt), (size_t)w.n_sec, u32(w.sel_off), u32(w.scan_tmp), stream);

@@ -33,13 +33,12 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
 }
 
 template <int NACC, bool RANDOM = false>
-void run(int waves) {
+void run(int waves, int iters = 4000) {
     float* d;
     (void)hipMalloc(&d, 256 * 512 * 4);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    const int iters = 4000;
     k<NACC, RANDOM><<<256, waves * 64>>>(d, iters);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
@@ -57,6 +56,9 @@ void run(int waves) {
 int main() {
     run<1>(4); run<2>(4); run<3>(4); run<4>(4); run<6>(4); run<12>(4);
     run<1>(8); run<2>(8); run<3>(8); run<4>(8); run<6>(8); run<12>(8);
-    run<1, true>(8); run<4, true>(8); run<12, true>(8); run<1, true>(16); run<4, true>(16); run<12, true>(16);
+    run<1, true>(8); run<4, true>(8); run<12, true>(8);
+    // sustained: tens of milliseconds, back to back (power management acts on this scale, not on 1 ms)
+    for (int r = 0; r < 3; r++) run<4, true>(8, 60000);
+    for (int r = 0; r < 2; r++) run<4, false>(8, 60000);
     return 0;
 }

@@ -315,14 +315,17 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
     constexpr int kDma = NG * 2 / kGW;
     static_assert(kDma >= 1, "fewer (group, chunk) pairs than waves");
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const uint32_t lds_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&qsl[0][0][0][lane];
+    // this lane's operand (query nn, dims 4 q4 .. + 4) sits in slot 4 nn + q4 (a 2-way bank conflict on the read)
+    const uint32_t lds_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&qsl[0][0][0][4 * nn + q4];
     auto stage_dma = [&](uint32_t ks, int buf) {
 #pragma unroll
         for (int i = 0; i < kDma; i++) {
             const int idx = wv * kDma + i, g = idx >> 1, ch = idx & 1;
-            uint32_t q = (uint32_t)(g * 16 + nn);
+            // slot l of the 1 KiB chunk holds (query l / 4, dims 4 (l % 4) .. + 4): four consecutive lanes fetch 64
+            // contiguous bytes (with one lane per query the instruction touched 64 lines for 16 B each)
+            uint32_t q = (uint32_t)(g * 16 + (lane >> 2));
             q = q < nq_pass ? q : nq_pass - 1;
-            const float* src = queries + (size_t)q * dim + ks * kGK + 16 * ch + 4 * q4;
+            const float* src = queries + (size_t)q * dim + ks * kGK + 16 * ch + 4 * (lane & 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)&qsl[buf][g][ch][0], 16, 0, 0);
         }

@@ -293,8 +293,8 @@ struct CosineFilter {
     uint32_t cap;
     uint32_t row_base;
 };
-template <int NG, bool FILT>
-__global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cosine_keys_gemm(const float* __restrict__ rows,
+template <int NG, bool FILT, int RT>
+__global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4 / RT, 4 / RT))) void cosine_keys_gemm(const float* __restrict__ rows,
                                                              const float* __restrict__ norms, size_t n, uint32_t dim,
                                                              const float* __restrict__ queries,
                                                              const float* __restrict__ qnorm, uint32_t nq_pass,
@@ -331,15 +331,20 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
         }
     };
     const size_t tiles = (n + 15) / 16;
-    const size_t tstep = (size_t)gridDim.x * kGW;
-    size_t tb = (size_t)blockIdx.x * kGW;
+    // a wave owns RT row tiles (16 rows each) of the workgroup's kGW * RT: with RT = 2 every operand read feeds eight
+    // MFMAs and the query slices are fetched once per 256 rows (the L2 -> LDS stream is what bounds RT = 1)
+    const size_t tstep = (size_t)gridDim.x * kGW * RT;
+    size_t tb = (size_t)blockIdx.x * kGW * RT;
     if (tb >= tiles) return;
-    auto row_ptr = [&](size_t t) {
-        const size_t r = (t + wave) * 16 + nn;
-        return rows + (r < n ? r : 0) * (size_t)dim + 4 * q4;   // dead rows read row 0; their results are not stored
+    auto row_of = [&](size_t t, int r) { return (t + (size_t)wave * RT + r) * 16 + nn; };
+    auto row_ptr = [&](size_t t, int r) {
+        const size_t row = row_of(t, r);
+        return rows + (row < n ? row : 0) * (size_t)dim + 4 * q4;   // dead rows read row 0; their results are not stored
     };
     // row chunks of slices ks and ks + 1 in flight
-    float4 xc[2], xn[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4 xc[RT][2], xn[RT][2];
+#pragma unroll
+    for (int r = 0; r < RT; r++) xn[r][0] = xn[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_x = [&](float4 (&x)[2], const float* __restrict__ v, uint32_t ks) {
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
@@ -351,27 +356,38 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
     // already requests the first slice of the next one (its query slice and this wave's next rows), so the epilogue
     // and the tile change cost no HBM round trip and no extra barrier.
     uint32_t gs = 0;
-    const float* __restrict__ v = row_ptr(tb);
+    const float* __restrict__ v[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) v[r] = row_ptr(tb, r);
     stage_dma(0, 0);
-    load_x(xc, v, 0);
+#pragma unroll
+    for (int r = 0; r < RT; r++) load_x(xc[r], v[r], 0);
     __syncthreads();
     for (; tb < tiles; tb += tstep) {
-        const size_t row = (tb + wave) * 16 + nn;
-        const bool live = row < n;
-        const float vn = norms[live ? row : 0];
         const bool more = tb + tstep < tiles;
-        const float* __restrict__ vnext = row_ptr(more ? tb + tstep : tb);
-        f32x4v acc[NG];
+        const float* __restrict__ vnext[RT];
+        float vn[RT];
 #pragma unroll
-        for (int g = 0; g < NG; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < RT; r++) {
+            const size_t row = row_of(tb, r);
+            vn[r] = norms[row < n ? row : 0];
+            vnext[r] = row_ptr(more ? tb + tstep : tb, r);
+        }
+        f32x4v acc[RT][NG];
+#pragma unroll
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+            for (int g = 0; g < NG; g++) acc[r][g] = f32x4v{0.f, 0.f, 0.f, 0.f};
         for (uint32_t ks = 0; ks < nks; ks++, gs++) {
             const int buf = gs & 1;
             if (ks + 1 < nks) {
                 stage_dma(ks + 1, buf ^ 1);   // last read during the previous slice; every wave passed the barrier since
-                load_x(xn, v, ks + 1);
+#pragma unroll
+                for (int r = 0; r < RT; r++) load_x(xn[r], v[r], ks + 1);
             } else if (more) {
                 stage_dma(0, buf ^ 1);
-                load_x(xn, vnext, 0);
+#pragma unroll
+                for (int r = 0; r < RT; r++) load_x(xn[r], vnext[r], 0);
             }
             // The 2 NG operand reads of the slice are hand-issued two ahead of their MFMAs (a ring of three
             // registers) with counted lgkmcnt waits.  Left to the compiler (128-VGPR budget) every read was followed
@@ -391,33 +407,43 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
                     if (st + 2 < kSteps) lds_wait<2>(q3[st % 3]);
                     else if (st + 1 < kSteps) lds_wait<1>(q3[st % 3]);
                     else lds_wait<0>(q3[st % 3]);
-                    const float4 xv = xc[st / NG];
                     const int g = st % NG;
                     const f32x4v qa = q3[st % 3];
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0], xv.x, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1], xv.y, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[2], xv.z, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[3], xv.w, acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < RT; r++) {
+                        const float4 xv = xc[r][st / NG];
+                        acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0], xv.x, acc[r][g], 0, 0, 0);
+                        acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1], xv.y, acc[r][g], 0, 0, 0);
+                        acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[2], xv.z, acc[r][g], 0, 0, 0);
+                        acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[3], xv.w, acc[r][g], 0, 0, 0);
+                    }
                 }
             }
-            xc[0] = xn[0];
-            xc[1] = xn[1];
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                xc[r][0] = xn[r][0];
+                xc[r][1] = xn[r][1];
+            }
             __syncthreads();
         }
-        v = vnext;
-        if (live) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            v[rt] = vnext[rt];
+            const size_t row = row_of(tb, rt);
+            if (row >= n) continue;
 #pragma unroll
             for (int g = 0; g < NG; g++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint32_t qt = g * 16 + 4 * q4 + r;
                     if (qt < nq_pass) {
+                        const float a = acc[rt][g][r];
                         if constexpr (FILT) {
-                            const float t = flt.uq[qt] * vn;
-                            if (acc[g][r] >= t - fabsf(t) * 0x1p-21f - 0x1p-120f) {
+                            const float t = flt.uq[qt] * vn[rt];
+                            if (a >= t - fabsf(t) * 0x1p-21f - 0x1p-120f) {
                                 const float qn = qnorm[qt];
-                                if (vn != 0.f && qn != 0.f) {
-                                    const float sc = acc[g][r] / (qn * vn);
+                                if (vn[rt] != 0.f && qn != 0.f) {
+                                    const float sc = a / (qn * vn[rt]);
                                     const uint32_t key = sc == sc ? score_to_key(sc) : 0xffffffffu;
                                     if (key != 0xffffffffu && key <= flt.tau[qt]) {
                                         const uint32_t pos = atomicAdd(&flt.ccnt[qt], 1u);
@@ -431,8 +457,8 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))
                         } else {
                             const float qn = qnorm[qt];   // once per 16 rows x 768 dims of matrix work: not worth 4 NG registers
                             uint32_t key = 0xffffffffu;
-                            if (vn != 0.f && qn != 0.f) {
-                                const float sc = acc[g][r] / (qn * vn);
+                            if (vn[rt] != 0.f && qn != 0.f) {
+                                const float sc = a / (qn * vn[rt]);
                                 if (sc == sc) key = score_to_key(sc);
                             }
                             keys[(size_t)qt * n + row] = key;
@@ -488,17 +514,22 @@ template <bool FILT>
 void launch_gemm(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
                  uint32_t nq_pass, uint32_t* keys, const CosineFilter& flt, const uint32_t* run_flag, hipStream_t stream) {
     const size_t tiles = (n + 15) / 16;
-    unsigned grid = (unsigned)((tiles + kGW - 1) / kGW);
-    if (grid > 256 * 2) grid = 256 * 2;
+    auto grid_for = [&](int rt) {
+        unsigned grid = (unsigned)((tiles + kGW * rt - 1) / (kGW * rt));
+        const unsigned cap = 256u * 2u / rt;   // resident workgroups: 128 VGPRs per row tile held
+        return grid > cap ? cap : grid;
+    };
     if (nq_pass <= 64)
-        hipLaunchKernelGGL((cosine_keys_gemm<4, FILT>), dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
-                           qnorm, nq_pass, keys, flt, run_flag);
+        hipLaunchKernelGGL((cosine_keys_gemm<4, FILT, 1>), dim3(grid_for(1)), dim3(kGW * 64), 0, stream, rows, norms, n, dim,
+                           queries, qnorm, nq_pass, keys, flt, run_flag);
     else if (nq_pass <= 128)
-        hipLaunchKernelGGL((cosine_keys_gemm<8, FILT>), dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
-                           qnorm, nq_pass, keys, flt, run_flag);
+        hipLaunchKernelGGL((cosine_keys_gemm<8, FILT, 1>), dim3(grid_for(1)), dim3(kGW * 64), 0, stream, rows, norms, n, dim,
+                           queries, qnorm, nq_pass, keys, flt, run_flag);
     else
-        hipLaunchKernelGGL((cosine_keys_gemm<16, FILT>), dim3(grid), dim3(kGW * 64), 0, stream, rows, norms, n, dim, queries,
-                           qnorm, nq_pass, keys, flt, run_flag);
+        // RT = 2 (32 rows per wave, half the query-slice traffic) measured slower: at 256 VGPRs the compiler spills
+        // inside the slice loop (3.8 vs 3.45 ms per 256 queries over 1 M x 768)
+        hipLaunchKernelGGL((cosine_keys_gemm<16, FILT, 1>), dim3(grid_for(1)), dim3(kGW * 64), 0, stream, rows, norms, n, dim,
+                           queries, qnorm, nq_pass, keys, flt, run_flag);
 }
 
 // tau[q] = the k-th key of the sample's answer (0xffffffff while the sample holds fewer than k scored rows: then

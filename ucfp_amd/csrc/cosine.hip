@@ -435,7 +435,8 @@ __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4 / RT
             for (int g = 0; g < NG; g++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const uint32_t qt = g * 16 + 4 * q4 + r;
+                    uint32_t qt = g * 16 + 4 * q4 + r;
+                    asm volatile("" : "+v"(qt));   // keep the 64 addresses of a tile's results out of the slice loop's registers
                     if (qt < nq_pass) {
                         const float a = acc[rt][g][r];
                         if constexpr (FILT) {
@@ -527,7 +528,7 @@ void launch_gemm(const float* rows, const float* norms, size_t n, uint32_t dim, 
                            queries, qnorm, nq_pass, keys, flt, run_flag);
     else
         // RT = 2 (32 rows per wave, half the query-slice traffic) measured slower: at 256 VGPRs the compiler spills
-        // inside the slice loop (3.8 vs 3.45 ms per 256 queries over 1 M x 768)
+        // (3.7 vs 3.45 ms per 256 queries over 1 M x 768, also with the epilogue addresses kept out of the loop)
         hipLaunchKernelGGL((cosine_keys_gemm<16, FILT, 1>), dim3(grid_for(1)), dim3(kGW * 64), 0, stream, rows, norms, n, dim,
                            queries, qnorm, nq_pass, keys, flt, run_flag);
 }

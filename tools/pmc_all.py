@@ -1,3 +1,10 @@
+"""Digest of a rocprofv3 --pmc run per kernel: LDS occupancy and bank-conflict share, VALU occupancy, wait split.
+
+    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU \
+              SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d <dir> -- python3 bench.py ...
+    python tools/pmc_all.py <dir>
+
+(this is how the audio twiddle-table and the cosine staging bank conflicts of round 1 were found)"""
 import csv, glob, sys
 from collections import defaultdict
 d = sys.argv[1]

@@ -252,6 +252,25 @@ def test_cosine_filtered_pass_overflow_falls_back(gpu_ctx):
     ix.close()
 
 
+def test_cosine_filtered_pass_degenerate_sample(gpu_ctx):
+    """The sample (the first rows of the shard) holds fewer than k scorable rows -- all-zero vectors -- so no
+    threshold exists: every row passes, the lists overflow and the gated dense pass answers.  Also the smallest
+    shard that takes the thresholded pass (2^18 rows) with a ragged tail tile."""
+    from ucfp_amd import index
+    n, dim, nq, k = (1 << 18) + 37, 32, 70, 10
+    rng = np.random.default_rng(11)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[:40_000] = 0.0
+    rows[5] = 1.0                                   # one scorable row inside the sample
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(7)) % np.uint64(1_000_003 * 7)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+    ix.close()
+
+
 def test_cosine_reference_index_tests(gpu_ctx):
     """src/index/embedded/mod.rs:522-589 replayed on GpuIndex with Records."""
     from ucfp_amd import index

@@ -13,7 +13,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "ucfp" not in n: continue
-        n = n.split("(")[0][-60:]
+        n = n.replace("(anonymous namespace)::", "").split("(")[0][-60:]
         tot[n][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE": cnt[n] += 1
 rows = []

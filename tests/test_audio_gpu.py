@@ -99,6 +99,20 @@ def test_wang_long_stream_crosses_chunks(gpu_ctx, oracle, seconds):
     assert g.shape == o.shape and np.array_equal(g, o)
 
 
+def test_wang_hours_long_stream_uses_the_longest_segments(gpu_ctx, oracle):
+    """Beyond 524 288 frames (2.3 h at 8 kHz) a workgroup's segment is capped at 512 frames; bit-exact against the
+    oracle over 2.5 h of noise + tones."""
+    from ucfp_amd import audio
+    rng = np.random.default_rng(3)
+    n = 9000 * 8000
+    t = np.arange(n, dtype=np.float32) * np.float32(1.0 / 8000.0)
+    x = (0.1 * rng.standard_normal(n).astype(np.float32) + 0.2 * np.sin(2 * np.pi * 523.25 * t)).astype(np.float32)
+    assert 1 + (n - 1024) // 128 > 512 * 1024
+    g = audio.wang_hashes(x, 8000, ctx=gpu_ctx)
+    o = oracle.wang(x)
+    assert g.shape == o.shape and g.shape[0] > 100_000 and np.array_equal(g, o)
+
+
 def test_haitsma_long_stream_crosses_chunks(gpu_ctx, oracle):
     """Haitsma chunks hold 131 072 frames (1678 s at 5 kHz) plus one frame of history."""
     from ucfp_amd import audio

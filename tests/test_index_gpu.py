@@ -162,7 +162,11 @@ def test_upsert_overwrite_delete_tenants(gpu_ctx, oracle):
                                         # batches beyond the LDS-resident kernel: the K-sliced GEMM kernel
                                         # (64 / 128 / 256 queries per corpus read, ragged row and query counts)
                                         (3001, 768, 60, 10), (2500, 128, 130, 5), (1777, 64, 300, 3),
-                                        (900, 1024, 257, 10), (4000, 96, 70, 7)])
+                                        (900, 1024, 257, 10), (4000, 96, 70, 7),
+                                        # one to four queries over >= 4096 rows: the row-streaming kernel (1-4
+                                        # 256-dim blocks per lane, ragged last block, ragged last row group)
+                                        (6001, 768, 1, 10), (5003, 384, 2, 10), (4099, 1024, 4, 5), (7000, 100, 3, 10),
+                                        (4097, 256, 1, 1), (9000, 260, 4, 20)])
 def test_cosine_matches_oracle(gpu_ctx, oracle, n, dim, nq, k):
     from ucfp_amd import index
     rng = np.random.default_rng(n + dim)

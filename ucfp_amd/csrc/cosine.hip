@@ -259,6 +259,76 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
     }
 }
 
+// ---- streaming variant for a handful of queries (the reference's own shape: one query per request) ----
+// The MFMA tile above feeds a wave-load with 16 rows x 64 B; for NQ <= 4 queries the matrix pipes do nothing
+// useful and the row stream is all that matters.  Here a wave reads a ROW as contiguous 1 KiB wave-loads (lane l
+// holds dims 256 b + 4 l .. + 4 of block b; the same dims of each query sit in its registers), multiplies, and
+// butterflies the 64 partial sums; four rows per step keep 4 NB KiB in flight per wave.  HBM-bound with
+// ideal coalescing.  dim <= 1024, dim % 4 == 0 (blocks past dim are zero-filled).
+template <int NQ, int NB>
+__global__ __launch_bounds__(256) void cosine_keys_stream(const float* __restrict__ rows, const float* __restrict__ norms,
+                                                          size_t n, uint32_t dim, const float* __restrict__ queries,
+                                                          const float* __restrict__ qnorm, uint32_t nq_pass,
+                                                          uint32_t* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (size_t)gridDim.x * 4;
+    f32x4v q[NQ][NB];
+    float qn[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; t++) {
+        const bool qlive = (uint32_t)t < nq_pass;
+        qn[t] = qlive ? qnorm[t] : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint32_t c = 256u * b + 4u * lane;
+            q[t][b] = (qlive && c < dim) ? *reinterpret_cast<const f32x4v*>(queries + (size_t)t * dim + c)
+                                         : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    constexpr int R = 4;   // rows per step
+    for (size_t r0 = wave * R; r0 < n; r0 += waves * R) {
+        f32x4v x[R][NB];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const size_t row = r0 + i < n ? r0 + i : n - 1;      // a clamped duplicate, not stored
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const uint32_t c = 256u * b + 4u * lane;
+                x[i][b] = c < dim ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(rows + row * (size_t)dim + c))
+                                  : f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        float vn = 0.f;
+        if (lane < R) vn = norms[r0 + lane < n ? r0 + lane : n - 1];
+#pragma unroll
+        for (int t = 0; t < NQ; t++) {
+            float mine = 0.f;   // lane i ends up with row i's dot product
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                float a = 0.f;
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    a = fmaf(x[i][b][0], q[t][b][0], a);
+                    a = fmaf(x[i][b][1], q[t][b][1], a);
+                    a = fmaf(x[i][b][2], q[t][b][2], a);
+                    a = fmaf(x[i][b][3], q[t][b][3], a);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+                if (lane == i) mine = a;
+            }
+            if (lane < R && r0 + lane < n && (uint32_t)t < nq_pass) {
+                uint32_t key = 0xffffffffu;
+                if (vn != 0.f && qn[t] != 0.f) {
+                    const float sc = mine / (qn[t] * vn);
+                    if (sc == sc) key = score_to_key(sc);
+                }
+                keys[(size_t)t * n + r0 + lane] = key;
+            }
+        }
+    }
+}
+
 // ---- GEMM variant for large batches: every query of the pass against the corpus in ONE read of the rows ----
 // The LDS-resident form above holds whole query rows, so 48 queries are all that fit and a batch of 256 reads
 // the corpus six times, each pass sitting on the MFMA/HBM ridge.  Here a wave owns 16 rows x ALL 16*NG queries
@@ -574,6 +644,32 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
     if (n == 0 || nq_pass == 0) return 0;
     if (gemm_path(rows, dim, queries, nq_pass)) {
         launch_gemm<false>(rows, norms, n, dim, queries, qnorm, nq_pass, keys, CosineFilter{}, run_flag, stream);
+        return 0;
+    }
+    if (nq_pass <= 4 && dim % 4 == 0 && dim <= 1024 && (reinterpret_cast<uintptr_t>(rows) & 15u) == 0 &&
+        (reinterpret_cast<uintptr_t>(queries) & 15u) == 0 && n >= 4096) {
+        unsigned grid = (unsigned)((n + 15) / 16);
+        if (grid > 256 * 8) grid = 256 * 8;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, stream, rows, norms, n, dim, queries, qnorm, nq_pass, keys);
+        };
+        const int nb = (int)((dim + 255) / 256);
+        if (nq_pass == 1) {
+            if (nb == 1) go(cosine_keys_stream<1, 1>);
+            else if (nb == 2) go(cosine_keys_stream<1, 2>);
+            else if (nb == 3) go(cosine_keys_stream<1, 3>);
+            else go(cosine_keys_stream<1, 4>);
+        } else if (nq_pass == 2) {
+            if (nb == 1) go(cosine_keys_stream<2, 1>);
+            else if (nb == 2) go(cosine_keys_stream<2, 2>);
+            else if (nb == 3) go(cosine_keys_stream<2, 3>);
+            else go(cosine_keys_stream<2, 4>);
+        } else {
+            if (nb == 1) go(cosine_keys_stream<4, 1>);
+            else if (nb == 2) go(cosine_keys_stream<4, 2>);
+            else if (nb == 3) go(cosine_keys_stream<4, 3>);
+            else go(cosine_keys_stream<4, 4>);
+        }
         return 0;
     }
     if (mfma_ok(rows, dim)) {

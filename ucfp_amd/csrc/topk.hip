@@ -182,6 +182,22 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
     out_ids += (size_t)blockIdx.y * nq * k;
     out_key += (size_t)blockIdx.y * nq * k;
     const uint32_t total = p_n * k;
+    // the k selection rounds run over LDS when the group's candidates fit (they do for the tree's fan-in at the
+    // usual k and for the per-GPU lists after the all-gather): read from global memory in every round, each round
+    // is a chain of dependent L2 round trips -- 28 us per level for 64 lists of 10
+    constexpr uint32_t kStage = 2048;
+    __shared__ uint32_t s_key[kStage];
+    __shared__ uint64_t s_id[kStage];
+    const bool staged = total <= kStage;
+    if (staged) {
+        for (uint32_t c = lane; c < total; c += kWave) {
+            const uint32_t p = c / k, e = c - p * k;
+            const size_t off = ((size_t)p * nq + q) * k + e;
+            s_key[c] = part_key[off];
+            s_id[c] = part_ids[off];
+        }
+        wave_lds_sync();
+    }
     uint32_t ld = 0;
     uint64_t li = 0;
     bool first = true;
@@ -190,10 +206,17 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
         uint32_t bd = 0xffffffffu;
         uint64_t bi = ~0ull;
         for (uint32_t c = lane; c < total; c += kWave) {
-            const uint32_t p = c / k, e = c - p * k;
-            const size_t off = ((size_t)p * nq + q) * k + e;
-            const uint32_t dd = part_key[off];
-            const uint64_t ii = part_ids[off];
+            uint32_t dd;
+            uint64_t ii;
+            if (staged) {
+                dd = s_key[c];
+                ii = s_id[c];
+            } else {
+                const uint32_t p = c / k, e = c - p * k;
+                const size_t off = ((size_t)p * nq + q) * k + e;
+                dd = part_key[off];
+                ii = part_ids[off];
+            }
             if (dd == 0xffffffffu) continue;
             if ((first || key_less(ld, li, dd, ii)) && key_less(dd, ii, bd, bi)) {
                 bd = dd;

@@ -25,17 +25,33 @@ __device__ __forceinline__ bool key_less(uint32_t d1, uint64_t i1, uint32_t d2, 
     return d1 < d2 || (d1 == d2 && i1 < i2);
 }
 
-// wave-wide argmin over (key, id) pairs held one per lane
-__device__ __forceinline__ void wave_argmin(uint32_t& bd, uint64_t& bi) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t od = __shfl_xor(bd, off, kWave);
-        const uint64_t oi = __shfl_xor(bi, off, kWave);
-        if (key_less(od, oi, bd, bi)) {
-            bd = od;
-            bi = oi;
-        }
+// wave-wide argmin over (key, id) pairs held one per lane; every lane returns the winner.  An inclusive DPP scan
+// (row_shr 1, 2, 4, 8, then the row broadcasts 15 and 31) leaves the minimum in lane 63 -- VALU moves only, where a
+// ds_bpermute butterfly pays six dependent LDS-crossbar round trips of three dwords each (the k selection rounds of
+// a merge are nothing but this reduction).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmin_step(uint32_t& bd, uint64_t& bi) {
+    const int od = __builtin_amdgcn_update_dpp(-1, (int)bd, CTRL, ROW_MASK, 0xf, false);
+    const int ol = __builtin_amdgcn_update_dpp(-1, (int)(uint32_t)bi, CTRL, ROW_MASK, 0xf, false);
+    const int oh = __builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(bi >> 32), CTRL, ROW_MASK, 0xf, false);
+    const uint32_t d2 = (uint32_t)od;
+    const uint64_t i2 = ((uint64_t)(uint32_t)oh << 32) | (uint32_t)ol;   // lanes without a source see (max key, max id)
+    if (key_less(d2, i2, bd, bi)) {
+        bd = d2;
+        bi = i2;
     }
+}
+__device__ __forceinline__ void wave_argmin(uint32_t& bd, uint64_t& bi) {
+    argmin_step<0x111, 0xf>(bd, bi);   // row_shr:1
+    argmin_step<0x112, 0xf>(bd, bi);   // row_shr:2
+    argmin_step<0x114, 0xf>(bd, bi);   // row_shr:4
+    argmin_step<0x118, 0xf>(bd, bi);   // row_shr:8   -> lane 15 of every row holds its row's minimum
+    argmin_step<0x142, 0xa>(bd, bi);   // row_bcast:15 into rows 1 and 3
+    argmin_step<0x143, 0xc>(bd, bi);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+    bd = (uint32_t)__builtin_amdgcn_readlane((int)bd, 63);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bi, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bi >> 32), 63);
+    bi = ((uint64_t)hi << 32) | lo;
 }
 }  // namespace
 

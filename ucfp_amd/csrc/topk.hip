@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
 
 SelectPlan select_plan(size_t n, uint32_t nq) {
     SelectPlan p;
-    const uint32_t want_waves = 256 * 64;   // the scan is latency-bound per wave: short slices, many waves
+    const uint32_t want_waves = 256 * 16;   // measured 8 / 16 / 32 / 64 per CU at 16 and 48 queries over 1 M keys: 16 is fastest (longer slices amortise the list warm-up)
     uint32_t slices = nq ? (want_waves + nq - 1) / nq : 1;
     const size_t max_slices = (n + 511) / 512;
     if (slices > max_slices) slices = (uint32_t)(max_slices ? max_slices : 1);

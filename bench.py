@@ -39,7 +39,7 @@ def parse():
                     help="TOTAL 64-bit fingerprints in the sharded Hamming corpus (BASELINE configs[4]: "
                          "100M; split evenly over the ranks = strong scaling). 0 skips the ANN leg")
     ap.add_argument("--ann-queries", type=int, default=4096)
-    ap.add_argument("--ann-steps", type=int, default=5)
+    ap.add_argument("--ann-steps", type=int, default=10)
     ap.add_argument("--rgb-frames", type=int, default=30_000, help="RGB8 512x512 frames for the RGB variant; 0 skips")
     ap.add_argument("--cosine-rows", type=int, default=1_000_000, help="768-d f32 rows per GPU for the cosine leg; 0 skips")
     ap.add_argument("--text-docs", type=int, default=1_000_000, help="4 KiB docs per GPU (BASELINE configs[3]); 0 skips")

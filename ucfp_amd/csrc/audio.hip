@@ -7,10 +7,12 @@
 // library is built with -ffp-contract=off), so the integer outputs are bit-identical.
 //
 //   resample_linear   A1   one thread per output sample
-//   wave_fft_power<N> A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT, 16/32 points per lane
-//                          in registers as (re, im) pairs on packed-f32 instructions, two LDS transposes
+//   wave_fft_power_core<N> A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT, 16/32 points per
+//                          lane in registers as (re, im) pairs on packed-f32 instructions; the first transpose goes
+//                          through LDS, the second runs on v_permlane32/16_swap; stage-major twiddle table
 //   wang_stream       A3+5 Wang: frames streamed through an LDS ring of row maxima, peaks judged in the
-//                          kernel (separable neighbourhood maximum + exact tie rule); nothing is spilled
+//                          kernel one round behind (separable neighbourhood maximum + exact tie rule); nothing
+//                          is spilled
 //   stft_power<2048>  A7   Haitsma: 33 band energies per frame (chunked so the band buffer stays bounded)
 //   wang_select       A5   one wave per second of audio: rank by strength, keep peaks_per_sec,
 //                          order by (t, k)

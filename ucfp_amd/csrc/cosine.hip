@@ -7,16 +7,19 @@
 // NaN case, which the reference leaves to rayon's split order, are fixed here as "ascending
 // record_id" and "NaN scores are dropped".
 //
-// (cosine_keys has two forms: an f32 MFMA tile kernel for dim % 4 == 0, and a VALU kernel for the rest.)
-// Three steps, all streaming:
-//   cosine_norms     |v| per row, once at upsert time (rows are immutable until overwritten)
-//   cosine_keys      one pass over the rows per group of QT queries: 8 lanes share a row
-//                    (8 x 16 B = one 128-B line per row per step, 8 rows per wave instruction),
-//                    query chunks come from LDS by broadcast; the score is mapped to an
-//                    order-preserving u32 key (ascending key = descending score) in a scratch
-//                    matrix keys[q][row].  HBM-bound for QT <= 16: 4*dim bytes per row.
-//   select_topk_u32  (topk.hip) per (slice, query): wave-shared candidate list + threshold
-//   topk_merge_u32   merge of the slices (and of the GPUs after the all-gather)
+// Steps, all streaming:
+//   cosine_norms        |v| per row, once at upsert time (rows are immutable until overwritten)
+//   keys, four forms by batch shape (launch_cosine_keys / launch_cosine_keys_filtered):
+//     cosine_keys_stream<NQ,NB>   1-4 queries, dim <= 1024: a wave reads a row as contiguous 1 KiB loads, the
+//                                 queries sit in registers -- HBM-bound, ideal coalescing
+//     cosine_keys_mfma<G,FULL>    up to 48 queries (dim % 4 == 0): f32 MFMA tile, query rows resident in LDS
+//     cosine_keys_gemm<NG,FILT,RT> batches: 256 queries per corpus read, K slices staged by LDS-DMA; FILT keeps
+//                                 only rows that beat a per-query threshold (candidate lists, no key matrix)
+//     cosine_keys                 VALU kernel for every other shape: 8 lanes share a row, queries from LDS
+//   the score is mapped to an order-preserving u32 key (ascending key = descending score), keys[q][row]
+//   select_topk_u32       (topk.hip) per (slice, query): wave-shared candidate list + threshold
+//   topk_select_lists_u32 (topk.hip) best k of the sample's answer + a candidate list (thresholded pass)
+//   topk_merge_u32        merge of the slices (and of the GPUs after the all-gather)
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -7,8 +7,10 @@
 //                     lane = row (coalesced), ONE wave-shared candidate list in LDS and a
 //                     wave-uniform threshold tau = current k-th key, so after warm-up a wave
 //                     only leaves its load/compare loop for the rare row that beats tau.
-//   topk_merge_u32    one wave per query merges `parts` sorted partial lists; used for the
-//                     slices of one GPU and, after the RCCL all-gather, for the shards of a node.
+//   topk_merge_u32    one wave per query merges `parts` partial lists (k rounds of a DPP wave argmin over
+//                     LDS-staged candidates); used for the slices of one GPU and, after the RCCL all-gather,
+//                     for the shards of a node.
+//   topk_select_lists_u32  one wave per query: best k of a base list + a list of candidate row numbers.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

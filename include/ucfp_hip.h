@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UCFP_ABI_VERSION 1
+#define UCFP_ABI_VERSION 2
 
 /* ---- status codes: map 1:1 onto the reference's Error enum (src/error.rs:9-61,
  *      HTTP mapping src/server/error.rs:22-41) ------------------------------------ */
@@ -299,6 +299,55 @@ int ucfp_index_search_dev(ucfp_index* idx, uint32_t tenant, const void* d_querie
 int ucfp_topk_merge_dev(ucfp_ctx* ctx, int kind, const uint64_t* d_part_ids, const uint32_t* d_part_keys,
                         uint32_t parts, size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
                         uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream);
+
+/* ---- the packed wire format of a sharded search: 16-byte entries {u64 id, u32 key, u32 0}, [nq][k] per shard.
+ * For hosts that move the per-shard lists with their own transport (MPI, gloo, host TCP) instead of RCCL:
+ * pack -> (their all-gather into [parts][nq][k] entries) -> merge_packed. */
+int ucfp_topk_pack_dev(ucfp_ctx* ctx, const uint64_t* d_ids, const uint32_t* d_keys, size_t nq, uint32_t k,
+                       void* d_entries, void* stream);
+int ucfp_topk_merge_packed_dev(ucfp_ctx* ctx, int kind, const void* d_entries, uint32_t parts, size_t nq, uint32_t k,
+                               uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_keys, uint32_t* d_out_counts,
+                               void* stream);
+
+/* ============================ SHARDED SEARCH (multi-GPU) ==============================
+ * "Multi-GPU variant takes a device list; shards are internal" of IndexBackend::knn
+ * (src/index/mod.rs:29-35).  Model: ONE PROCESS PER GPU (the "device list" is the job's ranks: rank r owns GPU
+ * LOCAL_RANK and one ucfp_index holding its range of the corpus, ucfp_shard_range).  Queries are replicated; each
+ * rank scans its shard; the only data-path exchange is ONE ncclAllGather (RCCL over xGMI) of the per-shard top-k
+ * as packed 16-byte entries -- nq x k x 16 B per rank, latency-bound -- then every rank runs the same merge
+ * ((key asc, id asc)) and holds the full answer.  The reference has no multi-device search.
+ *
+ *   rank 0:      ucfp_shard_unique_id(uid)            and ships the 128 bytes to the other ranks (the host's own
+ *                                                     control channel: env, file, TCP -- like ncclUniqueId)
+ *   every rank:  ucfp_shard_comm_create(ctx, uid, rank, world, &comm)     (collective: all ranks call it)
+ *                ucfp_index_search_sharded_dev(idx, comm, ...)            (collective, same nq / k everywhere)
+ * world = 1 needs no uid and never loads RCCL.  RCCL is dlopen()ed (librccl.so.1) when world > 1. */
+#define UCFP_SHARD_UID_BYTES 128
+typedef struct ucfp_shard_comm ucfp_shard_comm;
+int ucfp_shard_unique_id(uint8_t uid[UCFP_SHARD_UID_BYTES]);
+int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES], int rank, int world,
+                           ucfp_shard_comm** out);
+void ucfp_shard_comm_destroy(ucfp_shard_comm* comm);
+/* rank / world / number of all-gathers issued so far (each may be NULL) */
+int ucfp_shard_comm_info(ucfp_shard_comm* comm, int* rank, int* world, uint64_t* exchanges);
+/* [start, end) of a corpus of n_total rows (global insertion order) owned by `rank`: contiguous ranges, the first
+ * n_total % world ranks hold one extra row. */
+void ucfp_shard_range(uint64_t n_total, int rank, int world, uint64_t* start, uint64_t* end);
+
+/* Sharded IndexBackend::knn for a batch (device pointers; queries identical on every rank).
+ * submit: the shard scan is enqueued on `stream`, the all-gather + merge on the communicator's side stream, so the
+ *         exchange of this batch overlaps the scan of the next (two buffer sets: at most two batches in flight).
+ *         Outputs (as ucfp_index_search_dev; d_out_scores / d_out_keys may be NULL) are written by the side stream:
+ *         they and the queries must stay untouched until the ticket is collected.
+ * collect: makes `stream` wait for that batch's results (no host synchronisation).
+ * ucfp_index_search_sharded_dev = submit + collect on the same stream. */
+int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* comm, uint32_t tenant, const void* d_queries,
+                                     size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
+                                     uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream, uint64_t* ticket);
+int ucfp_index_search_sharded_collect(ucfp_shard_comm* comm, uint64_t ticket, void* stream);
+int ucfp_index_search_sharded_dev(ucfp_index* idx, ucfp_shard_comm* comm, uint32_t tenant, const void* d_queries,
+                                  size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
+                                  uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream);
 
 /* BLAKE3-256 (default hash mode) of a HOST buffer: the `exact` digest the reference stores in
  * ImageFingerprint.exact (BLAKE3 of the uploaded bytes). Host code; no device needed. */

@@ -4,7 +4,7 @@
  *
  * The reference's text SDK hashes shingles/tokens with the Xxh3_64 family
  * (src/server/tests.rs:1126-1127; xxhash-rust 0.8.15 in Cargo.lock:6144).  Both the CPU oracle and
- * the HIP kernels include this one header, and tests/test_oracle_text.py checks it against the
+ * the HIP kernels include this one header, and tests/test_oracle_spec.py checks it against the
  * independent `xxhash` Python module for every length class (0, 1-3, 4-8, 9-16, 17-128, 129-240,
  * > 240 bytes).
  *

@@ -16,7 +16,7 @@
  *                                    ascending record_id (redb range-scan order, :300-302),
  *                                    kept to show both agree whenever scores are distinct.
  * Pinned by the reference's own tests (src/index/embedded/mod.rs:522-589,
- * src/server/tests.rs:53-113), replayed in tests/test_oracle_index.py.
+ * src/server/tests.rs:53-113), replayed in tests/test_reference_pins.py (oracle) and tests/test_index_gpu.py (HIP path).
  *
  * HAMMING: the reference has no Hamming search -> nothing to pin; this is the
  * specification itself: d = popcount(q ^ x), order (d asc, id asc).

@@ -31,7 +31,7 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_abi_version_and_record_sizes():
     lib = _lib.load()
-    assert lib.ucfp_abi_version() == 1
+    assert lib.ucfp_abi_version() == 2
     # pinned by the reference: 536-B bundle (src/server/tests.rs:1206), 168-B single
     # (web/src/lib/components/charts/algorithmView.ts:11-17)
     assert lib.ucfp_image_record_bytes(7) == 536

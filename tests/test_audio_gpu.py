@@ -90,8 +90,8 @@ def test_wang_config_variants(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("seconds", [75.0, 530.0, 1100.0])
 def test_wang_long_stream_crosses_chunks(gpu_ctx, oracle, seconds):
-    """The spilled spectrogram is processed in chunks of 32 768 frames (524 s) with a +-7-frame halo;
-    530 s crosses one chunk boundary, 1100 s two. Bit-exact against the (unchunked) oracle."""
+    """Long streams: the stream kernel walks 256-frame segments with a +-7-frame halo and the per-second cap,
+    scan and pairing stages span many workgroups.  Bit-exact against the (unsegmented) oracle."""
     from ucfp_amd import audio
     x = _signal("chirps", seconds, 8000, seed=9)
     g = audio.wang_hashes(x, 8000, ctx=gpu_ctx)

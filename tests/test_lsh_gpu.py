@@ -7,11 +7,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _records(slots):
-    """uint64 [n, 128] -> 1032-byte MinHash records (8-byte header: version 1, H = 128)."""
+    """uint64 [n, 128] -> 1032-byte MinHash records (header: u16 schema = 1, six zero pad bytes)."""
     n = slots.shape[0]
     rec = np.zeros((n, 1032), np.uint8)
     rec[:, 0] = 1
-    rec[:, 4] = 128
     rec[:, 8:] = np.ascontiguousarray(slots, dtype="<u8").view(np.uint8).reshape(n, 1024)
     return rec
 

@@ -61,12 +61,21 @@ def test_minhash_golden_prefix_of_reference(oracle):
     assert rec[0, :16].tobytes().hex() == "0100000000000000a26accc88c8a8106"   # tests.rs:1153-1157
 
 
-def test_minhash_config_hash_pin():
+def test_default_config_hash_is_a_carried_constant_not_a_pin():
+    """tests.rs:1158-1161 shows txtfp::config_hash for ONE configuration; the function itself is unavailable and
+    unrecovered, so the value is carried verbatim -- this test only guards the constant and that
+    nothing is invented for any other configuration."""
     from ucfp_amd import text
+    from ucfp_amd.errors import UnsupportedError
     opts = text.TextOpts()
-    assert text.config_hash(opts.canonicalizer, opts.tokenizer_tag(), text.ALGORITHM_MINHASH_128) == \
-        2_212_816_233_060_047_056                                      # tests.rs:1158-1161
     assert opts.tokenizer_tag() == "shingle-k=5/word-uax29"            # text.rs:152-159
+    assert text.config_hash(opts.canonicalizer, opts.tokenizer_tag(), text.ALGORITHM_MINHASH_128) == \
+        2_212_816_233_060_047_056
+    for canon, tag, alg in ((text.Canonicalizer(normalization="nfc"), opts.tokenizer_tag(), text.ALGORITHM_MINHASH_128),
+                            (opts.canonicalizer, "shingle-k=3/word-uax29", text.ALGORITHM_MINHASH_128),
+                            (opts.canonicalizer, "word-uax29", text.ALGORITHM_SIMHASH_TF)):
+        with pytest.raises(UnsupportedError):
+            text.config_hash(canon, tag, alg)
 
 
 def test_simhash_is_8_bytes(oracle):

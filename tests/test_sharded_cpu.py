@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: two gloo ranks exercise the sharding rule and the all-gather plumbing of
-ucfp_amd/sharded.py.  The gathered [parts][nq][k] tensors are merged here by a numpy checker with
-the specified order (key asc, id asc) and compared with the oracle over the whole corpus; on the
-GPU box the same tensors feed ucfp_topk_merge_dev (tests/test_index_gpu.py covers that kernel)."""
+"""N > 1 path on CPU: two gloo ranks exercise the sharding rule and the wire format of the sharded search
+(ucfp_amd/sharded.py: packed 16-byte entries, ONE all-gather into [parts][nq][k]).  The gathered entries are
+merged here by a numpy checker with the specified order (key asc, id asc) and compared with the oracle over the
+whole corpus; on the GPU box the same entries feed ucfp_topk_merge_packed_dev, and the RCCL path inside the library
+(ucfp_index_search_sharded_*) is exercised at world = 1 (tests/test_sharded_gpu.py)."""
 import os
 import socket
 
@@ -33,11 +34,12 @@ def _worker(rank, world, port, n, nq, k, ret):
         s, e = sharded.shard_range(n, rank, world)
         # local top-k of this rank's shard (the oracle stands in for the HIP search on CPU)
         l_ids, l_d, _ = oracle.hamming_topk(ids[s:e], codes[s:e], queries, k)
-        g_ids, g_keys = sharded.all_gather_topk(torch.from_numpy(l_ids.view(np.int64)),
-                                                torch.from_numpy(l_d.view(np.int32)))
-        assert g_ids.shape == (world, nq, k) and g_keys.shape == (world, nq, k)
-        gi = g_ids.numpy().view(np.uint64)
-        gk = g_keys.numpy().view(np.uint32)
+        ent = sharded.pack_entries(l_ids, l_d)
+        assert ent.shape == (nq, k, 2) and ent.dtype == np.int64 and ent.nbytes == nq * k * sharded.ENTRY_BYTES
+        g = sharded.all_gather_entries(torch.from_numpy(ent))            # ONE collective
+        assert g.shape == (world, nq, k, 2)
+        gi, gk = sharded.unpack_entries(g.numpy())
+        assert np.array_equal(gi[rank], l_ids) and np.array_equal(gk[rank], l_d)      # own slot = own list
         merged_ids = np.zeros((nq, k), np.uint64)
         merged_d = np.zeros((nq, k), np.uint32)
         for q in range(nq):
@@ -57,10 +59,16 @@ def _worker(rank, world, port, n, nq, k, ret):
 
 
 def test_shard_range_partitions_exactly():
-    from ucfp_amd import sharded
+    import ctypes as C
+    from ucfp_amd import _lib, sharded
+    lib = _lib.load()
     for n in (0, 1, 7, 8, 100, 12_500_001):
         for world in (1, 2, 3, 8):
             spans = [sharded.shard_range(n, r, world) for r in range(world)]
+            for r in range(world):       # the C rule (ucfp_shard_range) is the same rule
+                a, b = C.c_uint64(0), C.c_uint64(0)
+                lib.ucfp_shard_range(n, r, world, C.byref(a), C.byref(b))
+                assert (a.value, b.value) == spans[r]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [e - s for s, e in spans]
@@ -78,3 +86,14 @@ def test_two_rank_gloo_allgather_merge_matches_global():
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+def test_wire_format_is_16_little_endian_bytes():
+    from ucfp_amd import sharded
+    ids = np.array([[0x0102030405060708, 0xFFFFFFFFFFFFFFFF]], np.uint64)
+    keys = np.array([[7, 0xFFFFFFFF]], np.uint32)
+    raw = sharded.pack_entries(ids, keys).tobytes()
+    assert raw[:16] == bytes([8, 7, 6, 5, 4, 3, 2, 1, 7, 0, 0, 0, 0, 0, 0, 0])
+    assert raw[16:] == b"\xff" * 12 + b"\0" * 4
+    i2, k2 = sharded.unpack_entries(sharded.pack_entries(ids, keys))
+    assert np.array_equal(i2, ids) and np.array_equal(k2, keys)

@@ -92,6 +92,20 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t,
                                       C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_topk_pack_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "ucfp_topk_merge_packed_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_shard_unique_id": (C.c_int, [C.c_void_p]),
+    "ucfp_shard_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ucfp_shard_comm_destroy": (None, [C.c_void_p]),
+    "ucfp_shard_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "ucfp_shard_range": (None, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ucfp_index_search_sharded_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                                   C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.POINTER(C.c_uint64)]),
+    "ucfp_index_search_sharded_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ucfp_index_search_sharded_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_image_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                             C.POINTER(ImagePreprocess), C.c_size_t, C.c_uint32,
                                             C.POINTER(C.c_void_p)]),
@@ -165,6 +179,21 @@ class Context:
 
 
 _default_ctx = {}
+
+
+def current_device() -> int:
+    """The device this process works on: torch's current device when torch has one selected (one process per GPU:
+    the launcher did `torch.cuda.set_device(LOCAL_RANK)`), else LOCAL_RANK, else 0."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        return int(torch.cuda.current_device())
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def current_context() -> "Context":
+    """Default context of the CURRENT device (never silently device 0 on a rank > 0)."""
+    return default_context(current_device())
 
 
 def default_context(device: int = 0) -> Context:

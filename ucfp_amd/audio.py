@@ -54,7 +54,7 @@ def _check_rate(sample_rate: int):
 
 def wang_hashes(samples, sample_rate: int, cfg: Optional[WangConfig] = None, ctx=None) -> np.ndarray:
     """-> uint32 [n, 2]: (packed hash, t_anchor) -- the byte image of audiofp's [WangHash]."""
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     _check_rate(sample_rate)
     x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
     c = (cfg or WangConfig())._c()
@@ -68,7 +68,7 @@ def wang_hashes(samples, sample_rate: int, cfg: Optional[WangConfig] = None, ctx
 
 
 def haitsma_frames(samples, sample_rate: int, cfg: Optional[HaitsmaConfig] = None, ctx=None) -> np.ndarray:
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     _check_rate(sample_rate)
     x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
     c = (cfg or HaitsmaConfig())._c()

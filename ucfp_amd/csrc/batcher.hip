@@ -25,7 +25,9 @@
 namespace ucfp {
 int capi_fail(int code, const char* fmt, ...);
 int ctx_device(const ucfp_ctx* ctx);
-uint8_t* ctx_norm_ws(const ucfp_ctx* ctx, size_t* frames);
+int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t n, uint32_t w, uint32_t h,
+                       size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim, uint32_t max_dim,
+                       const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t stream);
 }  // namespace ucfp
 using ucfp::capi_fail;
 
@@ -91,14 +93,10 @@ void worker_loop(ucfp_image_batcher* b) {
         int rc = UCFP_OK;
         hipError_t e = hipMemcpyAsync(b->d_in, b->h_in[s], n * b->frame_bytes, hipMemcpyHostToDevice, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_exact, b->h_exact[s], n * 32, hipMemcpyHostToDevice, b->stream);
-        if (e == hipSuccess) {
-            size_t ws_frames = 0;
-            uint8_t* ws = ucfp::ctx_norm_ws(b->ctx, &ws_frames);
-            ucfp::launch_image_hash(b->algo, b->d_in, n, b->width, b->height, b->d_row, b->frame_bytes, b->pixfmt,
-                                    b->pre.min_dimension, b->pre.max_dimension, b->d_exact, b->d_out, b->d_status, ws,
-                                    ws_frames, b->stream);
-            e = hipGetLastError();
-        }
+        if (e == hipSuccess)
+            e = (hipError_t)ucfp::image_hash_ordered(b->ctx, b->algo, b->d_in, n, b->width, b->height, b->d_row,
+                                                     b->frame_bytes, b->pixfmt, b->pre.min_dimension,
+                                                     b->pre.max_dimension, b->d_exact, b->d_out, b->d_status, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(b->h_out[s], b->d_out, n * b->rec, hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(b->h_status[s], b->d_status, n * 4, hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(b->stream);

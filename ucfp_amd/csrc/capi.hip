@@ -46,7 +46,9 @@ constexpr size_t kNormWsFrames = 2048;  // generic-geometry normalised planes he
 
 struct ucfp_ctx {
     int device = 0;
-    uint8_t* norm_ws = nullptr;  // kNormWsFrames x 65536
+    uint8_t* norm_ws = nullptr;  // kNormWsFrames x 65536: ONE scratch area shared by every generic-geometry launch,
+    std::mutex norm_mu;          // so its users are ordered across streams: enqueue under norm_mu, wait on / record
+    hipEvent_t norm_done = nullptr;  // norm_done around the launch (ucfp::image_hash_ordered)
     // host-variant staging (grown on demand), guarded by `mu`
     std::mutex mu;
     uint8_t* stage_in = nullptr;
@@ -77,9 +79,25 @@ int grow(uint8_t** p, size_t* cap, size_t need) {
 
 namespace ucfp {
 int ctx_device(const ucfp_ctx* ctx) { return ctx->device; }
-uint8_t* ctx_norm_ws(const ucfp_ctx* ctx, size_t* frames) {
-    *frames = kNormWsFrames;
-    return ctx->norm_ws;
+// Every image launch of the library goes through here.  The fused kernels touch no shared state; a geometry that
+// normalises into ctx->norm_ws first waits (on `stream`) for the previous user of that workspace -- whatever stream
+// it ran on -- and leaves its own completion event behind.  The caller has already selected ctx->device.
+int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t n, uint32_t w, uint32_t h,
+                       size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim, uint32_t max_dim,
+                       const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t stream) {
+    if (!image_hash_needs_ws(frames, w, h, row_stride, frame_stride, pixfmt, min_dim, max_dim)) {
+        launch_image_hash(algo, frames, n, w, h, row_stride, frame_stride, pixfmt, min_dim, max_dim, exact, out, status,
+                          ctx->norm_ws, kNormWsFrames, stream);
+        return (int)hipGetLastError();
+    }
+    std::lock_guard<std::mutex> lk(ctx->norm_mu);
+    hipError_t e = hipStreamWaitEvent(stream, ctx->norm_done, 0);
+    if (e != hipSuccess) return (int)e;
+    launch_image_hash(algo, frames, n, w, h, row_stride, frame_stride, pixfmt, min_dim, max_dim, exact, out, status,
+                      ctx->norm_ws, kNormWsFrames, stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return (int)hipEventRecord(ctx->norm_done, stream);
 }
 }  // namespace ucfp
 
@@ -111,6 +129,7 @@ int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
     hipError_t e2 = hipMalloc((void**)&c->norm_ws, kNormWsFrames * 65536);
     if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->audio_done, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->norm_done, hipEventDisableTiming);
     if (e2 != hipSuccess) {
         ucfp_ctx_destroy(c);
         return fail(UCFP_E_INDEX, "context allocation failed: %s", hipGetErrorString(e2));
@@ -128,6 +147,7 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->host_stream) (void)hipStreamDestroy(c->host_stream);
     if (c->audio_ws) (void)hipFree(c->audio_ws);
     if (c->audio_done) (void)hipEventDestroy(c->audio_done);
+    if (c->norm_done) (void)hipEventDestroy(c->norm_done);
     delete c;
 }
 
@@ -164,10 +184,9 @@ int ucfp_image_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frame
     if (rc) return rc;
     const uint32_t min_dim = pre ? pre->min_dimension : 32u;
     const uint32_t max_dim = pre ? pre->max_dimension : 8192u;
-    ucfp::launch_image_hash(algo, frames, n, width, height, row_stride, frame_stride, pixfmt,
-                            min_dim, max_dim, exact, out, status, ctx->norm_ws, kNormWsFrames,
-                            (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, frames, n, width, height, row_stride, frame_stride, pixfmt,
+                                                 min_dim, max_dim, exact, out, status, (hipStream_t)stream));
     return UCFP_OK;
 }
 
@@ -207,10 +226,8 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
     if (exact) HIP_TRY(hipMemcpyAsync(d_exact, exact, n * 32, hipMemcpyHostToDevice, st));
     const uint32_t min_dim = pre ? pre->min_dimension : 32u;
     const uint32_t max_dim = pre ? pre->max_dimension : 8192u;
-    ucfp::launch_image_hash(algo, ctx->stage_in, n, width, height, d_row, d_frame, pixfmt, min_dim,
-                            max_dim, exact ? d_exact : nullptr, d_out, d_status, ctx->norm_ws,
-                            kNormWsFrames, st);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, ctx->stage_in, n, width, height, d_row, d_frame, pixfmt,
+                                                 min_dim, max_dim, exact ? d_exact : nullptr, d_out, d_status, st));
     HIP_TRY(hipMemcpyAsync(out, d_out, n * rec, hipMemcpyDeviceToHost, st));
     if (status) HIP_TRY(hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -27,6 +27,8 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
                       size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim,
                       uint32_t max_dim, const uint8_t* exact, uint8_t* out, int32_t* status,
                       uint8_t* norm_ws, size_t norm_ws_frames, hipStream_t stream);
+bool image_hash_needs_ws(const uint8_t* frames, uint32_t w, uint32_t h, size_t row_stride, size_t frame_stride,
+                         int pixfmt, uint32_t min_dim, uint32_t max_dim);
 int launch_image_record_codes(const uint8_t* records, size_t n, uint32_t rec_bytes, uint32_t offset, uint64_t* codes,
                               hipStream_t stream);
 int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,
@@ -78,6 +80,10 @@ constexpr uint32_t kCosineListCap = 1024;   // candidates kept per query by the 
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts,
                           uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key,
                           uint32_t* out_cnt, const uint32_t* run_flag, hipStream_t stream);
+// wire format of the sharded search: 16-byte entries {id u64, key u32, pad u32}
+int launch_topk_pack_entries(const uint64_t* ids, const uint32_t* keys, size_t total, void* entries, hipStream_t stream);
+int launch_topk_merge_packed(const void* entries, uint32_t parts, uint32_t nq, uint32_t k, uint64_t* out_ids,
+                             uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream);
 // tree merge (fan-in 64 per level); tmp_* hold 2 x topk_merge_tmp_entries(parts, nq, k) entries
 size_t topk_merge_tmp_entries(uint32_t parts, uint32_t nq, uint32_t k);
 int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,

@@ -855,6 +855,21 @@ static inline bool aligned16(const void* p, size_t a, size_t b) {
     return (((uintptr_t)p | a | b) & 15u) == 0;
 }
 
+// true when a batch of this geometry goes through the normalise-into-workspace path (everything that is not one of
+// the fused kernels below): the caller must then order its use of the shared workspace against other streams.
+bool image_hash_needs_ws(const uint8_t* frames, uint32_t w, uint32_t h, size_t row_stride, size_t frame_stride,
+                         int pixfmt, uint32_t min_dim, uint32_t max_dim) {
+    if (w < min_dim || h < min_dim || w > max_dim || h > max_dim) return false;
+    const bool square = (w == h) && (w % 256 == 0);
+    const uint32_t S = square ? w / 256 : 0;
+    if (pixfmt == 0 && aligned16(frames, row_stride, frame_stride) && (S == 1 || S == 2 || S == 4)) return false;
+    if (S == 1 && pixfmt != 0 && (((uintptr_t)frames | row_stride | frame_stride) & 7u) == 0) return false;
+    if (S == 2 && ((pixfmt == 2 && aligned16(frames, row_stride, frame_stride)) ||
+                   (pixfmt == 1 && (((uintptr_t)frames | row_stride | frame_stride) & 3u) == 0)))
+        return false;
+    return true;
+}
+
 int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w, uint32_t h,
                       size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim,
                       uint32_t max_dim, const uint8_t* exact, uint8_t* out, int32_t* status,

@@ -101,8 +101,17 @@ struct ucfp_index {
     hipStream_t stream = nullptr;  // host-pointer entry points run here
     DevBuf ws;                     // search workspace (partials, keys, ...)
     hipEvent_t ws_done = nullptr;  // orders successive searches' use of `ws` across streams
+    // Mutations and searches may run on different streams: a mutation first waits for every search enqueued so far
+    // (ws_done: none may still be reading rows that are overwritten, swapped or re-allocated) and leaves `data_ready`
+    // behind; a search waits for `data_ready` (rows appended on another stream have landed).
+    hipEvent_t data_ready = nullptr;
     DevBuf stage;                  // host<->device staging
 };
+
+namespace ucfp {
+int index_kind(const ucfp_index* ix) { return ix->kind; }
+int index_device(const ucfp_index* ix) { return ix->device; }
+}  // namespace ucfp
 
 namespace {
 
@@ -341,6 +350,7 @@ int ucfp_index_create(ucfp_ctx* ctx, int kind, uint32_t dim, uint32_t flags, ucf
     hipError_t e = hipSetDevice(ix->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ws_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->data_ready, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete ix;
         return capi_fail(UCFP_E_INDEX, "index stream creation failed: %s", hipGetErrorString(e));
@@ -362,6 +372,7 @@ void ucfp_index_destroy(ucfp_index* ix) {
     ix->stage.release();
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     if (ix->ws_done) (void)hipEventDestroy(ix->ws_done);
+    if (ix->data_ready) (void)hipEventDestroy(ix->data_ready);
     delete ix;
 }
 
@@ -373,6 +384,8 @@ int ucfp_index_upsert(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, cons
     HIP_TRY(hipSetDevice(ix->device));
     Shard& s = ix->shards[tenant];
     hipStream_t st = ix->stream;
+    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));
     const bool mapped = !(ix->flags & UCFP_INDEX_APPEND_ONLY);
     // resolve target rows on the host; within a batch the LAST occurrence of an id wins
     std::vector<uint64_t> dst(n);
@@ -428,6 +441,7 @@ int ucfp_index_upsert(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, cons
                            m, s.norms);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ix->data_ready, st));
     HIP_TRY(hipStreamSynchronize(st));  // staging vectors are stack-owned
     if (mapped) {
         s.host_ids.resize(new_n);
@@ -451,6 +465,8 @@ int ucfp_index_append_dev(ucfp_index* ix, uint32_t tenant, const uint64_t* d_ids
     HIP_TRY(hipSetDevice(ix->device));
     Shard& s = ix->shards[tenant];
     hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));   // an earlier mutation on another stream (growth copies the rows)
     int rc = shard_reserve(ix, s, s.n + n, st);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(s.ids + s.n, d_ids, n * 8, hipMemcpyDeviceToDevice, st));
@@ -459,6 +475,7 @@ int ucfp_index_append_dev(ucfp_index* ix, uint32_t tenant, const uint64_t* d_ids
         ucfp::launch_cosine_norms(reinterpret_cast<const float*>(s.rows + s.n * ix->row_bytes), n, ix->dim,
                                   s.norms + s.n, st);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ix->data_ready, st));
     s.n += n;
     return UCFP_OK;
 }
@@ -475,6 +492,8 @@ int ucfp_index_delete(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, size
     Shard& s = sit->second;
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = ix->stream;
+    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));
     size_t removed = 0;
     for (size_t i = 0; i < n; i++) {
         auto it = s.pos.find(ids[i]);
@@ -494,6 +513,7 @@ int ucfp_index_delete(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, size
         s.n--;
         removed++;
     }
+    HIP_TRY(hipEventRecord(ix->data_ready, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (n_removed) *n_removed = removed;
     return UCFP_OK;
@@ -617,6 +637,7 @@ int ucfp_index_search_dev(ucfp_index* ix, uint32_t tenant, const void* d_queries
     const Shard* s = it == ix->shards.end() ? nullptr : &it->second;
     // the workspace is shared: a search may start only after the previous one (on any stream) is done
     HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));
     rc = search_shard_dev(ix, s, d_queries, nq, k, d_out_ids, d_out_scores, d_out_dist, d_out_counts, st);
     HIP_TRY(hipEventRecord(ix->ws_done, st));
     return rc;

@@ -182,6 +182,9 @@ __global__ __launch_bounds__(64) void select_topk_u32(const uint32_t* __restrict
 
 // One wave per query. parts x k candidates; invalid entries carry key 0xffffffff.
 // Output: best k by (key, id) ascending, each (key, id) pair emitted once.
+// PACKED: the lists are 16-byte entries {id u64, key u32, pad u32} (the wire format of the sharded search: what ONE
+// all-gather moves, see shard.hip); `part_ids` then points at the entries and `part_key` is unused.
+template <bool PACKED>
 __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict__ part_ids,
                                                      const uint32_t* __restrict__ part_key,
                                                      uint32_t parts, uint32_t nq, uint32_t k,
@@ -195,8 +198,9 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
     // blockIdx.y = group of `group_parts` consecutive parts (tree merge: one output list per group and query)
     const uint32_t p_lo = blockIdx.y * group_parts;
     const uint32_t p_n = parts - p_lo < group_parts ? parts - p_lo : group_parts;
+    const uint4* __restrict__ part_ent = reinterpret_cast<const uint4*>(part_ids) + (size_t)p_lo * nq * k;
     part_ids += (size_t)p_lo * nq * k;
-    part_key += (size_t)p_lo * nq * k;
+    if (!PACKED) part_key += (size_t)p_lo * nq * k;
     out_ids += (size_t)blockIdx.y * nq * k;
     out_key += (size_t)blockIdx.y * nq * k;
     const uint32_t total = p_n * k;
@@ -211,8 +215,14 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
         for (uint32_t c = lane; c < total; c += kWave) {
             const uint32_t p = c / k, e = c - p * k;
             const size_t off = ((size_t)p * nq + q) * k + e;
-            s_key[c] = part_key[off];
-            s_id[c] = part_ids[off];
+            if (PACKED) {
+                const uint4 en = part_ent[off];
+                s_key[c] = en.z;
+                s_id[c] = ((uint64_t)en.y << 32) | en.x;
+            } else {
+                s_key[c] = part_key[off];
+                s_id[c] = part_ids[off];
+            }
         }
         wave_lds_sync();
     }
@@ -232,8 +242,14 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
             } else {
                 const uint32_t p = c / k, e = c - p * k;
                 const size_t off = ((size_t)p * nq + q) * k + e;
-                dd = part_key[off];
-                ii = part_ids[off];
+                if (PACKED) {
+                    const uint4 en = part_ent[off];
+                    dd = en.z;
+                    ii = ((uint64_t)en.y << 32) | en.x;
+                } else {
+                    dd = part_key[off];
+                    ii = part_ids[off];
+                }
             }
             if (dd == 0xffffffffu) continue;
             if ((first || key_less(ld, li, dd, ii)) && key_less(dd, ii, bd, bi)) {
@@ -363,8 +379,33 @@ int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, ui
                           uint32_t k, uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt,
                           const uint32_t* run_flag, hipStream_t stream) {
     if (nq == 0) return 0;
-    hipLaunchKernelGGL(topk_merge_u32, dim3(nq), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, out_ids,
+    hipLaunchKernelGGL(topk_merge_u32<false>, dim3(nq), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, out_ids,
                        out_key, out_cnt, run_flag, parts);
+    return 0;
+}
+
+// ---- the sharded search's wire format: one 16-byte entry per (query, place) ----
+__global__ void topk_pack_entries_kernel(const uint64_t* __restrict__ ids, const uint32_t* __restrict__ keys, size_t total,
+                                         uint4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t id = ids[i];
+    out[i] = make_uint4((uint32_t)id, (uint32_t)(id >> 32), keys[i], 0u);
+}
+
+int launch_topk_pack_entries(const uint64_t* ids, const uint32_t* keys, size_t total, void* entries, hipStream_t stream) {
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(topk_pack_entries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids, keys,
+                       total, reinterpret_cast<uint4*>(entries));
+    return 0;
+}
+
+// merge `parts` packed lists ([parts][nq][k] entries, as all-gathered) into the final (ids, keys, counts)
+int launch_topk_merge_packed(const void* entries, uint32_t parts, uint32_t nq, uint32_t k, uint64_t* out_ids,
+                             uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(topk_merge_u32<true>, dim3(nq), dim3(64), 0, stream, reinterpret_cast<const uint64_t*>(entries),
+                       (const uint32_t*)nullptr, parts, nq, k, out_ids, out_key, out_cnt, (const uint32_t*)nullptr, parts);
     return 0;
 }
 
@@ -382,7 +423,7 @@ int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_ke
     if (parts <= kMergeFan)
         return launch_topk_merge_u32(part_ids, part_key, parts, nq, k, out_ids, out_key, out_cnt, run_flag, stream);
     const uint32_t groups = (parts + kMergeFan - 1) / kMergeFan;
-    hipLaunchKernelGGL(topk_merge_u32, dim3(nq, groups), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, tmp_ids,
+    hipLaunchKernelGGL(topk_merge_u32<false>, dim3(nq, groups), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, tmp_ids,
                        tmp_key, (uint32_t*)nullptr, run_flag, kMergeFan);
     return launch_topk_merge_tree_u32(tmp_ids, tmp_key, groups, nq, k, tmp_ids + (size_t)groups * nq * k,
                                       tmp_key + (size_t)groups * nq * k, out_ids, out_key, out_cnt, stream, run_flag);

@@ -65,7 +65,7 @@ def fingerprint_frames_dev(frames_ptr: int, n: int, width: int, height: int, *, 
                            preprocess: Optional[PreprocessConfig] = None, ctx=None) -> None:
     """Enqueue hashing of `n` device-resident frames; raw device addresses, no sync.
     `stream` is a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream)."""
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     bpp = _BPP[pixfmt]
     rs = row_stride if row_stride is not None else width * bpp
     fs = frame_stride if frame_stride is not None else rs * height
@@ -78,7 +78,7 @@ def fingerprint_frames_dev(frames_ptr: int, n: int, width: int, height: int, *, 
 def record_codes_dev(records_ptr: int, n: int, codes_ptr: int, *, algo: int = MULTI, which: int = PHASH,
                      stream: int = 0, ctx=None) -> None:
     """Device records (168 / 536 B each) -> their 64-bit global hashes, ready for DeviceIndex.append_dev."""
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     _lib.check(_lib.load().ucfp_image_record_codes_dev(ctx.handle, records_ptr, n, algo, which, codes_ptr,
                                                        stream or None))
 
@@ -88,7 +88,7 @@ def fingerprint_frames(frames: np.ndarray, *, algo: int = MULTI, pixfmt: int = P
                        preprocess: Optional[PreprocessConfig] = None, ctx=None):
     """Hash host-resident decoded frames [n, h, w(, c)] uint8 through the host-pointer ABI.
     Returns (records uint8 [n, record_bytes], status int32 [n])."""
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     if frames.ndim < 3:
         raise ModalityError("frames must be [n, h, w] or [n, h, w, c]")
@@ -198,7 +198,7 @@ class ImageBatcher:
                  max_batch: int = 512, max_delay_us: int = 200, preprocess: Optional[PreprocessConfig] = None,
                  ctx=None):
         self._lib = _lib.load()
-        self.ctx = ctx or _lib.default_context()
+        self.ctx = ctx or _lib.current_context()
         self.width, self.height, self.algo, self.pixfmt = width, height, algo, pixfmt
         self.rec = record_bytes(algo)
         pre = (preprocess or PreprocessConfig())._c()

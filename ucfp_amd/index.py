@@ -32,7 +32,7 @@ class DeviceIndex:
 
     def __init__(self, kind: int, dim: int = 0, flags: int = 0, ctx=None):
         self._lib = _lib.load()
-        self.ctx = ctx or _lib.default_context()
+        self.ctx = ctx or _lib.current_context()
         self.kind, self.dim, self.flags = kind, dim, flags
         h = C.c_void_p()
         _lib.check(self._lib.ucfp_index_create(self.ctx.handle, kind, dim, flags, C.byref(h)))
@@ -116,7 +116,7 @@ class DeviceIndex:
 def topk_merge_dev(kind: int, part_ids_ptr: int, part_keys_ptr: int, parts: int, nq: int, k: int,
                    out_ids_ptr: int, out_scores_ptr: int, out_keys_ptr: int, out_counts_ptr: int,
                    stream: int = 0, ctx=None) -> None:
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     _lib.check(_lib.load().ucfp_topk_merge_dev(ctx.handle, kind, part_ids_ptr, part_keys_ptr, parts, nq, k,
                                                out_ids_ptr, out_scores_ptr or None, out_keys_ptr,
                                                out_counts_ptr, stream or None))
@@ -129,7 +129,7 @@ class GpuIndex:
     (src/index/embedded/mod.rs:307-309)."""
 
     def __init__(self, ctx=None):
-        self.ctx = ctx or _lib.default_context()
+        self.ctx = ctx or _lib.current_context()
         self._cos = {}        # dim -> DeviceIndex
         self._ham = {}        # hash space name -> DeviceIndex
 
@@ -147,13 +147,35 @@ class GpuIndex:
 
     def upsert(self, records: Sequence[Record]) -> None:
         """Embeddings go to the cosine index of their dimension; image records also feed the
-        Hamming spaces `<algorithm>` with their 64-bit global hashes (SURVEY 8f N2 offsets)."""
-        by_cos, by_ham = {}, {}
+        Hamming spaces `<algorithm>` with their 64-bit global hashes (SURVEY 8f N2 offsets).
+
+        Overwrite semantics are the reference's: everything is keyed by (tenant_id, record_id), a re-ingested record
+        REPLACES the old one -- "Drop any stale vector for this key" when the new record has no embedding
+        (src/index/embedded/mod.rs:184-191), a new dimension or algorithm replaces the old row.  So before inserting,
+        the key is removed from every cosine index of another dimension and every hash space the new record does not
+        feed.  Within one batch the last record of a key wins, as successive `insert`s in one redb transaction do."""
+        last = {}
         for r in records:
-            if r.embedding is not None and len(r.embedding) > 0:
-                by_cos.setdefault((r.tenant_id, len(r.embedding)), []).append(r)
+            last[(r.tenant_id, r.record_id)] = r
+        by_cos, by_ham, stale_cos, stale_ham = {}, {}, {}, {}
+        for r in last.values():
+            dim = len(r.embedding) if r.embedding is not None else 0
+            if dim > 0:
+                by_cos.setdefault((r.tenant_id, dim), []).append(r)
+            for d in self._cos:
+                if d != dim:
+                    stale_cos.setdefault((r.tenant_id, d), []).append(r.record_id)
+            fed = set()
             for space, h in _hash_spaces(r):
                 by_ham.setdefault((r.tenant_id, space), []).append((r.record_id, h))
+                fed.add(space)
+            for space in self._ham:
+                if space not in fed:
+                    stale_ham.setdefault((r.tenant_id, space), []).append(r.record_id)
+        for (tenant, d), ids in stale_cos.items():
+            self._cos[d].delete(tenant, np.array(ids, np.uint64))
+        for (tenant, space), ids in stale_ham.items():
+            self._ham[space].delete(tenant, np.array(ids, np.uint64))
         for (tenant, dim), recs in by_cos.items():
             ids = np.array([r.record_id for r in recs], np.uint64)
             rows = np.array([r.embedding for r in recs], np.float32)

@@ -29,15 +29,21 @@ ALGORITHM_SIMHASH_TF = "simhash-b64-tf"
 ALGORITHM_SIMHASH_IDF = "simhash-b64-idf"
 ALGORITHM_LSH = "minhash-lsh-h128"
 FORMAT_VERSION = 1   # txtfp::FORMAT_VERSION as stored by text.rs:227
+# MinHash / LSH records: the slot derivation (DESIGN T5) is KNOWN not to be txtfp 0.2.0's (the reference's
+# golden slot 0, src/server/tests.rs:1153-1157, is not reproduced), so these records carry their own
+# format_version: a corpus mixing them with upstream-produced `minhash-h128` records is then rejected as
+# incompatible instead of yielding meaningless Jaccard estimates.  Layout, schema word and tag are upstream's.
+FORMAT_VERSION_MINHASH_HIP = 0x48500001
 
 RAW_ASCII, PRETOKENIZED = 0, 1
 NEEDS_HOST = 1
 MINHASH_BYTES, SIMHASH_BYTES = 1032, 8
 
-# The only config_hash the reference pins (src/server/tests.rs:1158-1161): default canonicalizer,
-# "shingle-k=5/word-uax29", "minhash-h128".  txtfp::config_hash itself is not available offline.
-_PINNED_CONFIG_HASH = {("nfkc", True, True, True, "shingle-k=5/word-uax29", ALGORITHM_MINHASH_128):
-                       2_212_816_233_060_047_056}
+# txtfp::config_hash is not available offline and could not be reconstructed (DESIGN section 2 lists what was
+# tried).  The ONE value the reference's tests show (src/server/tests.rs:1158-1161: default canonicalizer,
+# "shingle-k=5/word-uax29", "minhash-h128") is CARRIED here as a constant -- it is not computed, so it pins nothing.
+_CARRIED_CONFIG_HASH = {("nfkc", True, True, True, "shingle-k=5/word-uax29", ALGORITHM_MINHASH_128):
+                        2_212_816_233_060_047_056}
 
 
 @dataclass
@@ -80,15 +86,14 @@ class TextOpts:
 
 
 def config_hash(canon: Canonicalizer, tokenizer_tag: str, algorithm: str) -> int:
-    """txtfp::config_hash stand-in: the reference's pinned value for the default configuration,
-    otherwise XXH3-free FNV-1a of a canonical description (documented as NOT txtfp's value)."""
+    """txtfp::config_hash (text.rs:221): only the default MinHash configuration's value is known (carried as a
+    constant from the reference's test); for any other configuration the reference's value cannot be produced,
+    so this raises instead of inventing one."""
     key = (canon.normalization, canon.case_fold, canon.strip_bidi, canon.strip_format, tokenizer_tag, algorithm)
-    if key in _PINNED_CONFIG_HASH:
-        return _PINNED_CONFIG_HASH[key]
-    h = 0xCBF29CE484222325
-    for b in repr(key).encode():
-        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
-    return h
+    if key in _CARRIED_CONFIG_HASH:
+        return _CARRIED_CONFIG_HASH[key]
+    raise UnsupportedError(f"txtfp::config_hash of {key} is unknown: only the default MinHash configuration's value "
+                           "is carried (src/server/tests.rs:1158-1161)")
 
 
 def _host_tokens(s: str) -> List[str]:
@@ -115,7 +120,7 @@ def _pack(docs: Sequence[bytes]):
 
 
 def _run(kind: str, docs: Sequence[bytes], mode: int, k: int, ctx=None):
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     lib = _lib.load()
     blob, offs = _pack(docs)
     n = len(docs)
@@ -165,44 +170,65 @@ def _raise_for(status: int):
         raise ModalityError(f"text fingerprint failed with status {status}")
 
 
+CONFIG_HASH_UNKNOWN = 0
+
+
+def _record_config_hash(opts: TextOpts, tokenizer_tag: str, algorithm: str, supplied: Optional[int]) -> int:
+    """`config_hash` of a record.  In the drop-in the Rust host keeps calling txtfp::config_hash itself (a host-side
+    function of the configuration, text.rs:221,406 -- not on the hot path) and passes the value in (`supplied`).
+    Without it only the carried default-MinHash constant is known; every other configuration gets
+    CONFIG_HASH_UNKNOWN (0), never an invented value."""
+    if supplied is not None:
+        return int(supplied)
+    try:
+        return config_hash(opts.canonicalizer, tokenizer_tag, algorithm)
+    except UnsupportedError:
+        return CONFIG_HASH_UNKNOWN
+
+
 def fingerprint_minhash(text: str, tenant_id: int, record_id: int) -> Record:
     return fingerprint_minhash_with(text, TextOpts(), tenant_id, record_id)
 
 
-def fingerprint_minhash_with(text: str, opts: TextOpts, tenant_id: int, record_id: int) -> Record:
+def fingerprint_minhash_with(text: str, opts: TextOpts, tenant_id: int, record_id: int,
+                             config_hash_value: Optional[int] = None) -> Record:
     if opts.h != DEFAULT_H:
         raise UnsupportedError("only H = 128 is built (the reference's public entry point, text.rs:172-174)")
     recs, status = minhash_batch([text], opts)
     _raise_for(int(status[0]))
-    return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Text, format_version=FORMAT_VERSION,
-                  algorithm=ALGORITHM_MINHASH_128,
-                  config_hash=config_hash(opts.canonicalizer, opts.tokenizer_tag(), ALGORITHM_MINHASH_128),
+    return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Text,
+                  format_version=FORMAT_VERSION_MINHASH_HIP, algorithm=ALGORITHM_MINHASH_128,
+                  config_hash=_record_config_hash(opts, opts.tokenizer_tag(), ALGORITHM_MINHASH_128, config_hash_value),
                   fingerprint=recs[0].tobytes(), embedding=None, model_id=None, metadata=b"", text=text)
 
 
-def _simhash(text: str, opts: TextOpts, tag: str, tenant_id: int, record_id: int) -> Record:
+def _simhash(text: str, opts: TextOpts, tag: str, tenant_id: int, record_id: int,
+             config_hash_value: Optional[int] = None) -> Record:
     recs, status = simhash_batch([text], opts)
     _raise_for(int(status[0]))
     tok_tag = {"word": "word-uax29", "grapheme": "grapheme-uax29", "cjk-jp": "cjk-jp", "cjk-ko": "cjk-ko"}[opts.tokenizer]
     return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Text, format_version=FORMAT_VERSION,
-                  algorithm=tag, config_hash=config_hash(opts.canonicalizer, tok_tag, tag),
+                  algorithm=tag, config_hash=_record_config_hash(opts, tok_tag, tag, config_hash_value),
                   fingerprint=recs[0].tobytes(), embedding=None, model_id=None, metadata=b"", text=text)
 
 
-def fingerprint_simhash_tf(text: str, opts: TextOpts, tenant_id: int, record_id: int) -> Record:
-    return _simhash(text, opts, ALGORITHM_SIMHASH_TF, tenant_id, record_id)
+def fingerprint_simhash_tf(text: str, opts: TextOpts, tenant_id: int, record_id: int,
+                           config_hash_value: Optional[int] = None) -> Record:
+    return _simhash(text, opts, ALGORITHM_SIMHASH_TF, tenant_id, record_id, config_hash_value)
 
 
-def fingerprint_simhash_idf(text: str, opts: TextOpts, idf, tenant_id: int, record_id: int) -> Record:
+def fingerprint_simhash_idf(text: str, opts: TextOpts, idf, tenant_id: int, record_id: int,
+                            config_hash_value: Optional[int] = None) -> Record:
     """The server always passes IdfTable::default() (handlers.rs:410): an empty table weights every
     token 1.0, i.e. TF weighting; a non-empty table is not supported on the HIP path."""
     if idf:
         raise UnsupportedError("non-empty IdfTable is not built into the HIP path")
-    return _simhash(text, opts, ALGORITHM_SIMHASH_IDF, tenant_id, record_id)
+    return _simhash(text, opts, ALGORITHM_SIMHASH_IDF, tenant_id, record_id, config_hash_value)
 
 
-def fingerprint_lsh(text: str, opts: TextOpts, tenant_id: int, record_id: int) -> Record:
-    rec = fingerprint_minhash_with(text, opts, tenant_id, record_id)
+def fingerprint_lsh(text: str, opts: TextOpts, tenant_id: int, record_id: int,
+                    config_hash_value: Optional[int] = None) -> Record:
+    rec = fingerprint_minhash_with(text, opts, tenant_id, record_id, config_hash_value)
     rec.algorithm = ALGORITHM_LSH
     return rec
 
@@ -228,7 +254,7 @@ def lsh_band_keys(records, bands: int = 16, rows: int = 8, ctx=None) -> np.ndarr
     -> uint64 [n, bands].  Key spec: DESIGN.md "LSH" (slot-wise FNV fold + splitmix64 finaliser);
     computed by ucfp_text_lsh_band_keys_dev."""
     import torch
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.current_context()
     r = _records(records)
     n = r.shape[0]
     d_r = _dev(r)
@@ -244,7 +270,7 @@ class LshIndex:
 
     def __init__(self, bands: int = 16, rows: int = 8, cand_per_band: int = 64, ctx=None):
         self._lib = _lib.load()
-        self.ctx = ctx or _lib.default_context()
+        self.ctx = ctx or _lib.current_context()
         self.bands, self.rows, self.cand_per_band = bands, rows, cand_per_band
         h = C.c_void_p()
         _lib.check(self._lib.ucfp_lsh_create(self.ctx.handle, bands, rows, cand_per_band, C.byref(h)))

@@ -175,6 +175,20 @@ int ucfp_audio_wang_dev(ucfp_ctx* ctx, const float* d_pcm, size_t n, uint32_t sa
                         const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes, uint64_t* d_n_hashes,
                         void* stream);
 
+/* RAGGED BATCH of clips (SURVEY 8f N1 for audio: the reference ingests one short clip per request,
+ * src/server/handlers.rs:704-918; its bench clip is 4 s, benches/end_to_end.rs:55-75): clip i is
+ * d_pcm[d_offsets[i] .. d_offsets[i+1]) (n_clips + 1 device u64 offsets, d_offsets[n_clips] <= n_total), all at
+ * `sample_rate`.  8000 Hz clips are taken as they are; any other rate is resampled to 8 kHz by
+ * audiofp::dsp::resample::linear (A1) INSIDE the kernel that cuts the STFT frames -- HBM sees every source sample
+ * once (BASELINE config 3: 44.1 kHz).  One launch sequence covers the whole batch.  Hashes of clip i land in
+ * d_out[d_out_offsets[i] .. d_out_offsets[i+1]) (8 bytes each, t_anchor relative to the clip); d_out_offsets has
+ * n_clips + 1 device u64 entries; if d_out_offsets[n_clips] > cap_hashes the output was truncated at cap_hashes.
+ * Workspace: about 4 KiB per second of audio in the batch, held by the context.  No synchronisation. */
+size_t ucfp_audio_wang_batch_max_hashes(size_t n_total, size_t n_clips, uint32_t sample_rate, const ucfp_wang_config* cfg);
+int ucfp_audio_wang_batch_dev(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_offsets, size_t n_total, size_t n_clips,
+                              uint32_t sample_rate, const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes,
+                              uint64_t* d_out_offsets, void* stream);
+
 size_t ucfp_audio_haitsma_frames(size_t n_samples, uint32_t sample_rate);
 int ucfp_audio_haitsma(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate,
                        const ucfp_haitsma_config* cfg, uint32_t* out, size_t cap_frames, size_t* n_frames);

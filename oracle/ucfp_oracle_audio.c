@@ -51,28 +51,55 @@ static uint32_t bitrev(uint32_t x, int bits) {
     return r;
 }
 
-/* A2/A3: one frame -> power spectrum P[0..N/2). N in {1024, 2048}. Hann (periodic) window
- * w[n] = 0.5 - 0.5*cos(2*pi*n/N); in-place radix-2 DIT FFT; P = re*re + im*im. */
-static void frame_power(const float* x, int N, float* P, float* re, float* im) {
-    const int bits = N == 1024 ? 10 : 11;
+/* A2/A3 (round 2): one frame -> power spectrum P[0..N/2), N in {1024, 2048}, by the real-input route:
+ *   window  w[m] = 0.5 - 0.5*cos(2*pi*m/N) (periodic Hann), applied HALVED: wh[m] = 0.5f * w[m]  (an exact scaling;
+ *           it absorbs the factor 1/2 of the untangling step, so P is the plain |X[k]|^2 of the windowed frame)
+ *   pack    z[n] = (x[2n]*wh[2n], x[2n+1]*wh[2n+1]),  n = 0..M-1,  M = N/2
+ *   FFT     in-place radix-2 DIT over z, M points; in stages 1..3 a twiddle 1 is a pure add/subtract and a twiddle
+ *           -i is (xi, -xr); every other butterfly (and EVERY butterfly from stage 4 on, whatever its twiddle) is the
+ *           general one  t1 = xr c, t2 = xi s, t3 = xr s, t4 = xi c, v = (t1 - t2, t3 + t4), u' = u + v, x' = u - v
+ *   untangle for k = 0..M/2, with Y = Z[(M-k) mod M] and W = TW_N^k = (c, s):
+ *           A = (Zr + Yr, Zi - Yi)   B = (Zr - Yr, Zi + Yi)   T = (Br c - Bi s, Br s + Bi c)
+ *           X[k]   = (Ar + Ti, Ai - Tr)            P[k]   = Xr*Xr + Xi*Xi
+ *           X[M-k] = (Ar - Ti, Ai + Tr) (conj.)    P[M-k] = ...           for 0 < k < M/2
+ * Half the butterflies of a complex N-point transform; the HIP kernels (audio.hip, wave_rfft_power) perform the
+ * same single f32 operations in the same order.  The order is OURS (audiofp's is unknown: parity unpinned). */
+static float half_hann(int m, int N) {
     const int tws = 2048 / N; /* table stride */
-    for (int n = 0; n < N; n++) {
-        float c = TW[(n * tws) & 1023][0];
-        if (n * tws >= 1024) c = -c; /* cos(2*pi*n/N) for the second half: cos(theta + pi) = -cos(theta) */
-        float w = 0.5f - 0.5f * c;
-        uint32_t r = bitrev((uint32_t)n, bits);
-        re[r] = x[n] * w;
-        im[r] = 0.0f;
+    float c = TW[(m * tws) & 1023][0];
+    if (m * tws >= 1024) c = -c; /* cos(theta + pi) = -cos(theta) */
+    const float w = 0.5f - 0.5f * c;
+    return 0.5f * w;
+}
+static void frame_power(const float* x, int N, float* P, float* re, float* im) {
+    const int M = N / 2;
+    const int bits = N == 1024 ? 9 : 10;
+    const int tws = 2048 / N;
+    for (int n = 0; n < M; n++) {
+        const uint32_t r = bitrev((uint32_t)n, bits);
+        re[r] = x[2 * n] * half_hann(2 * n, N);
+        im[r] = x[2 * n + 1] * half_hann(2 * n + 1, N);
     }
     for (int s = 1; s <= bits; s++) {
         const int m = 1 << s, half = m >> 1, tstep = 2048 / m;
-        for (int b = 0; b < N; b += m)
+        for (int b = 0; b < M; b += m)
             for (int j = 0; j < half; j++) {
-                const float c = TW[j * tstep][0], sn = TW[j * tstep][1];
+                const int ti = j * tstep;
                 const int i0 = b + j, i1 = b + j + half;
                 const float xr = re[i1], xi = im[i1];
-                const float t1 = xr * c, t2 = xi * sn, t3 = xr * sn, t4 = xi * c;
-                const float vr = t1 - t2, vi = t3 + t4;
+                float vr, vi;
+                if (s <= 3 && ti == 0) {
+                    vr = xr;
+                    vi = xi;
+                } else if (s <= 3 && ti == 512) {
+                    vr = xi;
+                    vi = -xr;
+                } else {
+                    const float c = TW[ti][0], sn = TW[ti][1];
+                    const float t1 = xr * c, t2 = xi * sn, t3 = xr * sn, t4 = xi * c;
+                    vr = t1 - t2;
+                    vi = t3 + t4;
+                }
                 const float ur = re[i0], ui = im[i0];
                 re[i0] = ur + vr;
                 im[i0] = ui + vi;
@@ -80,9 +107,21 @@ static void frame_power(const float* x, int N, float* P, float* re, float* im) {
                 im[i1] = ui - vi;
             }
     }
-    for (int k = 0; k < N / 2; k++) {
-        const float a = re[k] * re[k], b2 = im[k] * im[k];
-        P[k] = a + b2;
+    for (int k = 0; k <= M / 2; k++) {
+        const int kk = (M - k) & (M - 1);
+        const float zr = re[k], zi = im[k], yr = re[kk], yi = im[kk];
+        const float ar = zr + yr, ai = zi - yi, br = zr - yr, bi = zi + yi;
+        const float c = TW[k * tws][0], sn = TW[k * tws][1];
+        const float t1 = br * c, t2 = bi * sn, t3 = br * sn, t4 = bi * c;
+        const float tr = t1 - t2, ti = t3 + t4;
+        const float xr = ar + ti, xi = ai - tr;
+        const float p1 = xr * xr, p2 = xi * xi;
+        P[k] = p1 + p2;
+        if (k > 0 && k < M / 2) {
+            const float ur = ar - ti, ui = ai + tr;
+            const float q1 = ur * ur, q2 = ui * ui;
+            P[M - k] = q1 + q2;
+        }
     }
 }
 

@@ -173,3 +173,67 @@ def test_records_and_streaming_session(gpu_ctx):
     assert s.push(x[:10000]) == [] and s.push(x[10000:]) == []
     out = s.finalize()
     assert len(out) == 1 and out[0].fingerprint == rec.fingerprint
+
+
+# ---- round 2: ragged batches and the resampler fused into the stream kernel ------------------------------------
+def _clip(rng, n, kind):
+    t = np.arange(n, dtype=np.float64)
+    if kind == 0:
+        x = 0.4 * np.sin(2 * np.pi * (200.0 + 1500.0 * rng.random()) * t / 8000.0 * (1 + 0.1 * t / max(n, 1)))
+    elif kind == 1:
+        x = 0.2 * rng.standard_normal(n)
+    elif kind == 2:
+        x = np.zeros(n)
+        x[rng.integers(0, max(n, 1), size=max(1, n // 900))] = rng.uniform(-1, 1, size=max(1, n // 900))
+    else:
+        x = 0.3 * np.sign(np.sin(2 * np.pi * 311.0 * t / 8000.0)) + 0.02 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def test_wang_batch_of_4096_random_length_clips_matches_oracle(gpu_ctx, oracle):
+    """4 096 clips of 0 .. 6 s at 8 kHz (empty, shorter than one frame, one frame exactly, several seconds) through ONE
+    call of ucfp_audio_wang_batch_dev; every clip's hashes equal the oracle's for that clip alone."""
+    from ucfp_amd import audio
+    rng = np.random.default_rng(4096)
+    lens = rng.integers(0, 48_000, size=4096)
+    lens[:8] = [0, 1, 1023, 1024, 1025, 1151, 1152, 8000]
+    clips = [_clip(rng, int(n), i % 4) for i, n in enumerate(lens)]
+    got = audio.wang_hashes_batch(clips, 8000, ctx=gpu_ctx)
+    assert len(got) == len(clips)
+    total = 0
+    for i, (c, g) in enumerate(zip(clips, got)):
+        o = oracle.wang(c)
+        assert g.shape == o.shape and np.array_equal(g, o), (i, c.size, g.shape, o.shape)
+        total += o.shape[0]
+    assert total > 100_000          # the batch is not trivially empty
+
+
+@pytest.mark.parametrize("sr", [44100, 16000, 11025, 48000, 7999])
+def test_wang_batch_fused_resample_matches_resample_then_wang(gpu_ctx, oracle, sr):
+    """A clip at another rate: the stream kernel's own A1 resampling = oracle.resample_linear followed by oracle.wang."""
+    from ucfp_amd import audio
+    rng = np.random.default_rng(sr)
+    clips = []
+    for i, secs in enumerate((0.05, 0.129, 1.0, 3.7, 12.3)):
+        n = int(secs * sr)
+        t = np.arange(n) / sr
+        x = 0.3 * np.sin(2 * np.pi * (300 + 90 * i + 40 * t) * t) + 0.05 * rng.standard_normal(n)
+        clips.append(x.astype(np.float32))
+    cfg = audio.WangConfig(fan_out=5, target_zone_t=40, target_zone_f=80, peaks_per_sec=20, min_anchor_mag_db=-60.0)
+    got = audio.wang_hashes_batch(clips, sr, cfg, ctx=gpu_ctx)
+    ocfg = oracle.WangCfg(5, 40, 80, 20, -60.0)
+    for c, g in zip(clips, got):
+        o = oracle.wang(oracle.resample_linear(c, sr, 8000), ocfg)
+        assert g.shape == o.shape and np.array_equal(g, o), (sr, c.size, g.shape, o.shape)
+
+
+def test_wang_batch_long_clip_between_short_ones(gpu_ctx, oracle):
+    """A 20-minute clip (many workgroup segments) between two short ones: segment -> clip and second -> clip maps,
+    and pairing never crosses a clip boundary."""
+    from ucfp_amd import audio
+    rng = np.random.default_rng(77)
+    clips = [_clip(rng, 20_000, 0), _signal("chirps", 1200.0, 8000, seed=3), _clip(rng, 30_000, 3)]
+    got = audio.wang_hashes_batch(clips, 8000, ctx=gpu_ctx)
+    for c, g in zip(clips, got):
+        o = oracle.wang(c)
+        assert g.shape == o.shape and np.array_equal(g, o)

@@ -52,6 +52,9 @@ SIGNATURES = {
                                   C.c_size_t, C.POINTER(C.c_size_t)]),
     "ucfp_audio_wang_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(WangConfig),
                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ucfp_audio_wang_batch_max_hashes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(WangConfig)]),
+    "ucfp_audio_wang_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                            C.POINTER(WangConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ucfp_audio_haitsma_frames": (C.c_size_t, [C.c_size_t, C.c_uint32]),
     "ucfp_audio_haitsma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(HaitsmaConfig),
                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -67,6 +67,46 @@ def wang_hashes(samples, sample_rate: int, cfg: Optional[WangConfig] = None, ctx
     return out[: n.value].copy()
 
 
+def wang_hashes_batch_dev(pcm_ptr: int, offsets_ptr: int, n_total: int, n_clips: int, sample_rate: int, out_ptr: int,
+                          cap_hashes: int, out_offsets_ptr: int, cfg: Optional[WangConfig] = None, stream: int = 0,
+                          ctx=None) -> None:
+    """Ragged batch of clips, device pointers, no sync (ucfp_audio_wang_batch_dev): clip i = pcm[offsets[i] ..
+    offsets[i+1]) at `sample_rate` (resampled to 8 kHz in the kernel unless it is 8000)."""
+    ctx = ctx or _lib.current_context()
+    c = (cfg or WangConfig())._c()
+    _lib.check(_lib.load().ucfp_audio_wang_batch_dev(ctx.handle, pcm_ptr or None, offsets_ptr or None, n_total, n_clips,
+                                                     sample_rate, C.byref(c), out_ptr or None, cap_hashes,
+                                                     out_offsets_ptr, stream or None))
+
+
+def wang_hashes_batch(clips, sample_rate: int, cfg: Optional[WangConfig] = None, ctx=None) -> List[np.ndarray]:
+    """Host convenience over the batch entry: a list of mono f32 clips (all at `sample_rate`) -> one uint32 [n_i, 2]
+    array per clip.  One launch sequence for the whole batch."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    _check_rate(sample_rate)
+    arrs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in clips]
+    if not arrs:
+        return []
+    offs = np.zeros(len(arrs) + 1, np.uint64)
+    np.cumsum([a.size for a in arrs], out=offs[1:])
+    blob = np.concatenate(arrs) if offs[-1] else np.zeros(1, np.float32)
+    c = (cfg or WangConfig())._c()
+    cap = max(1, int(_lib.load().ucfp_audio_wang_batch_max_hashes(int(offs[-1]), len(arrs), sample_rate, C.byref(c))))
+    dev = f"cuda:{ctx.device}"
+    d_pcm = torch.from_numpy(blob).to(dev)
+    d_off = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_out = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+    d_oo = torch.zeros(len(arrs) + 1, dtype=torch.int64, device=dev)
+    wang_hashes_batch_dev(d_pcm.data_ptr(), d_off.data_ptr(), int(offs[-1]), len(arrs), sample_rate, d_out.data_ptr(), cap,
+                          d_oo.data_ptr(), cfg, torch.cuda.current_stream().cuda_stream, ctx)
+    oo = d_oo.cpu().numpy()
+    out = d_out.cpu().numpy().view(np.uint32)
+    if oo[-1] > cap:
+        raise ModalityError(f"Wang batch produced {oo[-1]} hashes, buffer holds {cap}")
+    return [out[oo[i]:oo[i + 1]].copy() for i in range(len(arrs))]
+
+
 def haitsma_frames(samples, sample_rate: int, cfg: Optional[HaitsmaConfig] = None, ctx=None) -> np.ndarray:
     ctx = ctx or _lib.current_context()
     _check_rate(sample_rate)

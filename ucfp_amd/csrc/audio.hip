@@ -6,13 +6,17 @@
 // oracle/ (audio).  Every float step is one IEEE f32 operation in the order the oracle uses (the
 // library is built with -ffp-contract=off), so the integer outputs are bit-identical.
 //
-//   resample_linear   A1   one thread per output sample
-//   wave_fft_power_core<N> A2-3 ONE WAVE PER FRAME: Hann window + 1024/2048-point radix-2 FFT, 16/32 points per
-//                          lane in registers as (re, im) pairs on packed-f32 instructions; the first transpose goes
-//                          through LDS, the second runs on v_permlane32/16_swap; stage-major twiddle table
-//   wang_stream       A3+5 Wang: frames streamed through an LDS ring of row maxima, peaks judged in the
-//                          kernel one round behind (separable neighbourhood maximum + exact tie rule); nothing
-//                          is spilled
+//   resample_linear   A1   one thread per output sample (stand-alone entry; the Wang path resamples inside its
+//                          stream kernel)
+//   wave_rfft_power<N> A2-3 ONE WAVE PER FRAME, real-input route: the N real samples are packed into N/2 complex points
+//                          (8 / 16 per lane in registers, packed-f32 butterflies), transformed by an N/2-point radix-2
+//                          FFT whose first transpose runs on v_permlane32/16_swap + bank-masked DPP and whose second
+//                          goes through LDS, then untangled into the power spectrum; window, twiddles and untangling
+//                          factors are loop-invariant per lane and live in registers (Wang)
+//   wang_stream       A1+3+5 Wang over a RAGGED BATCH of clips: a workgroup owns a segment of one clip, stages (and, if
+//                          the input is not at 8 kHz, linearly resamples) the samples of its frames in an LDS ring,
+//                          streams the frames through a ring of row maxima and judges peaks one round behind
+//                          (separable neighbourhood maximum + exact tie rule); nothing is spilled
 //   stft_power<2048>  A7   Haitsma: 33 band energies per frame (chunked so the band buffer stays bounded)
 //   wang_select       A5   one wave per second of audio: rank by strength, keep peaks_per_sec,
 //                          order by (t, k)
@@ -50,278 +54,285 @@ __global__ void resample_linear_kernel(const float* __restrict__ in, size_t n, u
     out[i] = x0 + mm;
 }
 
-// ---- A2/A3: one wave per frame, FFT register-tiled ------------------------------------------------
-// N = 64 * E points, E = 16 (Wang, N = 1024) or 32 (Haitsma, N = 2048) complex values per lane.
-// The radix-2 DIT butterflies are EXACTLY those of the oracle (same operands, same f32 ops), only
-// their placement changes: a lane keeps E points in registers and runs every stage whose partner
-// distance stays inside its E points, then the wave transposes through LDS:
-//   phase 1  lane L holds p = E*L + i           -> stages 1..B        (B = log2 E), twiddles constant
-//   phase 2  lane (hi, lo) holds p = hi*E*E + m*E + lo  -> stages B+1..2B
-//   phase 3  lane l holds p = e*64 + l          -> stages 2B+1..log2 N
-// Two LDS transposes (padded: p + p/E) replace the ten LDS round trips of a stage-by-stage FFT.
-// Twiddles of the stages that run after a transpose live in LDS STAGE-MAJOR: stage st (2^(st-1) distinct
-// twiddles W^(jj * 2048 >> st)) occupies entries [2^(st-1) - E, 2^st - E), so a read at jj = const | lane-low-bits
-// touches consecutive 8-byte entries.  (Read from the natural 1024-entry table at stride 2048 >> st, the 16 distinct
-// addresses of a stage-5 read all fall on one bank: 59 % of the LDS cycles of the first version were conflicts.)
-constexpr int kFftWaves = 12;  // one workgroup per CU, 3 waves per SIMD: 16 KiB of twiddles + 12 x 8.25 KiB (N = 2048)
+// ---- A2/A3: one wave per frame, real-input FFT register-tiled -------------------------------------
+// N real samples -> M = N/2 complex points z[n] = (x[2n] wh[2n], x[2n+1] wh[2n+1]) (wh = the HALVED Hann window)
+// -> M-point radix-2 DIT FFT -> untangling -> P[k] = |X[k]|^2, k < M.  Exactly the operations of the oracle
+// (oracle/ucfp_oracle_audio.c frame_power), only their placement changes.  M = 64 E, E = 8 (Wang, N = 1024) or
+// 16 (Haitsma, N = 2048) complex values per lane, B = log2 E; point p (a bit-reversed sample-pair index) sits at
+//   phase 1  register i = p[B-1:0];   lane bits [5:6-B] = p[2B-1:B],  lane bits [5-B:0] = p[.. :2B]    stages 1..B
+//   phase 2  register m = p[2B-1:B];  lane bits [5:6-B] = p[B-1:0] ("lo"), low lane bits = "hi"        stages B+1..2B
+//   phase 3  register e = p[..:6];    lane = p[5:0]                                                    stages 2B+1..
+// Transpose 1 swaps register bit j with lane bit 6-B+j IN REGISTERS: lane bits 5 / 4 with gfx950's
+// v_permlane32_swap / v_permlane16_swap (one instruction moves both directions), lane bits 3 / 2 with two
+// bank-masked DPP moves (row_ror:8; row_shl:4 + row_shr:4).  Transpose 2 goes through LDS (real and imaginary halves
+// one after the other through one padded buffer).  Everything that depends only on the lane -- window, the twiddles
+// of phases 2 and 3, the untangling factors -- is loop-invariant and handed in by the caller (RfftConst).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int N>
-struct FftLds {
-    float2 stw[N - N / 64];
-    float buf[kFftWaves][N + 64];    // per wave (split-component transpose); reused as the power spectrum float[N/2]
-    float win[N / 64][64];           // Hann window at a lane's sample positions
+struct Rfft {
+    static constexpr int M = N / 2, E = M / 64, B = E == 8 ? 3 : 4, BITS = N == 1024 ? 9 : 10, L6 = 6 - B;
+    static constexpr int PADK = E == 8 ? 4 : 8;                 // transpose-2 padding per 2^(2B) points (see t2 below)
+    static constexpr int T3 = (1 << (BITS - 6)) - (1 << (2 * B - 6));   // phase-3 twiddles per lane: 7 / 12
+    static constexpr int T3_FIRST = 1 << (2 * B - 6);
+    static constexpr int BUF_FLOATS = E == 8 ? 544 : 1056;      // transpose / exchange / spectrum scratch per wave
 };
 template <int N>
-__device__ __forceinline__ void fill_stage_twiddles(float2* __restrict__ stw, int tid, int nthreads) {
-    constexpr int E = N / 64;
-    for (int idx = tid; idx < N - E; idx += nthreads) {
-        const int g = idx + E;                       // 2^(st-1) + jj
-        const int st = 32 - __clz(g);
-        const int jj = g - (1 << (st - 1));
-        stw[idx] = make_float2(c_tw[jj * (2048 >> st)][0], c_tw[jj * (2048 >> st)][1]);
+struct RfftConst {
+    f32x2 win[Rfft<N>::E];        // halved Hann at this lane's E sample pairs
+    f32x2 tw2[Rfft<N>::E - 1];    // stage st in B+1..2B: entry (halfm - 1) + (m0 & (halfm - 1)), halfm = 2^(st-B-1)
+    f32x2 tw3[Rfft<N>::T3];       // stage st in 2B+1..BITS: entry (halfe - T3_FIRST) + (e0 & (halfe - 1)), halfe = 2^(st-7)
+    f32x2 utw[Rfft<N>::E / 2];    // W_N^k, k = 64 e + lane
+};
+
+// sample-pair index n (z[n]) of element i of a lane = bit reversal of p(lane, i); n = (rev_B(i) << (BITS-B)) | pair_base(lane)
+template <int N>
+__device__ __forceinline__ uint32_t rfft_pair_base(int lane) {
+    using R = Rfft<N>;
+    const uint32_t p = (((uint32_t)lane >> R::L6) << R::B) | (((uint32_t)lane & ((1u << R::L6) - 1u)) << (2 * R::B));
+    return __brev(p) >> (32 - R::BITS);
+}
+__device__ __forceinline__ float half_hann_at(uint32_t m, int N) {
+    const uint32_t tws = 2048u / (uint32_t)N;
+    float c = c_tw[(m * tws) & 1023u][0];
+    if (m * tws >= 1024u) c = -c;
+    const float w = 0.5f - 0.5f * c;
+    return 0.5f * w;
+}
+template <int N>
+__device__ __forceinline__ void rfft_consts(int lane, RfftConst<N>& K) {
+    using R = Rfft<N>;
+    const uint32_t nb = rfft_pair_base<N>(lane);
+    const int lo = lane >> R::L6;
+#pragma unroll
+    for (int i = 0; i < R::E; i++) {
+        const uint32_t n = ((__brev((uint32_t)i) >> (32 - R::B)) << (R::BITS - R::B)) | nb;
+        K.win[i] = f32x2{half_hann_at(2 * n, N), half_hann_at(2 * n + 1, N)};
+    }
+#pragma unroll
+    for (int st = R::B + 1; st <= 2 * R::B; st++) {
+        const int halfm = 1 << (st - R::B - 1);
+#pragma unroll
+        for (int j = 0; j < halfm; j++) {
+            const int jj = (j << R::B) | lo;
+            K.tw2[halfm - 1 + j] = f32x2{c_tw[jj * (2048 >> st)][0], c_tw[jj * (2048 >> st)][1]};
+        }
+    }
+#pragma unroll
+    for (int st = 2 * R::B + 1; st <= R::BITS; st++) {
+        const int halfe = 1 << (st - 7);
+#pragma unroll
+        for (int j = 0; j < halfe; j++) {
+            const int jj = (j << 6) | lane;
+            K.tw3[halfe - R::T3_FIRST + j] = f32x2{c_tw[jj * (2048 >> st)][0], c_tw[jj * (2048 >> st)][1]};
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < R::E / 2; e++) {
+        const int k = e * 64 + lane;
+        K.utw[e] = f32x2{c_tw[k * (2048 / N)][0], c_tw[k * (2048 / N)][1]};
     }
 }
 
 // One radix-2 butterfly on (re, im) pairs in packed f32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations
-// per lane per instruction, so 6 instructions instead of 10).  Same operations in the same order as the
-// oracle: t1 = xr c, t2 = xi s, t3 = xr s, t4 = xi c, v = (t1 - t2, t3 + t4), u' = u + v, x' = u - v.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void bfly(f32x2& u, f32x2& x, f32x2 tw) {   // tw = (c, s)
+// per lane per instruction).  Same operations in the same order as the oracle:
+// t1 = xr c, t2 = xi s, t3 = xr s, t4 = xi c, v = (t1 - t2, t3 + t4), u' = u + v, x' = u - v.
+__device__ __forceinline__ f32x2 cmul_tw(f32x2 x, f32x2 tw) {      // (t1 - t2, t4 + t3), tw = (c, s)
     const f32x2 a = x * f32x2{tw.x, tw.x};              // (t1, t4): broadcast by op_sel, no move
     // (-t2, t3) = (xi * -s, xr * s) in ONE instruction: swapped x halves by op_sel, the low product's sign by the
     // source modifier (xi * (-s) == -(xi * s) exactly); the compiler spends a negate + a move on this otherwise
     f32x2 b;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(b) : "v"(x), "v"(tw));
-    const f32x2 v = a + b;                              // (t1 - t2, t4 + t3)
+    return a + b;
+}
+__device__ __forceinline__ void bfly(f32x2& u, f32x2& x, f32x2 tw) {
+    const f32x2 v = cmul_tw(x, tw);
     const f32x2 w = u;
     u = w + v;
     x = w - v;
 }
+__device__ __forceinline__ void bfly_one(f32x2& u, f32x2& x) {          // twiddle 1: v = x
+    const f32x2 w = u, v = x;
+    u = w + v;
+    x = w - v;
+}
+__device__ __forceinline__ void bfly_minus_i(f32x2& u, f32x2& x) {      // twiddle -i: v = (xi, -xr)
+    const f32x2 w = u;
+    const f32x2 v = f32x2{x.y, -x.x};
+    u = w + v;
+    x = w - v;
+}
 
-// element i of lane L is p = E*L + i = bit-reversed sample index n = (rev(i) << 6) | rev(L); the sample
-// positions of a lane are the same for every frame, so a caller may keep the window in registers
-// gfx950 half / row exchange between two registers (see transpose 2 in wave_fft_power_core)
-template <int W>
-__device__ __forceinline__ void swap_lanes(f32x2& a, f32x2& b) {   // both components
+// (register bit, lane bit LB) transposed: a is the register-bit-0 side, b the register-bit-1 side
+template <int LB>
+__device__ __forceinline__ void xchg_lane_bit(f32x2& a, f32x2& b) {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const uint32_t ua = __float_as_uint(a[c]), ub = __float_as_uint(b[c]);
-        if constexpr (W == 32) {
-            const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
-            a[c] = __uint_as_float(r[0]);
-            b[c] = __uint_as_float(r[1]);
+        uint32_t na, nb;
+        if constexpr (LB == 5) {
+            const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);   // lanes 32-63 of a <-> lanes 0-31 of b
+            na = r[0];
+            nb = r[1];
+        } else if constexpr (LB == 4) {
+            const auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);   // odd rows of a <-> even rows of b
+            na = r[0];
+            nb = r[1];
+        } else if constexpr (LB == 3) {
+            // lanes with bit 3 clear (banks 0, 1 of every row) take a of lane ^ 8 into b; the others b of lane ^ 8 into a
+            nb = (uint32_t)__builtin_amdgcn_update_dpp((int)ub, (int)ua, 0x128, 0xf, 0x3, false);   // row_ror:8
+            na = (uint32_t)__builtin_amdgcn_update_dpp((int)ua, (int)ub, 0x128, 0xf, 0xc, false);
         } else {
-            const auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);
-            a[c] = __uint_as_float(r[0]);
-            b[c] = __uint_as_float(r[1]);
+            static_assert(LB == 2, "lane bits 2..5 only");
+            nb = (uint32_t)__builtin_amdgcn_update_dpp((int)ub, (int)ua, 0x104, 0xf, 0x5, false);   // row_shl:4 -> from lane + 4
+            na = (uint32_t)__builtin_amdgcn_update_dpp((int)ua, (int)ub, 0x114, 0xf, 0xa, false);   // row_shr:4 -> from lane - 4
         }
+        a[c] = __uint_as_float(na);
+        b[c] = __uint_as_float(nb);
     }
 }
 
-// first-stage forms for real input (see wave_fft_power_core)
-__device__ __forceinline__ void bfly_real(f32x2& u, f32x2& x) {          // twiddle (1, -0), imaginary parts zero
-    const float a = u.x, b = x.x;
-    u.x = a + b;
-    x.x = a - b;
-}
-__device__ __forceinline__ void bfly_real_in(f32x2& u, f32x2& x, f32x2 tw) {   // imaginary INPUTS zero
-    f32x2 m;                                                                  // (xr c, xr s)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m) : "v"(x), "v"(tw));
-    const f32x2 w = u;
-    u = w + m;
-    x = w - m;
-}
-
+// x: the windowed packed input z at this lane's E points (phase-1 layout).  buf: >= Rfft<N>::BUF_FLOATS floats of this
+// wave's LDS, 8-byte aligned; on return buf[0 .. N/2) holds the power spectrum.
 template <int N>
-__device__ __forceinline__ void frame_load(const float* __restrict__ src, int lane, float (&s)[N / 64]) {
-    constexpr int E = N / 64;
-    constexpr int B = E == 16 ? 4 : 5;
-    const uint32_t rl = __brev((uint32_t)lane) >> 26;  // 6-bit reversal of the lane
+__device__ __forceinline__ void wave_rfft_power(f32x2 (&x)[Rfft<N>::E], const RfftConst<N>& K, int lane, float* __restrict__ buf) {
+    using R = Rfft<N>;
+    constexpr int E = R::E, B = R::B, M = R::M;
+    // ---- phase 1: stages 1..B on the register index; stages 1..3 shortcut the twiddles 1 and -i ----
 #pragma unroll
-    for (int i = 0; i < E; i++) {
-        const uint32_t ri = __brev((uint32_t)i) >> (32 - B);   // compile-time after unrolling
-        s[i] = src[(ri << 6) | rl];
-    }
-}
-template <int N>
-__device__ __forceinline__ void frame_window(int lane, float (&w)[N / 64]) {
-    constexpr int E = N / 64;
-    constexpr int B = E == 16 ? 4 : 5;
-    constexpr int TWS = 2048 / N;
-    const uint32_t rl = __brev((uint32_t)lane) >> 26;
-#pragma unroll
-    for (int i = 0; i < E; i++) {
-        const uint32_t ri = __brev((uint32_t)i) >> (32 - B);
-        const uint32_t n = (ri << 6) | rl;
-        float c = c_tw[(n * TWS) & 1023][0];
-        if (n * TWS >= 1024) c = -c;
-        w[i] = 0.5f - 0.5f * c;
-    }
-}
-
-// SPLIT: the transposes move the real and the imaginary halves one after the other through a buffer of N + 64
-// FLOATS (4.25 KiB at N = 1024) instead of N + 64 float2 -- twice the LDS instructions for half the LDS, which is
-// what lets 16 frames be in flight per CU in wang_stream_kernel.
-template <int N, bool SPLIT = false>
-__device__ __forceinline__ void wave_fft_power_core(const float (&smp)[N / 64], const float (&win)[N / 64], int lane,
-                                                    const float2* __restrict__ stw, float2* __restrict__ buf) {
-    constexpr int E = N / 64;
-    constexpr int B = E == 16 ? 4 : 5;
-    constexpr int BITS = N == 1024 ? 10 : 11;
-    f32x2 x[E];
-#pragma unroll
-    for (int i = 0; i < E; i++) x[i] = f32x2{smp[i] * win[i], 0.0f};
-    // ---- phase 1: stages 1..B on bits 0..B-1 (register index), twiddles are table constants ----
-    // The input is real, so the first two stages are cheaper than general butterflies without changing a bit of
-    // the power spectrum: with twiddle (1, -0) and zero imaginary parts a butterfly is one add and one subtract of
-    // the real parts (x*1 and 0*s are exact, the imaginary outputs stay zero); with zero imaginary INPUTS and any
-    // twiddle, v = (xr c - 0 s, xr s + 0 c) = (xr c, xr s) exactly.  (Only the sign of exact zeros can differ from
-    // the five-instruction form, and (+-0)^2 is +0.)
-#pragma unroll
-    for (int i0 = 0; i0 < E; i0 += 2) bfly_real(x[i0], x[i0 + 1]);
-#pragma unroll
-    for (int i0 = 0; i0 < E; i0 += 4) {
-        bfly_real(x[i0], x[i0 + 2]);
-        bfly_real_in(x[i0 + 1], x[i0 + 3], f32x2{c_tw[512][0], c_tw[512][1]});
-    }
-#pragma unroll
-    for (int st = 3; st <= B; st++) {
+    for (int st = 1; st <= B; st++) {
         const int half = 1 << (st - 1), tstep = 2048 >> st;
 #pragma unroll
         for (int i0 = 0; i0 < E; i0++) {
             if (i0 & half) continue;
-            const int jj = i0 & (half - 1);
-            bfly(x[i0], x[i0 + half], f32x2{c_tw[jj * tstep][0], c_tw[jj * tstep][1]});
+            const int ti = (i0 & (half - 1)) * tstep;
+            if (st <= 3 && ti == 0) bfly_one(x[i0], x[i0 + half]);
+            else if (st <= 3 && ti == 512) bfly_minus_i(x[i0], x[i0 + half]);
+            else bfly(x[i0], x[i0 + half], f32x2{c_tw[ti][0], c_tw[ti][1]});
         }
     }
-    // ---- transpose 1 ----
-    const int lo = lane & (E - 1), hi = lane >> B;
-    float* fb = reinterpret_cast<float*>(buf);
-    if constexpr (SPLIT) {
-        float nr[E];
+    // ---- transpose 1, in registers: register bit j <-> lane bit 6 - B + j ----
 #pragma unroll
-        for (int i = 0; i < E; i++) fb[(E + 1) * lane + i] = x[i].x;
-        wave_lds_fence();
+    for (int j = 0; j < B; j++) {
 #pragma unroll
-        for (int m = 0; m < E; m++) {
-            const int pp = hi * E * E + m * E + lo;
-            nr[m] = fb[pp + (pp >> B)];
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int i = 0; i < E; i++) fb[(E + 1) * lane + i] = x[i].y;
-        wave_lds_fence();
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-            const int pp = hi * E * E + m * E + lo;
-            x[m] = f32x2{nr[m], fb[pp + (pp >> B)]};
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < E; i++) buf[(E + 1) * lane + i] = make_float2(x[i].x, x[i].y);   // p + p/E, p = E*lane + i
-        wave_lds_fence();
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-            const int pp = hi * E * E + m * E + lo;
-            const float2 v = buf[pp + (pp >> B)];
-            x[m] = f32x2{v.x, v.y};
+        for (int r = 0; r < E; r++) {
+            if (r & (1 << j)) continue;
+            if (6 - B + j == 5) xchg_lane_bit<5>(x[r], x[r | (1 << j)]);
+            else if (6 - B + j == 4) xchg_lane_bit<4>(x[r], x[r | (1 << j)]);
+            else if (6 - B + j == 3) xchg_lane_bit<3>(x[r], x[r | (1 << j)]);
+            else xchg_lane_bit<2>(x[r], x[r | (1 << j)]);
         }
     }
-    // ---- phase 2: stages B+1..2B on bits B..2B-1 (register index m) ----
+    // ---- phase 2: stages B+1..2B on the register index m ----
 #pragma unroll
     for (int st = B + 1; st <= 2 * B; st++) {
         const int halfm = 1 << (st - B - 1);
 #pragma unroll
         for (int m0 = 0; m0 < E; m0++) {
             if (m0 & halfm) continue;
-            const int jj = ((m0 & (halfm - 1)) << B) | lo;
-            const float2 t2 = stw[(1 << (st - 1)) - E + jj];
-            bfly(x[m0], x[m0 + halfm], f32x2{t2.x, t2.y});
+            bfly(x[m0], x[m0 + halfm], K.tw2[halfm - 1 + (m0 & (halfm - 1))]);
         }
     }
-    // ---- transpose 2: p = hi*E*E + m*E + lo  ->  p = e*64 + lane.  For E = 16 this only exchanges the two lane-row
-    // bits (hi) with the two low bits of the register index: two rounds of gfx950's row/half swaps, no LDS at all
-    // (E = 32: one lane bit and one register bit, one round).
-    // v_permlane32_swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B, i.e. (register bit, lane bit 5) transposed;
-    // v_permlane16_swap: odd rows of A <-> even rows of B, i.e. (register bit, lane bit 4).  Afterwards register
-    // r = (m_hi, hi) holds e = (hi, m_hi) of this lane: a renaming. ----
-    if constexpr (E == 16) {
+    // ---- transpose 2 through LDS: p = hi 2^2B + m E + lo  ->  p = 64 e + lane; a point p is stored at
+    // p + PADK (p >> 2B), which spreads the 32 lanes of a ds_write_b32 group over the 32 banks ----
+    const int lo = lane >> R::L6, hi = lane & ((1 << R::L6) - 1);
+    const int wbase = hi * (E * E + R::PADK) + lo;
+    float nr[E];
 #pragma unroll
-        for (int r = 0; r < E; r++) {
-            if (r & 2) continue;
-            swap_lanes<32>(x[r], x[r + 2]);
-        }
+    for (int m = 0; m < E; m++) buf[wbase + m * E] = x[m].x;
+    wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < E; r++) {
-            if (r & 1) continue;
-            swap_lanes<16>(x[r], x[r + 1]);
-        }
-        f32x2 y[E];
+    for (int e = 0; e < E; e++) nr[e] = buf[e * 64 + lane + R::PADK * ((e * 64) >> (2 * B))];
+    wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < E; r++) y[((r & 3) << 2) | (r >> 2)] = x[r];
+    for (int m = 0; m < E; m++) buf[wbase + m * E] = x[m].y;
+    wave_lds_fence();
 #pragma unroll
-        for (int e = 0; e < E; e++) x[e] = y[e];
-    } else {
-        // E = 32: hi is lane bit 5 alone and trades places with register bit 0; e = (hi, m >> 1)
+    for (int e = 0; e < E; e++) x[e] = f32x2{nr[e], buf[e * 64 + lane + R::PADK * ((e * 64) >> (2 * B))]};
+    // ---- phase 3: stages 2B+1..BITS on the register index e ----
 #pragma unroll
-        for (int r = 0; r < E; r += 2) swap_lanes<32>(x[r], x[r + 1]);
-        f32x2 y[E];
-#pragma unroll
-        for (int r = 0; r < E; r++) y[((r & 1) << 4) | (r >> 1)] = x[r];
-#pragma unroll
-        for (int e = 0; e < E; e++) x[e] = y[e];
-    }
-    // ---- phase 3: stages 2B+1..BITS on bits 2B.. (register index e, bit st-1-6) ----
-#pragma unroll
-    for (int st = 2 * B + 1; st <= BITS; st++) {
-        const int halfe = 1 << (st - 1 - 6);
+    for (int st = 2 * B + 1; st <= R::BITS; st++) {
+        const int halfe = 1 << (st - 7);
 #pragma unroll
         for (int e0 = 0; e0 < E; e0++) {
             if (e0 & halfe) continue;
-            const int jj = ((e0 & (halfe - 1)) << 6) | lane;
-            const float2 t2 = stw[(1 << (st - 1)) - E + jj];
-            bfly(x[e0], x[e0 + halfe], f32x2{t2.x, t2.y});
+            bfly(x[e0], x[e0 + halfe], K.tw3[halfe - R::T3_FIRST + (e0 & (halfe - 1))]);
         }
     }
+    // ---- untangle.  Z[k] sits in register e of lane l for k = 64 e + l; its partner Z[M - k] in register E-1-e of
+    // lane 64 - l (lane 0: register E - e, and Z[0] pairs with itself).  The upper half of the spectrum goes through
+    // LDS as float2 slots (bin b -> slot b - M/2; slot M/2 holds Z[0]) and every lane reads its E/2 partners. ----
     wave_lds_fence();
-    // ---- power spectrum, bins k = e*64 + lane < N/2, into the (now free) buffer as float[N/2] ----
-    float* pw = reinterpret_cast<float*>(buf);
+    f32x2* ex = reinterpret_cast<f32x2*>(buf);
+#pragma unroll
+    for (int e = E / 2; e < E; e++) ex[(e - E / 2) * 64 + lane] = x[e];
+    if (lane == 0) ex[M / 2] = x[0];
+    wave_lds_fence();
+    f32x2 y[E / 2];
+#pragma unroll
+    for (int e = 0; e < E / 2; e++) y[e] = ex[M / 2 - 64 * e - lane];
+    wave_lds_fence();
+    // P[k] and P[M-k] from one (A, T); lane 0 also owns the self-paired bin M/2 (register E/2)
+    auto pair_power = [](f32x2 z, f32x2 yv, f32x2 w, float& pk, float& pmk) {
+        const f32x2 a = f32x2{z.x + yv.x, z.y - yv.y};
+        const f32x2 b = f32x2{z.x - yv.x, z.y + yv.y};
+        const f32x2 t = cmul_tw(b, w);                       // (Tr, Ti)
+        const f32x2 xk = f32x2{a.x + t.y, a.y - t.x};
+        const f32x2 xm = f32x2{a.x - t.y, a.y + t.x};
+        const f32x2 s1 = xk * xk, s2 = xm * xm;
+        pk = s1.x + s1.y;
+        pmk = s2.x + s2.y;
+    };
+    float pk[E / 2], pmk[E / 2], pmid, pdummy;
+#pragma unroll
+    for (int e = 0; e < E / 2; e++) pair_power(x[e], y[e], K.utw[e], pk[e], pmk[e]);
+    pair_power(x[E / 2], x[E / 2], f32x2{c_tw[512][0], c_tw[512][1]}, pmid, pdummy);
 #pragma unroll
     for (int e = 0; e < E / 2; e++) {
-        const f32x2 sq = x[e] * x[e];
-        pw[e * 64 + lane] = sq.x + sq.y;
+        buf[e * 64 + lane] = pk[e];
+        if (e > 0 || lane > 0) buf[M - e * 64 - lane] = pmk[e];
     }
+    if (lane == 0) buf[M / 2] = pmid;
     wave_lds_fence();
 }
+
+// ---- Haitsma STFT: band energies per frame --------------------------------------------------------
+constexpr int kFftWaves = 8;   // 2 waves per SIMD: the 2048-sample transform keeps ~100 loop-invariant registers per lane
+template <int N>
+struct FftLds {
+    float buf[kFftWaves][Rfft<N>::BUF_FLOATS];
+};
 
 template <int N, bool HAITSMA>
 __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float* __restrict__ x, size_t first_frame,
                                                          size_t n_frames, int hop, float* __restrict__ out,
                                                          const uint32_t* __restrict__ edges,
                                                          float* __restrict__ rowmax_out) {
+    using R = Rfft<N>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     FftLds<N>& L = *reinterpret_cast<FftLds<N>*>(lds_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    fill_stage_twiddles<N>(L.stw, threadIdx.x, kFftWaves * 64);
-    if (wave == 0) {   // a lane windows the same sample positions in every frame
-        float w0[N / 64];
-        frame_window<N>(lane, w0);
-#pragma unroll
-        for (int i = 0; i < N / 64; i++) L.win[i][lane] = w0[i];
-    }
-    __syncthreads();
-    float2* buf = reinterpret_cast<float2*>(L.buf[wave]);
-    const float* pw = L.buf[wave];
-    // frames are dealt to waves round-robin over the whole grid (three waves per SIMD cover the sample loads)
+    RfftConst<N> K;
+    rfft_consts<N>(lane, K);
+    float* buf = L.buf[wave];
+    const uint32_t nb = rfft_pair_base<N>(lane);
+    // frames are dealt to waves round-robin over the whole grid
     const uint32_t k0 = lane < kHkBands ? edges[lane] : 0u, k1 = lane < kHkBands ? edges[lane + 1] : 0u;
     const size_t step = (size_t)gridDim.x * kFftWaves;
     for (size_t f = (size_t)blockIdx.x * kFftWaves + wave; f < n_frames; f += step) {
-        float smp[N / 64], win[N / 64];
-        frame_load<N>(x + (first_frame + f) * (size_t)hop, lane, smp);
+        const float* src = x + (first_frame + f) * (size_t)hop;
+        f32x2 z[R::E];
 #pragma unroll
-        for (int i = 0; i < N / 64; i++) win[i] = L.win[i][lane];
-        wave_fft_power_core<N, true>(smp, win, lane, L.stw, buf);
+        for (int i = 0; i < R::E; i++) {
+            const uint32_t n = ((__brev((uint32_t)i) >> (32 - R::B)) << (R::BITS - R::B)) | nb;
+            z[i] = f32x2{src[2 * n], src[2 * n + 1]};
+        }
+#pragma unroll
+        for (int i = 0; i < R::E; i++) z[i] = z[i] * K.win[i];
+        wave_rfft_power<N>(z, K, lane, buf);
         {
             // lane b sums band b sequentially (same order as the oracle); eight spectrum reads are in flight at a time
+            const float* pw = buf;
             float e = 0.0f;
             uint32_t k = k0;
             for (; k + 8 <= k1; k += 8) {
@@ -338,10 +349,13 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
     }
 }
 
-// ---- A3 + A5 fused: STFT frames streamed through LDS, peaks picked without spilling the spectrogram ----
-// A workgroup (kSW waves) owns a segment of `seg` consecutive frames and walks it in rounds of kSW frames, one
-// FFT per wave (plus kRT halo frames on each side, recomputed: 14 / seg extra).  Of every frame only two
-// things survive in LDS:
+// ---- A1 + A3 + A5 fused: STFT frames streamed through LDS, peaks picked without spilling the spectrogram ----
+// The input is a RAGGED BATCH of clips (one clip = the single-stream entry points).  A workgroup (kSW waves) owns a
+// segment of `seg` consecutive frames of ONE clip and walks it in rounds of kSW frames, one FFT per wave (plus kRT
+// halo frames on each side, recomputed: 14 / seg extra).  Per round the workgroup also brings the next kSW * hop
+// samples at 8 kHz into an LDS ring -- two per thread: copied, or linearly interpolated from a clip at another rate
+// (A1: position exact in integers, x0 + (x1 - x0) * frac) -- so HBM sees every source sample once and the frames
+// (each sample belongs to 8 of them) are cut from LDS.  Of every frame only two things survive in LDS:
 //   ring    its +-kRK-bin running maximum ("row maximum"), 2 KiB, in a ring of kRing frames
 //   plist   its row-local peak candidates: bins with P == row maximum > 0 and no equal value among the kRK
 //           bins below (the same-row half of the tie rule) -- two of them are >= 16 bins apart, so <= 32 per frame
@@ -351,19 +365,40 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
 // skipped).  HBM sees the samples once and the peaks -- not 2 x 4 B x 512 bins per frame of spilled spectrum.
 constexpr int kSegMax = 512;    // frames per workgroup segment: long inputs (halo 14 / 512 = 2.7 %); short ones get
                                 // shorter segments so that ~1000 workgroups exist (wang_segment)
-constexpr int kSW = 12;      // waves per workgroup = frames in flight (LDS: 8.5 KiB FFT buffer each + the ring)
+constexpr int kSW = 12;      // waves per workgroup = frames in flight
 constexpr int kRing = 38;    // >= 2 kRT + 2 kSW: the rows being judged (one round behind) + the rows being produced
 constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
+constexpr int kSmpRing = 4096;                // 8 kHz samples staged per workgroup
+constexpr int kBatch = kSW * kWangHop;        // new samples per round = 2 per thread
+constexpr int kPrologue = 2560;               // samples staged before round 0: >= (kSW - 1) hop + N = 2432 (round 0 can
+                                              // be cut), <= kSmpRing - kBatch (a round's batch never lands on samples
+                                              // another wave may still be cutting its frame from)
+static_assert(kBatch == 2 * kSW * 64 && kPrologue >= (kSW - 1) * kWangHop + kWangN && kPrologue + kBatch <= kSmpRing, "");
+
+struct WangClip {
+    uint64_t src_off;   // first source sample of the clip in the batch buffer
+    uint64_t src_n;     // source samples
+    uint64_t n8k;       // samples at 8 kHz (= src_n when the input is at 8 kHz)
+    uint32_t frames;    // STFT frames
+    uint32_t n_sec;     // seconds holding at least one frame
+    uint32_t n_seg;     // workgroup segments
+    uint32_t pad;
+};
 
 struct WangStreamLds {
-    float2 stw[kWangN - kWangN / 64];
-    float buf[kSW][kWangN + 64];
-    float win[kWangN / 64][64];   // Hann window at this lane's 16 sample positions (registers are for the FFT)
+    float buf[kSW][1024];         // per wave: transpose 2, untangling exchange, power spectrum, row-maximum scratch
+    float smp[kSmpRing];          // the workgroup's 8 kHz samples, index swizzled (smp_swz)
     float ring[kRing][kWangBins];
     uint32_t pl_cnt[kRing];
     uint32_t pl_k[kRing][kPl];
     float pl_v[kRing][kPl];
 };
+static_assert(Rfft<kWangN>::BUF_FLOATS <= 1024, "");
+
+// A frame's pairs (x[2n], x[2n+1]) are read by ds_read_b64 with n = (register part) | (6 lane-dependent bits): the 32
+// lanes of a group then touch dwords {0-15, 64-79, 32-47, 96-111} + const, i.e. two bank quarters twice.  XOR-ing
+// dword-index bit 4 with bit 6 gives every 16-dword piece its own quarter of the 64 banks.
+__device__ __forceinline__ uint32_t smp_swz(uint32_t s) { return s ^ ((s >> 2) & 16u); }
 
 inline uint32_t wang_segment(size_t frames) {
     size_t seg = (frames + 1023) / 1024;
@@ -372,37 +407,105 @@ inline uint32_t wang_segment(size_t frames) {
     return (uint32_t)seg;
 }
 
-__global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __restrict__ x, size_t total_frames,
-                                                          uint32_t seg, uint32_t* __restrict__ cand_cnt,
+template <bool RESAMPLE>
+__global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __restrict__ pcm,
+                                                          const WangClip* __restrict__ clips,
+                                                          const uint32_t* __restrict__ seg_clip,
+                                                          const uint32_t* __restrict__ seg_base,
+                                                          const uint32_t* __restrict__ sec_base,
+                                                          const uint32_t* __restrict__ n_segs_total, uint32_t seg,
+                                                          uint32_t sr_in, const float* __restrict__ frac_tab,
+                                                          uint32_t* __restrict__ cand_cnt,
                                                           uint32_t* __restrict__ cand_t,
                                                           uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
+    if (blockIdx.x >= *n_segs_total) return;       // the grid is a host-side upper bound (whole workgroup leaves)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     WangStreamLds& L = *reinterpret_cast<WangStreamLds*>(lds_raw);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // frame and ring arithmetic stays scalar
-    fill_stage_twiddles<kWangN>(L.stw, threadIdx.x, kSW * 64);
-    if (wave == 0) {
-        float w0[kWangN / 64];
-        frame_window<kWangN>(lane, w0);
-#pragma unroll
-        for (int i = 0; i < kWangN / 64; i++) L.win[i][lane] = w0[i];
-    }
-    __syncthreads();
-    float2* buf = reinterpret_cast<float2*>(L.buf[wave]);
-    const float* pw = L.buf[wave];
-    const long total = (long)total_frames;
-    const long s0 = (long)blockIdx.x * seg;                        // frames [s0, s1) are this segment's to judge
+    const uint32_t clip = seg_clip[blockIdx.x];
+    const WangClip cl = clips[clip];
+    const float* __restrict__ x = pcm + cl.src_off;
+    const uint32_t sec0 = sec_base[clip];
+    RfftConst<kWangN> K;
+    rfft_consts<kWangN>(lane, K);
+    float* buf = L.buf[wave];
+    const float* pw = buf;
+    const long total = (long)cl.frames;
+    const long s0 = (long)(blockIdx.x - seg_base[clip]) * seg;      // frames [s0, s1) are this segment's to judge
     const long s1 = s0 + seg < total ? s0 + seg : total;
     const long f_lo = s0 - kRT < 0 ? 0 : s0 - kRT;                 // frames [f_lo, f_hi) are computed
     const long f_hi = s1 + kRT < total ? s1 + kRT : total;
-    // the Hann window of this lane's 16 sample positions, and the NEXT frame's samples: loaded one round ahead, so
-    // the HBM/L2 latency hides behind the current FFT instead of stalling every wave at the top of a round
-    float nxt[kWangN / 64];
+
+    // ---- sample staging.  Batch state (wave-uniform): b_i = 8 kHz index of the next batch's first sample; for a
+    // resampled clip that sample sits at source position b_q + b_r / 8000.  A thread fetches samples 2 tid, 2 tid + 1 of
+    // the batch into registers (the loads stay in flight across the FFT) and stores them at the end of the round. ----
+    uint64_t b_i = (uint64_t)f_lo * kWangHop;
+    uint64_t b_q = 0;
+    uint32_t b_r = 0;
+    if (RESAMPLE) {
+        const uint64_t num = b_i * sr_in;
+        b_q = num / (uint32_t)kWangSr;
+        b_r = (uint32_t)(num - b_q * (uint32_t)kWangSr);
+    }
+    float sx0[2], sx1[2], sfr[2];
+    const uint32_t j0 = 2u * threadIdx.x;
+    auto fetch = [&](uint32_t count) {
 #pragma unroll
-    for (int i = 0; i < kWangN / 64; i++) nxt[i] = 0.0f;
-    if (f_lo + wave < f_hi) frame_load<kWangN>(x + (size_t)(f_lo + wave) * kWangHop, lane, nxt);
+        for (int u = 0; u < 2; u++) {
+            const uint32_t j = j0 + u;
+            const uint64_t i = b_i + j;
+            sx0[u] = 0.0f;
+            sx1[u] = 0.0f;
+            sfr[u] = 0.0f;
+            if (j < count && i < cl.n8k) {
+                if (RESAMPLE) {
+                    const uint32_t num = b_r + j * sr_in;                 // < 2^32: sr_in <= 2^21, j < 1536
+                    const uint32_t qd = num / (uint32_t)kWangSr;
+                    const uint32_t rem = num - qd * (uint32_t)kWangSr;
+                    const uint64_t idx = b_q + qd;
+                    sx0[u] = x[idx];
+                    sx1[u] = x[idx + 1 < cl.src_n ? idx + 1 : cl.src_n - 1];
+                    sfr[u] = frac_tab[rem];
+                } else {
+                    sx0[u] = x[i];
+                }
+            }
+        }
+    };
+    auto store = [&](uint32_t count) {
+        float v[2];
 #pragma unroll
-    for (int i = 0; i < kWangN / 64; i++) asm volatile("" : "+v"(nxt[i]));   // taken in before the loop (see below)
+        for (int u = 0; u < 2; u++) {
+            if (RESAMPLE) {
+                const float d = sx1[u] - sx0[u];
+                const float mm = d * sfr[u];
+                v[u] = sx0[u] + mm;
+            } else {
+                v[u] = sx0[u];
+            }
+        }
+        if (j0 < count) {
+            const uint32_t s = smp_swz(((uint32_t)b_i + j0) & (uint32_t)(kSmpRing - 1));   // even: the pair stays together
+            *reinterpret_cast<float2*>(&L.smp[s]) = make_float2(v[0], v[1]);
+        }
+        b_i += count;
+        if (RESAMPLE) {
+            const uint32_t num = b_r + count * sr_in;
+            const uint32_t qd = num / (uint32_t)kWangSr;
+            b_q += qd;
+            b_r = num - qd * (uint32_t)kWangSr;
+        }
+    };
+    fetch(kPrologue - kBatch);
+    store(kPrologue - kBatch);
+    fetch(kBatch);
+    store(kBatch);
+    __syncthreads();
+    // this lane's sample-pair offset inside a frame: dword 2 n, n = (rev(i) << 6) | nb; the swizzle only touches the
+    // lane part (2 nb < 128), the register part + the frame start are wave-uniform
+    const uint32_t nb2 = smp_swz(2u * rfft_pair_base<kWangN>(lane));
+
     int slot = (int)((f_lo + wave) % kRing);                       // ring row of frame base + wave
     // a found peak waits one round for its slot: the atomic's round trip overlaps the next FFT
     bool pend = false, pend_wave = false;      // pend_wave: wave-uniform "an atomic is in flight"
@@ -427,10 +530,8 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
         // ---- judge frame base + wave - kSW - kRT: its window [t - kRT, t + kRT] was complete at the last barrier, so
         // this overlaps the other waves' FFTs instead of standing between two barriers of its own ----
         flush();
-        // The prefetched samples are taken in HERE (they landed during the last FFT): returns come back in order, so
-        // a wait for them placed after the judge's atomic would wait for the atomic as well.
-#pragma unroll
-        for (int i = 0; i < kWangN / 64; i++) asm volatile("" : "+v"(nxt[i]));
+        // next round's samples: requested now, stored behind the FFT
+        fetch(kBatch);
         const long t = f - kSW - kRT;
         if (t >= s0 && t < s1) {
             int st = slot - kSW - kRT;
@@ -477,7 +578,7 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
             // (s_waitcnt vmcnt(0) + v_readfirstlane right behind the atomic), which parks every wave for the trip.
             const uint64_t pm = __ballot(is_peak);
             if (pm) {
-                const uint32_t sec = (uint32_t)(((size_t)t * kWangHop) / kWangSr);
+                const uint32_t sec = sec0 + (uint32_t)(((size_t)t * kWangHop) / kWangSr);
                 pend = is_peak;
                 pend_sec = sec;
                 pend_t = (uint32_t)t;
@@ -497,21 +598,26 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
         }
         // ---- produce frame base + wave ----
         if (f < f_hi) {
-            float smp[kWangN / 64], win[kWangN / 64];
+            f32x2 z[kWangN / 128];
+            {
+                // frame start in the ring, in units of 128 dwords (the hop): wave-uniform
+                const uint32_t fs = (uint32_t)(((uint64_t)f * kWangHop) & (uint64_t)(kSmpRing - 1)) >> 7;
 #pragma unroll
-            for (int i = 0; i < kWangN / 64; i++) {
-                smp[i] = nxt[i];
-                win[i] = L.win[i][lane];
+                for (int i = 0; i < kWangN / 128; i++) {
+                    const uint32_t ri = __brev((uint32_t)i) >> 29;                       // 3-bit reversal: n = (ri << 6) | nb
+                    const uint32_t blk = (fs + ri) & (uint32_t)(kSmpRing / 128 - 1);     // scalar
+                    const float2 v = *reinterpret_cast<const float2*>(&L.smp[(blk << 7) | nb2]);
+                    z[i] = f32x2{v.x, v.y} * K.win[i];
+                }
             }
-            if (f + kSW < f_hi) frame_load<kWangN>(x + (size_t)(f + kSW) * kWangHop, lane, nxt);
-            wave_fft_power_core<kWangN, true>(smp, win, lane, L.stw, buf);
+            wave_rfft_power<kWangN>(z, K, lane, buf);
             // Row maximum over +-kRK bins and the same-row tie test, blocked: lane L owns bins 8L .. 8L+7.  The
             // window [k-15, k+15] of bin k = 8L + j is  suffix_{L-2}[j+1] u block_{L-1} u block_L u block_{L+1} u
             // prefix_{L+2}[j-1], and the 15 bins below k are  suffix_{L-2}[j+1] u block_{L-1} u prefix_L[j-1]:
             // 14 maxima per lane for the prefix / suffix tables, two LDS exchanges, instead of 31 taps per bin.
             // P >= 0, so -1 stands for "no bin there" (a clamped duplicate never changes a maximum either).
             float* row = L.ring[slot];
-            float* sx = L.buf[wave];      // scratch OVER the spectrum (b8 is read first; the LDS keeps a wave's order):
+            float* sx = buf;              // scratch OVER the spectrum (b8 is read first; the LDS keeps a wave's order):
             float* px = sx + 64 * 7;      // [lane][7] suffix 1..7, [lane][8] prefix (row strides 7 and 9: conflict-free)
             float b8[8], pre[8], suf[8];
             {
@@ -578,7 +684,8 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                 L.pl_cnt[slot] = npl < (uint32_t)kPl ? npl : (uint32_t)kPl;
             }
         }
-        __syncthreads();   // the only one per round: rows base .. base + kSW - 1 are complete
+        store(kBatch);     // the samples of the next round's frames (requested at the top of this round)
+        __syncthreads();   // the only one per round: rows base .. base + kSW - 1 and the next samples are complete
         slot = slot + kSW >= kRing ? slot + kSW - kRing : slot + kSW;
     }
     flush();
@@ -589,6 +696,7 @@ __global__ __launch_bounds__(64) void wang_select_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ cand_t,
                                                          const uint32_t* __restrict__ cand_k,
                                                          const float* __restrict__ cand_p, uint32_t pps,
+                                                         const uint32_t* __restrict__ n_sec_total,
                                                          uint32_t* __restrict__ sel_cnt, uint32_t* __restrict__ sel_t,
                                                          uint32_t* __restrict__ sel_k, float* __restrict__ sel_p) {
     __shared__ uint32_t st[kCandCap], sk[kCandCap];
@@ -596,6 +704,10 @@ __global__ __launch_bounds__(64) void wang_select_kernel(const uint32_t* __restr
     __shared__ uint8_t keep[kCandCap];
     const uint32_t sec = blockIdx.x;
     const int lane = threadIdx.x;
+    if (sec >= *n_sec_total) {            // the grid is a host-side upper bound
+        if (lane == 0) sel_cnt[sec] = 0;
+        return;
+    }
     uint32_t n = cand_cnt[sec];
     n = n < (uint32_t)kCandCap ? n : (uint32_t)kCandCap;
     for (uint32_t i = lane; i < n; i += 64) {
@@ -727,8 +839,9 @@ void launch_exclusive_scan(const uint32_t* in, size_t n, uint32_t* out, uint32_t
 
 __global__ void wang_compact_kernel(const uint32_t* __restrict__ sel_cnt, const uint32_t* __restrict__ sel_off,
                                     const uint32_t* __restrict__ sel_t, const uint32_t* __restrict__ sel_k,
-                                    const float* __restrict__ sel_p, uint32_t n_sec, uint32_t pps,
-                                    uint32_t* __restrict__ pt, uint32_t* __restrict__ pk, float* __restrict__ pp) {
+                                    const float* __restrict__ sel_p, const uint32_t* __restrict__ sec_clip,
+                                    uint32_t n_sec, uint32_t pps, uint32_t* __restrict__ pt, uint32_t* __restrict__ pk,
+                                    float* __restrict__ pp, uint32_t* __restrict__ pc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n_sec * pps) return;
     const uint32_t sec = (uint32_t)(i / pps), j = (uint32_t)(i - (size_t)sec * pps);
@@ -737,12 +850,14 @@ __global__ void wang_compact_kernel(const uint32_t* __restrict__ sel_cnt, const 
     pt[o] = sel_t[i];
     pk[o] = sel_k[i];
     pp[o] = sel_p[i];
+    pc[o] = sec_clip[sec];
 }
 
 // ---- A6: pairing (src/modality/audio.rs:965-1003) ------------------------------------------------
 template <bool EMIT>
 __global__ void wang_pair_kernel(const uint32_t* __restrict__ pt, const uint32_t* __restrict__ pk,
-                                 const float* __restrict__ pp, const uint32_t* __restrict__ np_ptr,
+                                 const float* __restrict__ pp, const uint32_t* __restrict__ pc,
+                                 const uint32_t* __restrict__ np_ptr,
                                  uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, float floor_p,
                                  uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
                                  uint32_t* __restrict__ out, size_t cap) {
@@ -751,9 +866,10 @@ __global__ void wang_pair_kernel(const uint32_t* __restrict__ pt, const uint32_t
     if (i >= np) return;
     uint32_t taken = 0;
     if (pp[i] >= floor_p) {
-        const uint32_t ta = pt[i], ka = pk[i];
+        const uint32_t ta = pt[i], ka = pk[i], ca = pc[i];
         size_t o = EMIT ? offs[i] : 0;
         for (uint32_t j = i + 1; j < np && taken < fan_out; j++) {
+            if (pc[j] != ca) break;                        // the peaks of a clip are contiguous: the next clip starts here
             const int32_t dt = (int32_t)pt[j] - (int32_t)ta;
             if (dt <= 0) continue;
             if (dt > (int32_t)zone_t) break;
@@ -772,6 +888,51 @@ __global__ void wang_pair_kernel(const uint32_t* __restrict__ pt, const uint32_t
 }
 
 __global__ void copy_u32_kernel(const uint32_t* __restrict__ src, uint64_t* __restrict__ dst) { *dst = *src; }
+
+// ---- the ragged batch: clip table, segment -> clip and second -> clip maps, per-clip hash offsets ----
+// one thread per clip.  offsets == nullptr: a single clip [0, n_single)
+__global__ void wang_clip_prep_kernel(const uint64_t* __restrict__ offsets, uint64_t n_single, uint32_t n_clips,
+                                      uint32_t sr_in, uint32_t seg, WangClip* __restrict__ clips,
+                                      uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ sec_cnt) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clips) return;
+    WangClip cl;
+    cl.src_off = offsets ? offsets[c] : 0;
+    cl.src_n = offsets ? offsets[c + 1] - offsets[c] : n_single;
+    cl.n8k = sr_in == (uint32_t)kWangSr ? cl.src_n : (uint64_t)(((unsigned __int128)cl.src_n * kWangSr) / sr_in);
+    const uint64_t fr = cl.n8k >= (uint64_t)kWangN ? 1 + (cl.n8k - kWangN) / kWangHop : 0;
+    cl.frames = (uint32_t)fr;
+    cl.n_sec = fr ? (uint32_t)(((fr - 1) * kWangHop) / kWangSr + 1) : 0;
+    cl.n_seg = (uint32_t)((fr + seg - 1) / seg);
+    cl.pad = 0;
+    clips[c] = cl;
+    seg_cnt[c] = cl.n_seg;
+    sec_cnt[c] = cl.n_sec;
+}
+// base[0..n_clips] ascending (exclusive scan of counts); entry g of the map = the clip c with base[c] <= g < base[c+1]
+__device__ __forceinline__ uint32_t clip_of(const uint32_t* __restrict__ base, uint32_t n_clips, uint32_t g) {
+    uint32_t lo = 0, hi = n_clips;                 // first index in (0, n_clips] with base[idx] > g, minus one
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (base[mid + 1] > g) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+__global__ void wang_clip_map_kernel(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ sec_base,
+                                     uint32_t n_clips, uint32_t* __restrict__ seg_clip, uint32_t* __restrict__ sec_clip) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < seg_base[n_clips]) seg_clip[g] = clip_of(seg_base, n_clips, g);
+    if (g < sec_base[n_clips]) sec_clip[g] = clip_of(sec_base, n_clips, g);
+}
+// hashes of clip c = out[out_off[c] .. out_off[c+1]): the pair offset of the clip's first peak
+__global__ void wang_clip_offsets_kernel(const uint32_t* __restrict__ sec_base, const uint32_t* __restrict__ sel_off,
+                                         const uint32_t* __restrict__ pair_off, uint32_t n_clips,
+                                         uint64_t* __restrict__ out_off) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_clips) return;
+    out_off[c] = pair_off[sel_off[sec_base[c]]];
+}
 
 // ---- A8 ------------------------------------------------------------------------------------
 __global__ void haitsma_bits_kernel(const float* __restrict__ E, size_t first, size_t n, uint32_t* __restrict__ out) {
@@ -815,14 +976,26 @@ size_t audio_stft_frames(size_t n, int N, int hop) { return n >= (size_t)N ? 1 +
 // ---- Wang orchestration ------------------------------------------------------------------------
 constexpr size_t kChunkFrames = 32768;  // Haitsma band energies are produced in chunks of 4 x this many frames
 
-WangWs wang_ws_layout(size_t n_samples, uint32_t pps) {
+WangWs wang_ws_layout(size_t n_src_total, size_t n_clips, uint32_t sr_in, uint32_t pps) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     WangWs w;
-    w.frames = audio_stft_frames(n_samples, kWangN, kWangHop);
-    w.n_sec = w.frames ? (uint32_t)(((w.frames - 1) * kWangHop) / kWangSr + 1) : 0;
+    // upper bounds from what the host knows (the per-clip lengths live on the device): sum of floors <= floor of sum
+    const size_t n8k = sr_in == (uint32_t)kWangSr ? n_src_total
+                                                   : (size_t)(((unsigned __int128)n_src_total * kWangSr) / sr_in);
+    w.frames = n8k / kWangHop + 1;                                   // frames_c < n8k_c / hop
+    w.seg = wang_segment(w.frames);
+    w.n_seg = (uint32_t)(w.frames / w.seg + n_clips + 1);
+    w.n_sec = (uint32_t)((w.frames * kWangHop) / kWangSr + n_clips + 1);
+    w.n_clips = (uint32_t)n_clips;
     size_t off = 0;
-    w.P = off;        // (the spectrogram is no longer spilled: wang_stream_kernel)
-    w.rowmax = off;
+    w.clips = off;    off = align(off + n_clips * sizeof(WangClip));
+    w.seg_cnt = off;  off = align(off + (n_clips + 1) * 4);
+    w.seg_base = off; off = align(off + (n_clips + 1) * 4);
+    w.sec_cnt = off;  off = align(off + (n_clips + 1) * 4);
+    w.sec_base = off; off = align(off + (n_clips + 1) * 4);
+    w.seg_clip = off; off = align(off + (size_t)w.n_seg * 4);
+    w.sec_clip = off; off = align(off + (size_t)w.n_sec * 4);
+    w.out_off = off;  off = align(off + (n_clips + 1) * 8);
     w.cand_cnt = off; off = align(off + (size_t)w.n_sec * 4);
     w.cand_t = off;   off = align(off + (size_t)w.n_sec * kCandCap * 4);
     w.cand_k = off;   off = align(off + (size_t)w.n_sec * kCandCap * 4);
@@ -836,47 +1009,82 @@ WangWs wang_ws_layout(size_t n_samples, uint32_t pps) {
     w.pt = off;       off = align(off + maxp * 4);
     w.pk = off;       off = align(off + maxp * 4);
     w.pp = off;       off = align(off + maxp * 4);
+    w.pc = off;       off = align(off + maxp * 4);
     w.pair_cnt = off; off = align(off + (maxp + 1) * 4);
     w.pair_off = off; off = align(off + (maxp + 1) * 4);
-    w.scan_tmp = off; off = align(off + 2 * (maxp / 4096 + 4) * 4);
+    const size_t scan_n = maxp > n_clips ? maxp : n_clips;
+    w.scan_tmp = off; off = align(off + 2 * (scan_n / 4096 + 4) * 4);
     w.total = off + 256;
     return w;
 }
 
-int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
-                float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* out_count,
-                hipStream_t stream) {
-    if (w.frames == 0 || pps == 0) {
-        (void)hipMemsetAsync(out_count, 0, 8, stream);
+// pcm: the batch buffer; d_offsets: n_clips + 1 device offsets into it (nullptr: one clip [0, n_src_total)); sr_in: the
+// clips' sample rate (8000: taken as is; anything else: resampled to 8 kHz inside the stream kernel, A1);
+// d_out_off: n_clips + 1 hash offsets (may be nullptr); out_count: total hashes produced (may be nullptr)
+int launch_wang_batch(const float* pcm, const uint64_t* d_offsets, size_t n_src_total, size_t n_clips, uint32_t sr_in,
+                      const float* frac_tab, uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
+                      float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* d_out_off,
+                      uint64_t* out_count, hipStream_t stream) {
+    if (n_clips == 0 || pps == 0) {
+        if (out_count) (void)hipMemsetAsync(out_count, 0, 8, stream);
+        if (d_out_off) (void)hipMemsetAsync(d_out_off, 0, (n_clips + 1) * 8, stream);
         return 0;
     }
     auto f32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+    WangClip* clips = reinterpret_cast<WangClip*>(ws + w.clips);
+    const uint32_t nc = (uint32_t)n_clips;
+    hipLaunchKernelGGL(wang_clip_prep_kernel, dim3(blocks_for(n_clips, 256)), dim3(256), 0, stream, d_offsets,
+                       (uint64_t)n_src_total, nc, sr_in, w.seg, clips, u32(w.seg_cnt), u32(w.sec_cnt));
+    launch_exclusive_scan(u32(w.seg_cnt), n_clips, u32(w.seg_base), u32(w.scan_tmp), stream);
+    launch_exclusive_scan(u32(w.sec_cnt), n_clips, u32(w.sec_base), u32(w.scan_tmp), stream);
+    const size_t map_n = w.n_seg > w.n_sec ? w.n_seg : w.n_sec;
+    hipLaunchKernelGGL(wang_clip_map_kernel, dim3(blocks_for(map_n, 256)), dim3(256), 0, stream,
+                       (const uint32_t*)u32(w.seg_base), (const uint32_t*)u32(w.sec_base), nc, u32(w.seg_clip),
+                       u32(w.sec_clip));
+    const uint32_t* n_segs_total = u32(w.seg_base) + n_clips;
+    const uint32_t* n_sec_total = u32(w.sec_base) + n_clips;
     (void)hipMemsetAsync(u32(w.cand_cnt), 0, (size_t)w.n_sec * 4, stream);
     const size_t lds = sizeof(WangStreamLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wang_stream_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const uint32_t seg = wang_segment(w.frames);
-    hipLaunchKernelGGL(wang_stream_kernel, dim3((unsigned)((w.frames + seg - 1) / seg)), dim3(kSW * 64), lds, stream, pcm8k,
-                       w.frames, seg, u32(w.cand_cnt), u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
+    if (sr_in == (uint32_t)kWangSr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wang_stream_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(wang_stream_kernel<false>, dim3(w.n_seg), dim3(kSW * 64), lds, stream, pcm,
+                           (const WangClip*)clips, (const uint32_t*)u32(w.seg_clip), (const uint32_t*)u32(w.seg_base),
+                           (const uint32_t*)u32(w.sec_base), n_segs_total, w.seg, sr_in, frac_tab, u32(w.cand_cnt),
+                           u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wang_stream_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(wang_stream_kernel<true>, dim3(w.n_seg), dim3(kSW * 64), lds, stream, pcm,
+                           (const WangClip*)clips, (const uint32_t*)u32(w.seg_clip), (const uint32_t*)u32(w.seg_base),
+                           (const uint32_t*)u32(w.sec_base), n_segs_total, w.seg, sr_in, frac_tab, u32(w.cand_cnt),
+                           u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
+    }
     hipLaunchKernelGGL(wang_select_kernel, dim3(w.n_sec), dim3(64), 0, stream, u32(w.cand_cnt), u32(w.cand_t),
-                       u32(w.cand_k), f32(w.cand_p), pps, u32(w.sel_cnt), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p));
+                       u32(w.cand_k), f32(w.cand_p), pps, n_sec_total, u32(w.sel_cnt), u32(w.sel_t), u32(w.sel_k),
+                       f32(w.sel_p));
     launch_exclusive_scan(u32(w.sel_cnt), (size_t)w.n_sec, u32(w.sel_off), u32(w.scan_tmp), stream);
     hipLaunchKernelGGL(wang_compact_kernel, dim3(blocks_for((size_t)w.n_sec * pps, 256)), dim3(256), 0, stream,
-                       u32(w.sel_cnt), u32(w.sel_off), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p), w.n_sec, pps,
-                       u32(w.pt), u32(w.pk), f32(w.pp));
+                       u32(w.sel_cnt), u32(w.sel_off), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p),
+                       (const uint32_t*)u32(w.sec_clip), w.n_sec, pps, u32(w.pt), u32(w.pk), f32(w.pp), u32(w.pc));
     const size_t maxp = (size_t)w.n_sec * pps;
     const uint32_t* np_ptr = u32(w.sel_off) + w.n_sec;  // total peaks
     (void)hipMemsetAsync(u32(w.pair_cnt), 0, (maxp + 1) * 4, stream);
     hipLaunchKernelGGL(wang_pair_kernel<false>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
-                       u32(w.pk), f32(w.pp), np_ptr, fan_out, zone_t, zone_f, floor_power, u32(w.pair_cnt),
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
+                       u32(w.pk), f32(w.pp), (const uint32_t*)u32(w.pc), np_ptr, fan_out, zone_t, zone_f, floor_power,
+                       u32(w.pair_cnt), (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
     launch_exclusive_scan(u32(w.pair_cnt), maxp, u32(w.pair_off), u32(w.scan_tmp), stream);
     hipLaunchKernelGGL(wang_pair_kernel<true>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
-                       u32(w.pk), f32(w.pp), np_ptr, fan_out, zone_t, zone_f, floor_power, (uint32_t*)nullptr,
-                       (const uint32_t*)u32(w.pair_off), out, cap);
-    hipLaunchKernelGGL(copy_u32_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)(u32(w.pair_off) + maxp),
-                       out_count);
+                       u32(w.pk), f32(w.pp), (const uint32_t*)u32(w.pc), np_ptr, fan_out, zone_t, zone_f, floor_power,
+                       (uint32_t*)nullptr, (const uint32_t*)u32(w.pair_off), out, cap);
+    if (out_count)
+        hipLaunchKernelGGL(copy_u32_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)(u32(w.pair_off) + maxp),
+                           out_count);
+    if (d_out_off)
+        hipLaunchKernelGGL(wang_clip_offsets_kernel, dim3(blocks_for(n_clips + 1, 256)), dim3(256), 0, stream,
+                           (const uint32_t*)u32(w.sec_base), (const uint32_t*)u32(w.sel_off),
+                           (const uint32_t*)u32(w.pair_off), nc, d_out_off);
     return 0;
 }
 

@@ -60,6 +60,7 @@ struct ucfp_ctx {
     uint8_t* audio_ws = nullptr;
     size_t audio_ws_cap = 0;
     hipEvent_t audio_done = nullptr;
+    float* frac8000 = nullptr;   // A1 interpolation weights (float)((double)rem / 8000.0), rem = 0..7999 (Wang's fused resampler)
 };
 
 namespace {
@@ -130,6 +131,12 @@ int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
     if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->audio_done, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->norm_done, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipMalloc((void**)&c->frac8000, 8000 * sizeof(float));
+    if (e2 == hipSuccess) {
+        std::vector<float> tab(8000);
+        for (uint32_t r = 0; r < 8000; r++) tab[r] = (float)((double)r / (double)8000);   // the oracle's expression
+        e2 = hipMemcpy(c->frac8000, tab.data(), 8000 * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e2 != hipSuccess) {
         ucfp_ctx_destroy(c);
         return fail(UCFP_E_INDEX, "context allocation failed: %s", hipGetErrorString(e2));
@@ -148,6 +155,7 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->audio_ws) (void)hipFree(c->audio_ws);
     if (c->audio_done) (void)hipEventDestroy(c->audio_done);
     if (c->norm_done) (void)hipEventDestroy(c->norm_done);
+    if (c->frac8000) (void)hipFree(c->frac8000);
     delete c;
 }
 
@@ -253,6 +261,40 @@ size_t ucfp_audio_wang_max_hashes(size_t n_samples, const ucfp_wang_config* cfg)
     return n_sec * c.peaks_per_sec * c.fan_out;
 }
 
+size_t ucfp_audio_wang_batch_max_hashes(size_t n_total, size_t n_clips, uint32_t sample_rate,
+                                        const ucfp_wang_config* cfg) {
+    if (!sample_rate || !n_clips) return 0;
+    const ucfp_wang_config c = cfg ? *cfg : wang_defaults();
+    const ucfp::WangWs w = ucfp::wang_ws_layout(n_total, n_clips, sample_rate, c.peaks_per_sec);
+    return (size_t)w.n_sec * c.peaks_per_sec * c.fan_out;
+}
+
+// shared by the single-stream and the batch entry point
+static int wang_batch_impl(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_offsets, size_t n_total, size_t n_clips,
+                           uint32_t sample_rate, const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes,
+                           uint64_t* d_out_offsets, uint64_t* d_n_hashes, hipStream_t st) {
+    const ucfp_wang_config c = cfg ? *cfg : wang_defaults();
+    int rc = wang_cfg_check(c);
+    if (rc) return rc;
+    if (n_clips > 0x7fffffffu || n_total > ((size_t)1 << 46))
+        return fail(UCFP_E_INVALID, "audio batch too large for one call");
+    const ucfp::WangWs w = ucfp::wang_ws_layout(n_total, n_clips, sample_rate, c.peaks_per_sec);
+    if (w.n_seg > 0x7fffffffu || (size_t)w.n_sec * c.peaks_per_sec > 0x7fffffffu)
+        return fail(UCFP_E_INVALID, "audio batch too large for one call");
+    const float floor_p = (float)(65536.0 * pow(10.0, (double)c.min_anchor_mag_db / 10.0));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = grow(&ctx->audio_ws, &ctx->audio_ws_cap, w.total);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, ctx->audio_done, 0));
+    ucfp::launch_wang_batch(d_pcm, d_offsets, n_total, n_clips, sample_rate, ctx->frac8000, c.fan_out, c.target_zone_t,
+                            c.target_zone_f, c.peaks_per_sec, floor_p, ctx->audio_ws, w,
+                            reinterpret_cast<uint32_t*>(d_out), cap_hashes, d_out_offsets, d_n_hashes, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->audio_done, st));
+    return UCFP_OK;
+}
+
 int ucfp_audio_wang_dev(ucfp_ctx* ctx, const float* d_pcm, size_t n, uint32_t sample_rate,
                         const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes, uint64_t* d_n_hashes,
                         void* stream) {
@@ -260,22 +302,20 @@ int ucfp_audio_wang_dev(ucfp_ctx* ctx, const float* d_pcm, size_t n, uint32_t sa
     if (!d_n_hashes || (n && !d_pcm) || (cap_hashes && !d_out)) return fail(UCFP_E_INVALID, "NULL buffer");
     if (sample_rate != 8000)
         return fail(UCFP_E_MODALITY, "Wang requires 8 kHz mono input (got %u Hz); resample upstream", sample_rate);
-    const ucfp_wang_config c = cfg ? *cfg : wang_defaults();
-    int rc = wang_cfg_check(c);
-    if (rc) return rc;
-    const ucfp::WangWs w = ucfp::wang_ws_layout(n, c.peaks_per_sec);
-    const float floor_p = (float)(65536.0 * pow(10.0, (double)c.min_anchor_mag_db / 10.0));
-    hipStream_t st = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
-    rc = grow(&ctx->audio_ws, &ctx->audio_ws_cap, w.total);
-    if (rc) return rc;
-    HIP_TRY(hipStreamWaitEvent(st, ctx->audio_done, 0));
-    ucfp::launch_wang(d_pcm, n, c.fan_out, c.target_zone_t, c.target_zone_f, c.peaks_per_sec, floor_p, ctx->audio_ws,
-                      w, reinterpret_cast<uint32_t*>(d_out), cap_hashes, d_n_hashes, st);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->audio_done, st));
-    return UCFP_OK;
+    return wang_batch_impl(ctx, d_pcm, nullptr, n, 1, sample_rate, cfg, d_out, cap_hashes, nullptr, d_n_hashes,
+                           (hipStream_t)stream);
+}
+
+int ucfp_audio_wang_batch_dev(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_offsets, size_t n_total, size_t n_clips,
+                              uint32_t sample_rate, const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes,
+                              uint64_t* d_out_offsets, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (!d_out_offsets || (n_clips && !d_offsets) || (n_total && !d_pcm) || (cap_hashes && !d_out))
+        return fail(UCFP_E_INVALID, "NULL buffer");
+    if (sample_rate < 1000 || sample_rate > 384000)
+        return fail(UCFP_E_MODALITY, "invalid sample rate %u (1 000 .. 384 000 Hz)", sample_rate);
+    return wang_batch_impl(ctx, d_pcm, d_offsets, n_total, n_clips, sample_rate, cfg, d_out, cap_hashes, d_out_offsets,
+                           nullptr, (hipStream_t)stream);
 }
 
 int ucfp_audio_wang(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate, const ucfp_wang_config* cfg,

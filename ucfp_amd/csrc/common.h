@@ -115,19 +115,20 @@ int launch_text_simhash(const uint8_t* utf8, const uint64_t* offsets, size_t n, 
 
 // audio.hip
 struct WangWs {
-    size_t frames = 0;
-    uint32_t n_sec = 0;
-    size_t P, rowmax, cand_cnt, cand_t, cand_k, cand_p, sel_cnt, sel_off, sel_t, sel_k, sel_p, pt, pk, pp, pair_cnt,
-        pair_off, scan_tmp, total = 0;
+    size_t frames = 0;          // upper bounds (the per-clip lengths of a batch live on the device)
+    uint32_t n_sec = 0, n_seg = 0, seg = 0, n_clips = 0;
+    size_t clips, seg_cnt, seg_base, sec_cnt, sec_base, seg_clip, sec_clip, out_off, cand_cnt, cand_t, cand_k, cand_p,
+        sel_cnt, sel_off, sel_t, sel_k, sel_p, pt, pk, pp, pc, pair_cnt, pair_off, scan_tmp, total = 0;
 };
 size_t audio_resample_len(size_t n, uint32_t sr_in, uint32_t sr_out);
 int launch_resample_linear(const float* in, size_t n, uint32_t sr_in, uint32_t sr_out, float* out,
                            hipStream_t stream);
 size_t audio_stft_frames(size_t n, int N, int hop);
-WangWs wang_ws_layout(size_t n_samples, uint32_t pps);
-int launch_wang(const float* pcm8k, size_t n, uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
-                float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* out_count,
-                hipStream_t stream);
+WangWs wang_ws_layout(size_t n_src_total, size_t n_clips, uint32_t sr_in, uint32_t pps);
+int launch_wang_batch(const float* pcm, const uint64_t* d_offsets, size_t n_src_total, size_t n_clips, uint32_t sr_in,
+                      const float* frac_tab, uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
+                      float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* d_out_off,
+                      uint64_t* out_count, hipStream_t stream);
 size_t haitsma_ws_bytes(size_t n5k);
 int launch_haitsma(const float* pcm5k, size_t n, const uint32_t* h_edges, uint8_t* ws, uint32_t* out,
                    hipStream_t stream);

@@ -58,10 +58,11 @@ static uint32_t bitrev(uint32_t x, int bits) {
  *   FFT     in-place radix-2 DIT over z, M points; in stages 1..3 a twiddle 1 is a pure add/subtract and a twiddle
  *           -i is (xi, -xr); every other butterfly (and EVERY butterfly from stage 4 on, whatever its twiddle) is the
  *           general one  t1 = xr c, t2 = xi s, t3 = xr s, t4 = xi c, v = (t1 - t2, t3 + t4), u' = u + v, x' = u - v
- *   untangle for k = 0..M/2, with Y = Z[(M-k) mod M] and W = TW_N^k = (c, s):
+ *   untangle for k = 0..M/2-1, with Y = Z[(M-k) mod M] and W = TW_N^k = (c, s)  (bin M/2 pairs with itself:
+ *           P[M/2] = (2 Zr)^2 + (2 Zi)^2):
  *           A = (Zr + Yr, Zi - Yi)   B = (Zr - Yr, Zi + Yi)   T = (Br c - Bi s, Br s + Bi c)
  *           X[k]   = (Ar + Ti, Ai - Tr)            P[k]   = Xr*Xr + Xi*Xi
- *           X[M-k] = (Ar - Ti, Ai + Tr) (conj.)    P[M-k] = ...           for 0 < k < M/2
+ *           X[M-k] = (Ar - Ti, Ai + Tr) (conj.)    P[M-k] = ...           for k > 0
  * Half the butterflies of a complex N-point transform; the HIP kernels (audio.hip, wave_rfft_power) perform the
  * same single f32 operations in the same order.  The order is OURS (audiofp's is unknown: parity unpinned). */
 static float half_hann(int m, int N) {
@@ -107,7 +108,12 @@ static void frame_power(const float* x, int N, float* P, float* re, float* im) {
                 im[i1] = ui - vi;
             }
     }
-    for (int k = 0; k <= M / 2; k++) {
+    {   /* the self-paired bin M/2: A = (2 Zr, 0), B = (0, 2 Zi), W = -i  =>  X = (2 Zr, -2 Zi) */
+        const float xr = re[M / 2] + re[M / 2], xi = im[M / 2] + im[M / 2];
+        const float p1 = xr * xr, p2 = xi * xi;
+        P[M / 2] = p1 + p2;
+    }
+    for (int k = 0; k < M / 2; k++) {
         const int kk = (M - k) & (M - 1);
         const float zr = re[k], zi = im[k], yr = re[kk], yi = im[kk];
         const float ar = zr + yr, ai = zi - yi, br = zr - yr, bi = zi + yi;
@@ -117,7 +123,7 @@ static void frame_power(const float* x, int N, float* P, float* re, float* im) {
         const float xr = ar + ti, xi = ai - tr;
         const float p1 = xr * xr, p2 = xi * xi;
         P[k] = p1 + p2;
-        if (k > 0 && k < M / 2) {
+        if (k > 0) {
             const float ur = ar - ti, ui = ai + tr;
             const float q1 = ur * ur, q2 = ui * ui;
             P[M - k] = q1 + q2;

@@ -215,3 +215,13 @@ def test_lsh_checker_against_pure_python(oracle):
     # the per-band cap keeps the first rows of a run
     o_ids, _, o_ct = oracle.lsh_query(ids, rec, rec[:1], 128, 16, 8, cand_per_band=3)
     assert o_ct[0] == 3 and o_ids[0, :3].tolist() == [100, 130, 131]
+
+
+def test_resample_weight_reciprocal_form_is_exact():
+    """The Wang stream kernel computes the A1 interpolation weight as (float)((double)rem * (1.0 / sr_out)) instead of
+    the oracle's (float)((double)rem / (double)sr_out): identical floats for every remainder (sr_out = 8000, 5000)."""
+    for sr in (8000, 5000):
+        rem = np.arange(sr, dtype=np.float64)
+        a = (rem / np.float64(sr)).astype(np.float32)
+        b = (rem * (np.float64(1.0) / np.float64(sr))).astype(np.float32)
+        assert np.array_equal(a, b)

@@ -72,10 +72,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int N>
 struct Rfft {
     static constexpr int M = N / 2, E = M / 64, B = E == 8 ? 3 : 4, BITS = N == 1024 ? 9 : 10, L6 = 6 - B;
-    static constexpr int PADK = E == 8 ? 4 : 8;                 // transpose-2 padding per 2^(2B) points (see t2 below)
+    static constexpr int PADK = E == 8 ? 2 : 4;                 // transpose-2 padding per 2^(2B) points (see t2 below)
     static constexpr int T3 = (1 << (BITS - 6)) - (1 << (2 * B - 6));   // phase-3 twiddles per lane: 7 / 12
     static constexpr int T3_FIRST = 1 << (2 * B - 6);
-    static constexpr int BUF_FLOATS = E == 8 ? 544 : 1056;      // transpose / exchange / spectrum scratch per wave
+    static constexpr int BUF_FLOATS = E == 8 ? 1056 : 2080;     // transpose / exchange / spectrum scratch per wave
 };
 template <int N>
 struct RfftConst {
@@ -145,6 +145,11 @@ __device__ __forceinline__ f32x2 cmul_tw(f32x2 x, f32x2 tw) {      // (t1 - t2, 
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(b) : "v"(x), "v"(tw));
     return a + b;
 }
+// the two packed products of W x, kept apart so that a caller can issue a whole stage's products before the sums
+__device__ __forceinline__ void cmul_parts(f32x2 x, f32x2 tw, f32x2& a, f32x2& b) {
+    a = x * f32x2{tw.x, tw.x};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(b) : "v"(x), "v"(tw));
+}
 __device__ __forceinline__ void bfly(f32x2& u, f32x2& x, f32x2 tw) {
     const f32x2 v = cmul_tw(x, tw);
     const f32x2 w = u;
@@ -156,11 +161,33 @@ __device__ __forceinline__ void bfly_one(f32x2& u, f32x2& x) {          // twidd
     u = w + v;
     x = w - v;
 }
+// (a.x + b.y, a.y - b.x) and (a.x - b.y, a.y + b.x): b's halves swapped by op_sel, the sign by the source modifier
+// (a + (-b) is a - b exactly) -- one packed instruction each, no moves
+__device__ __forceinline__ f32x2 pk_add_swz_pm(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add_swz_mp(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.x + b.x, a.y - b.y) and (a.x - b.x, a.y + b.y)
+__device__ __forceinline__ f32x2 pk_add_pm(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add_mp(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void bfly_minus_i(f32x2& u, f32x2& x) {      // twiddle -i: v = (xi, -xr)
-    const f32x2 w = u;
-    const f32x2 v = f32x2{x.y, -x.x};
-    u = w + v;
-    x = w - v;
+    const f32x2 w = u, xx = x;
+    u = pk_add_swz_pm(w, xx);        // (ur + xi, ui - xr)      = u + v
+    x = pk_add_swz_mp(w, xx);        // (ur - xi, ui + xr)      = u - v
 }
 
 // (register bit, lane bit LB) transposed: a is the register-bit-0 side, b the register-bit-1 side
@@ -192,8 +219,20 @@ __device__ __forceinline__ void xchg_lane_bit(f32x2& a, f32x2& b) {
     }
 }
 
+// The two non-trivial twiddles of stage 3, W8 = (r, -r) and W8^3 = (-r, -r), r = cos(pi/4): the products with -r are
+// the negated products with r, so one broadcast pair (r, r) and source modifiers serve both
+// rr lives in a scalar register pair (it is the same for every lane; vector registers are what this kernel is short of)
+__device__ __forceinline__ void cmul_w8_parts(f32x2 x, f32x2 rr, bool third, f32x2& a, f32x2& b) {
+    if (third) asm("v_pk_mul_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a) : "v"(x), "s"(rr));   // (xr * -r, xi * -r) = (t1, t4)
+    else asm("v_pk_mul_f32 %0, %1, %2" : "=v"(a) : "v"(x), "s"(rr));                                    // (xr * r, xi * r) = (t1, t4)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(b) : "v"(x), "s"(rr));   // (xi * r, xr * -r) = (-t2, t3)
+}
+
 // x: the windowed packed input z at this lane's E points (phase-1 layout).  buf: >= Rfft<N>::BUF_FLOATS floats of this
 // wave's LDS, 8-byte aligned; on return buf[0 .. N/2) holds the power spectrum.
+// The butterflies of a stage are written as "all products, then all sums": a product and the sum that consumes it
+// are then several instructions apart, which is what the packed pipeline wants (back to back the assembler has to pad
+// every butterfly with two s_nop, and an instruction slot is an instruction slot in this issue-bound kernel).
 template <int N>
 __device__ __forceinline__ void wave_rfft_power(f32x2 (&x)[Rfft<N>::E], const RfftConst<N>& K, int lane, float* __restrict__ buf) {
     using R = Rfft<N>;
@@ -202,13 +241,36 @@ __device__ __forceinline__ void wave_rfft_power(f32x2 (&x)[Rfft<N>::E], const Rf
 #pragma unroll
     for (int st = 1; st <= B; st++) {
         const int half = 1 << (st - 1), tstep = 2048 >> st;
+        f32x2 v[E / 2], pa[E / 2], pb[E / 2];
 #pragma unroll
-        for (int i0 = 0; i0 < E; i0++) {
+        for (int i0 = 0, c = 0; i0 < E; i0++) {
             if (i0 & half) continue;
             const int ti = (i0 & (half - 1)) * tstep;
-            if (st <= 3 && ti == 0) bfly_one(x[i0], x[i0 + half]);
-            else if (st <= 3 && ti == 512) bfly_minus_i(x[i0], x[i0 + half]);
-            else bfly(x[i0], x[i0 + half], f32x2{c_tw[ti][0], c_tw[ti][1]});
+            if (st <= 3 && (ti == 0 || ti == 512)) v[c] = x[i0 + half];                  // taken as is below
+            else if (st == 3) cmul_w8_parts(x[i0 + half], f32x2{c_tw[256][0], c_tw[256][0]}, ti == 768, pa[c], pb[c]);
+            else cmul_parts(x[i0 + half], f32x2{c_tw[ti][0], c_tw[ti][1]}, pa[c], pb[c]);
+            c++;
+        }
+#pragma unroll
+        for (int i0 = 0, c = 0; i0 < E; i0++) {
+            if (i0 & half) continue;
+            const int ti = (i0 & (half - 1)) * tstep;
+            if (!(st <= 3 && (ti == 0 || ti == 512))) v[c] = pa[c] + pb[c];
+            c++;
+        }
+#pragma unroll
+        for (int i0 = 0, c = 0; i0 < E; i0++) {
+            if (i0 & half) continue;
+            const int ti = (i0 & (half - 1)) * tstep;
+            const f32x2 w = x[i0];
+            if (st <= 3 && ti == 512) {                 // twiddle -i: v = (xi, -xr)
+                x[i0] = pk_add_swz_pm(w, v[c]);
+                x[i0 + half] = pk_add_swz_mp(w, v[c]);
+            } else {
+                x[i0] = w + v[c];
+                x[i0 + half] = w - v[c];
+            }
+            c++;
         }
     }
     // ---- transpose 1, in registers: register bit j <-> lane bit 6 - B + j ----
@@ -227,72 +289,104 @@ __device__ __forceinline__ void wave_rfft_power(f32x2 (&x)[Rfft<N>::E], const Rf
 #pragma unroll
     for (int st = B + 1; st <= 2 * B; st++) {
         const int halfm = 1 << (st - B - 1);
+        // two butterflies at a time: products, then the sums that consume them (a product and its sum must not be
+        // adjacent, and more than two in flight would cost registers this kernel does not have)
+        int ml[E / 2];
 #pragma unroll
-        for (int m0 = 0; m0 < E; m0++) {
-            if (m0 & halfm) continue;
-            bfly(x[m0], x[m0 + halfm], K.tw2[halfm - 1 + (m0 & (halfm - 1))]);
+        for (int m0 = 0, c = 0; m0 < E; m0++)
+            if (!(m0 & halfm)) ml[c++] = m0;
+#pragma unroll
+        for (int c = 0; c < E / 2; c += 2) {
+            f32x2 pa0, pb0, pa1, pb1;
+            cmul_parts(x[ml[c] + halfm], K.tw2[halfm - 1 + (ml[c] & (halfm - 1))], pa0, pb0);
+            cmul_parts(x[ml[c + 1] + halfm], K.tw2[halfm - 1 + (ml[c + 1] & (halfm - 1))], pa1, pb1);
+            const f32x2 v0 = pa0 + pb0, v1 = pa1 + pb1;
+            const f32x2 w0 = x[ml[c]], w1 = x[ml[c + 1]];
+            x[ml[c]] = w0 + v0;
+            x[ml[c] + halfm] = w0 - v0;
+            x[ml[c + 1]] = w1 + v1;
+            x[ml[c + 1] + halfm] = w1 - v1;
         }
     }
-    // ---- transpose 2 through LDS: p = hi 2^2B + m E + lo  ->  p = 64 e + lane; a point p is stored at
-    // p + PADK (p >> 2B), which spreads the 32 lanes of a ds_write_b32 group over the 32 banks ----
+    // ---- transpose 2 through LDS as (re, im) pairs: p = hi 2^2B + m E + lo  ->  p = 64 e + lane; a point p is stored
+    // at pair index p + PADK (p >> 2B), which spreads the 16 lanes of a ds_write_b64 group over the 32 banks ----
     const int lo = lane >> R::L6, hi = lane & ((1 << R::L6) - 1);
+    f32x2* tb = reinterpret_cast<f32x2*>(buf);
     const int wbase = hi * (E * E + R::PADK) + lo;
-    float nr[E];
 #pragma unroll
-    for (int m = 0; m < E; m++) buf[wbase + m * E] = x[m].x;
+    for (int m = 0; m < E; m++) tb[wbase + m * E] = x[m];
     wave_lds_fence();
 #pragma unroll
-    for (int e = 0; e < E; e++) nr[e] = buf[e * 64 + lane + R::PADK * ((e * 64) >> (2 * B))];
-    wave_lds_fence();
-#pragma unroll
-    for (int m = 0; m < E; m++) buf[wbase + m * E] = x[m].y;
-    wave_lds_fence();
-#pragma unroll
-    for (int e = 0; e < E; e++) x[e] = f32x2{nr[e], buf[e * 64 + lane + R::PADK * ((e * 64) >> (2 * B))]};
+    for (int e = 0; e < E; e++) x[e] = tb[e * 64 + lane + R::PADK * ((e * 64) >> (2 * B))];
     // ---- phase 3: stages 2B+1..BITS on the register index e ----
 #pragma unroll
     for (int st = 2 * B + 1; st <= R::BITS; st++) {
         const int halfe = 1 << (st - 7);
+        int el[E / 2];
 #pragma unroll
-        for (int e0 = 0; e0 < E; e0++) {
-            if (e0 & halfe) continue;
-            bfly(x[e0], x[e0 + halfe], K.tw3[halfe - R::T3_FIRST + (e0 & (halfe - 1))]);
+        for (int e0 = 0, c = 0; e0 < E; e0++)
+            if (!(e0 & halfe)) el[c++] = e0;
+#pragma unroll
+        for (int c = 0; c < E / 2; c += 2) {
+            f32x2 pa0, pb0, pa1, pb1;
+            cmul_parts(x[el[c] + halfe], K.tw3[halfe - R::T3_FIRST + (el[c] & (halfe - 1))], pa0, pb0);
+            cmul_parts(x[el[c + 1] + halfe], K.tw3[halfe - R::T3_FIRST + (el[c + 1] & (halfe - 1))], pa1, pb1);
+            const f32x2 v0 = pa0 + pb0, v1 = pa1 + pb1;
+            const f32x2 w0 = x[el[c]], w1 = x[el[c + 1]];
+            x[el[c]] = w0 + v0;
+            x[el[c] + halfe] = w0 - v0;
+            x[el[c + 1]] = w1 + v1;
+            x[el[c + 1] + halfe] = w1 - v1;
         }
     }
     // ---- untangle.  Z[k] sits in register e of lane l for k = 64 e + l; its partner Z[M - k] in register E-1-e of
     // lane 64 - l (lane 0: register E - e, and Z[0] pairs with itself).  The upper half of the spectrum goes through
-    // LDS as float2 slots (bin b -> slot b - M/2; slot M/2 holds Z[0]) and every lane reads its E/2 partners. ----
+    // LDS as float2 slots (bin b -> slot b - M/2; slot M/2 holds Z[0]) and every lane reads its E/2 partners.
+    // Writes that only lane 0 owes are made by every lane, the others into a spare slot of their own: a store under a
+    // lane condition costs a save / branch / restore of the exec mask, the spare store nothing. ----
     wave_lds_fence();
     f32x2* ex = reinterpret_cast<f32x2*>(buf);
 #pragma unroll
     for (int e = E / 2; e < E; e++) ex[(e - E / 2) * 64 + lane] = x[e];
-    if (lane == 0) ex[M / 2] = x[0];
+    ex[lane == 0 ? M / 2 : M / 2 + 1 + lane] = x[0];                     // spare slots M/2 + 2 .. M/2 + 64
     wave_lds_fence();
     f32x2 y[E / 2];
 #pragma unroll
     for (int e = 0; e < E / 2; e++) y[e] = ex[M / 2 - 64 * e - lane];
     wave_lds_fence();
-    // P[k] and P[M-k] from one (A, T); lane 0 also owns the self-paired bin M/2 (register E/2)
-    auto pair_power = [](f32x2 z, f32x2 yv, f32x2 w, float& pk, float& pmk) {
-        const f32x2 a = f32x2{z.x + yv.x, z.y - yv.y};
-        const f32x2 b = f32x2{z.x - yv.x, z.y + yv.y};
-        const f32x2 t = cmul_tw(b, w);                       // (Tr, Ti)
-        const f32x2 xk = f32x2{a.x + t.y, a.y - t.x};
-        const f32x2 xm = f32x2{a.x - t.y, a.y + t.x};
-        const f32x2 s1 = xk * xk, s2 = xm * xm;
-        pk = s1.x + s1.y;
-        pmk = s2.x + s2.y;
-    };
-    float pk[E / 2], pmk[E / 2], pmid, pdummy;
+    // P[k] and P[M-k] from one (A, T)
+    f32x2 ta[E / 2], tt[E / 2];
 #pragma unroll
-    for (int e = 0; e < E / 2; e++) pair_power(x[e], y[e], K.utw[e], pk[e], pmk[e]);
-    pair_power(x[E / 2], x[E / 2], f32x2{c_tw[512][0], c_tw[512][1]}, pmid, pdummy);
+    for (int e = 0; e < E / 2; e++) {
+        ta[e] = pk_add_pm(x[e], y[e]);                       // A = (Zr + Yr, Zi - Yi)
+        tt[e] = pk_add_mp(x[e], y[e]);                       // B = (Zr - Yr, Zi + Yi)
+    }
+    {
+        f32x2 pa[E / 2], pb[E / 2];
+#pragma unroll
+        for (int e = 0; e < E / 2; e++) cmul_parts(tt[e], K.utw[e], pa[e], pb[e]);
+#pragma unroll
+        for (int e = 0; e < E / 2; e++) tt[e] = pa[e] + pb[e];               // T = W B = (Tr, Ti)
+    }
+    float pk[E / 2], pmk[E / 2];
+#pragma unroll
+    for (int e = 0; e < E / 2; e++) {
+        const f32x2 xk = pk_add_swz_pm(ta[e], tt[e]);        // X[k]   = (Ar + Ti, Ai - Tr)
+        const f32x2 xm = pk_add_swz_mp(ta[e], tt[e]);        // X[M-k] = (Ar - Ti, Ai + Tr) (conjugate)
+        const f32x2 s1 = xk * xk, s2 = xm * xm;
+        pk[e] = s1.x + s1.y;
+        pmk[e] = s2.x + s2.y;
+    }
+    // the self-paired bin M/2 (register E/2 of lane 0): A = (2 Zr, 0), B = (0, 2 Zi), W = -i  =>  |X|^2 = (2 Zr)^2 + (2 Zi)^2
+    const f32x2 zm = x[E / 2] + x[E / 2];
+    const f32x2 sm = zm * zm;
+    const float pmid = sm.x + sm.y;
 #pragma unroll
     for (int e = 0; e < E / 2; e++) {
         buf[e * 64 + lane] = pk[e];
-        if (e > 0 || lane > 0) buf[M - e * 64 - lane] = pmk[e];
+        buf[M - e * 64 - lane] = pmk[e];                     // e = 0, lane 0: index M, a spare word
     }
-    if (lane == 0) buf[M / 2] = pmid;
+    buf[lane == 0 ? M / 2 : M + 1 + lane] = pmid;            // spare words M + 2 .. M + 64
     wave_lds_fence();
 }
 
@@ -386,14 +480,17 @@ struct WangClip {
 };
 
 struct WangStreamLds {
-    float buf[kSW][1024];         // per wave: transpose 2, untangling exchange, power spectrum, row-maximum scratch
-    float smp[kSmpRing];          // the workgroup's 8 kHz samples, index swizzled (smp_swz)
+    float buf[kSW][Rfft<kWangN>::BUF_FLOATS];   // per wave: transpose 2, untangling exchange, power spectrum, row-maximum scratch
+    float smp[kSmpRing + 64];     // the workgroup's 8 kHz samples, index swizzled (smp_swz); + a spare tail for stores that own nothing
     float ring[kRing][kWangBins];
     uint32_t pl_cnt[kRing];
     uint32_t pl_k[kRing][kPl];
     float pl_v[kRing][kPl];
+    float2 win[kWangN / 128][64]; // halved Hann at a lane's 8 sample pairs (registers go to the FFT's twiddles)
+    uint32_t spare_k[kSW][kPl];   // where the lanes WITHOUT a candidate store (an unconditional store is cheaper than a branch)
+    float spare_v[kSW][kPl];
 };
-static_assert(Rfft<kWangN>::BUF_FLOATS <= 1024, "");
+
 
 // A frame's pairs (x[2n], x[2n+1]) are read by ds_read_b64 with n = (register part) | (6 lane-dependent bits): the 32
 // lanes of a group then touch dwords {0-15, 64-79, 32-47, 96-111} + const, i.e. two bank quarters twice.  XOR-ing
@@ -414,10 +511,12 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                                                           const uint32_t* __restrict__ seg_base,
                                                           const uint32_t* __restrict__ sec_base,
                                                           const uint32_t* __restrict__ n_segs_total, uint32_t seg,
-                                                          uint32_t sr_in, const float* __restrict__ frac_tab,
-                                                          uint32_t* __restrict__ cand_cnt,
+                                                          uint32_t sr_in, uint32_t* __restrict__ cand_cnt,
                                                           uint32_t* __restrict__ cand_t,
                                                           uint32_t* __restrict__ cand_k, float* __restrict__ cand_p) {
+    // This kernel is bound by instruction issue (every instruction of any kind costs about the same: measured by
+    // padding the loop with scalar or vector adds), so the loop body is written for instruction count: 32-bit indices,
+    // loads and stores without lane conditions (clamped addresses, spare slots), immediate LDS offsets.
     if (blockIdx.x >= *n_segs_total) return;       // the grid is a host-side upper bound (whole workgroup leaves)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     WangStreamLds& L = *reinterpret_cast<WangStreamLds*>(lds_raw);
@@ -429,47 +528,54 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
     const uint32_t sec0 = sec_base[clip];
     RfftConst<kWangN> K;
     rfft_consts<kWangN>(lane, K);
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < kWangN / 128; i++) L.win[i][lane] = make_float2(K.win[i].x, K.win[i].y);
+    }
     float* buf = L.buf[wave];
     const float* pw = buf;
-    const long total = (long)cl.frames;
-    const long s0 = (long)(blockIdx.x - seg_base[clip]) * seg;      // frames [s0, s1) are this segment's to judge
-    const long s1 = s0 + seg < total ? s0 + seg : total;
-    const long f_lo = s0 - kRT < 0 ? 0 : s0 - kRT;                 // frames [f_lo, f_hi) are computed
-    const long f_hi = s1 + kRT < total ? s1 + kRT : total;
+    const int total = (int)cl.frames;
+    const int s0 = (int)((blockIdx.x - seg_base[clip]) * seg);     // frames [s0, s1) are this segment's to judge
+    const int s1 = s0 + (int)seg < total ? s0 + (int)seg : total;
+    const int f_lo = s0 - kRT < 0 ? 0 : s0 - kRT;                  // frames [f_lo, f_hi) are computed
+    const int f_hi = s1 + kRT < total ? s1 + kRT : total;
 
-    // ---- sample staging.  Batch state (wave-uniform): b_i = 8 kHz index of the next batch's first sample; for a
-    // resampled clip that sample sits at source position b_q + b_r / 8000.  A thread fetches samples 2 tid, 2 tid + 1 of
-    // the batch into registers (the loads stay in flight across the FFT) and stores them at the end of the round. ----
-    uint64_t b_i = (uint64_t)f_lo * kWangHop;
-    uint64_t b_q = 0;
-    uint32_t b_r = 0;
+    // ---- sample staging.  Everything is kept RELATIVE to the segment's first sample so that the per-thread index
+    // arithmetic is 32-bit: b_i = 8 kHz index of the next batch's first sample minus i_base; for a resampled clip that
+    // sample sits at source position q_base + b_q + b_r / 8000.  A thread fetches samples 2 tid, 2 tid + 1 of the batch
+    // into registers (the loads stay in flight across the FFT) and stores them at the end of the round.  Loads are
+    // unconditional at clamped positions: what lies past the clip's last frame is never cut into a frame. ----
+    const uint64_t i_base = (uint64_t)f_lo * kWangHop;
+    uint64_t q_base = i_base;
+    uint32_t b_i = 0, b_q = 0, b_r = 0;
     if (RESAMPLE) {
-        const uint64_t num = b_i * sr_in;
-        b_q = num / (uint32_t)kWangSr;
-        b_r = (uint32_t)(num - b_q * (uint32_t)kWangSr);
+        const uint64_t num = i_base * sr_in;
+        q_base = num / (uint32_t)kWangSr;
+        b_r = (uint32_t)(num - q_base * (uint32_t)kWangSr);
     }
+    const char* __restrict__ xs = reinterpret_cast<const char*>(x + q_base);       // source sample q_base
+    const uint64_t src_left = (RESAMPLE ? cl.src_n : cl.n8k) - q_base;             // >= 1: the segment has a frame
+    const uint32_t last_off = (uint32_t)((src_left < (1ull << 29) ? src_left : (1ull << 29)) - 1) * 4u;   // byte offset of the last sample
     float sx0[2], sx1[2], sfr[2];
     const uint32_t j0 = 2u * threadIdx.x;
-    auto fetch = [&](uint32_t count) {
+    auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float*>(xs + byte_off); };   // uniform base + 32-bit offset
+    auto fetch = [&]() {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const uint32_t j = j0 + u;
-            const uint64_t i = b_i + j;
-            sx0[u] = 0.0f;
-            sx1[u] = 0.0f;
-            sfr[u] = 0.0f;
-            if (j < count && i < cl.n8k) {
-                if (RESAMPLE) {
-                    const uint32_t num = b_r + j * sr_in;                 // < 2^32: sr_in <= 2^21, j < 1536
-                    const uint32_t qd = num / (uint32_t)kWangSr;
-                    const uint32_t rem = num - qd * (uint32_t)kWangSr;
-                    const uint64_t idx = b_q + qd;
-                    sx0[u] = x[idx];
-                    sx1[u] = x[idx + 1 < cl.src_n ? idx + 1 : cl.src_n - 1];
-                    sfr[u] = frac_tab[rem];
-                } else {
-                    sx0[u] = x[i];
-                }
+            if (RESAMPLE) {
+                const uint32_t num = b_r + j * sr_in;                 // < 2^32: sr_in <= 384 000, j < 1536
+                const uint32_t qd = num / (uint32_t)kWangSr;
+                const uint32_t rem = num - qd * (uint32_t)kWangSr;
+                const uint32_t off = (b_q + qd) * 4u;
+                sx0[u] = ld(off < last_off ? off : last_off);
+                sx1[u] = ld(off + 4u < last_off ? off + 4u : last_off);
+                // = (float)((double)rem / 8000.0), the oracle's expression: the reciprocal form gives the same
+                // float for every rem in [0, 8000) (checked exhaustively, tests/test_oracle_spec.py)
+                sfr[u] = (float)((double)rem * (1.0 / (double)kWangSr));
+            } else {
+                const uint32_t off = (b_i + j) * 4u;
+                sx0[u] = ld(off < last_off ? off : last_off);
             }
         }
     };
@@ -485,10 +591,11 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                 v[u] = sx0[u];
             }
         }
-        if (j0 < count) {
-            const uint32_t s = smp_swz(((uint32_t)b_i + j0) & (uint32_t)(kSmpRing - 1));   // even: the pair stays together
-            *reinterpret_cast<float2*>(&L.smp[s]) = make_float2(v[0], v[1]);
-        }
+        // ring position of 8 kHz sample i_base + b_i + j0 (i_base is a multiple of the hop; the ring's size too); a
+        // thread past the batch (prologue only) stores into the spare tail of the ring array instead
+        uint32_t sidx = smp_swz(((uint32_t)i_base + b_i + j0) & (uint32_t)(kSmpRing - 1));   // even: the pair stays together
+        if (count < (uint32_t)kBatch) sidx = j0 < count ? sidx : (uint32_t)kSmpRing + (j0 & 62u);
+        *reinterpret_cast<float2*>(&L.smp[sidx]) = make_float2(v[0], v[1]);
         b_i += count;
         if (RESAMPLE) {
             const uint32_t num = b_r + count * sr_in;
@@ -497,9 +604,9 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
             b_r = num - qd * (uint32_t)kWangSr;
         }
     };
-    fetch(kPrologue - kBatch);
+    fetch();
     store(kPrologue - kBatch);
-    fetch(kBatch);
+    fetch();
     store(kBatch);
     __syncthreads();
     // this lane's sample-pair offset inside a frame: dword 2 n, n = (rev(i) << 6) | nb; the swizzle only touches the
@@ -507,32 +614,63 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
     const uint32_t nb2 = smp_swz(2u * rfft_pair_base<kWangN>(lane));
 
     int slot = (int)((f_lo + wave) % kRing);                       // ring row of frame base + wave
-    // a found peak waits one round for its slot: the atomic's round trip overlaps the next FFT
+    // a found peak waits one round for its slot: the atomic's round trip overlaps the next FFT.
+    // flush_take (the atomic's result, requested a round ago, becomes this lane's offset) + flush_put (the three
+    // stores).  The round's sample loads are issued BETWEEN the two: a wait for the atomic must not include them, and
+    // nothing may have to wait for the stores' acknowledgement (memory returns count in order).
     bool pend = false, pend_wave = false;      // pend_wave: wave-uniform "an atomic is in flight"
-    uint32_t pend_base = 0, pend_rank = 0, pend_sec = 0, pend_t = 0, pend_k = 0;
+    uint32_t pend_base = 0, pend_rank = 0, pend_off = 0, pend_t = 0, pend_k = 0;
     int pend_leader = 0;
     float pend_v = 0.0f;
-    auto flush = [&]() {
+    auto flush_take = [&]() {
         if (pend_wave) {
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pend_base, pend_leader);
-            const uint32_t pos = base + pend_rank;
-            if (pend && pos < (uint32_t)kCandCap) {
-                cand_t[(size_t)pend_sec * kCandCap + pos] = pend_t;
-                cand_k[(size_t)pend_sec * kCandCap + pos] = pend_k;
-                cand_p[(size_t)pend_sec * kCandCap + pos] = pend_v;
-            }
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)pend_base, pend_leader) + pend_rank;
+            pend = pend && pos < (uint32_t)kCandCap;
+            pend_off = (pend_off + pos) * 4u;                                   // byte offset into cand_*
+        }
+    };
+    auto flush_put = [&]() {
+        if (pend_wave && pend) {
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cand_t) + pend_off) = pend_t;
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cand_k) + pend_off) = pend_k;
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(cand_p) + pend_off) = pend_v;
         }
         pend = false;
         pend_wave = false;
     };
-    for (long base = f_lo; base < s1 + kRT + kSW; base += kSW) {
-        const long f = base + wave;
-        // ---- judge frame base + wave - kSW - kRT: its window [t - kRT, t + kRT] was complete at the last barrier, so
-        // this overlaps the other waves' FFTs instead of standing between two barriers of its own ----
-        flush();
+    for (int base = f_lo; base < s1 + kRT + kSW; base += kSW) {
+        const int f = base + wave;
+        flush_take();
         // next round's samples: requested now, stored behind the FFT
-        fetch(kBatch);
-        const long t = f - kSW - kRT;
+        fetch();
+        flush_put();
+        // this round's frame is cut from the sample ring first: the reads are in flight while the judge below runs
+        f32x2 z[kWangN / 128];
+        if (f < f_hi) {
+            // frame start in the ring, in units of 128 dwords (the hop): wave-uniform.  A frame spans 8 units; unless it
+            // wraps around the ring's end (7 of 32 start positions) the eight reads are one address + immediates
+            const uint32_t fs = ((uint32_t)f * kWangHop & (uint32_t)(kSmpRing - 1)) >> 7;
+            if (fs <= (uint32_t)(kSmpRing / 128 - 8)) {
+                const float* p0 = &L.smp[(fs << 7) | nb2];
+#pragma unroll
+                for (int i = 0; i < kWangN / 128; i++) {
+                    const uint32_t ri = __brev((uint32_t)i) >> 29;                       // 3-bit reversal: n = (ri << 6) | nb
+                    const float2 v = *reinterpret_cast<const float2*>(__builtin_assume_aligned(p0 + (ri << 7), 8));
+                    z[i] = f32x2{v.x, v.y};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kWangN / 128; i++) {
+                    const uint32_t ri = __brev((uint32_t)i) >> 29;
+                    const uint32_t blk = (fs + ri) & (uint32_t)(kSmpRing / 128 - 1);     // scalar
+                    const float2 v = *reinterpret_cast<const float2*>(
+                        __builtin_assume_aligned(&L.smp[(blk << 7) | nb2], 8));
+                    z[i] = f32x2{v.x, v.y};
+                }
+            }
+        }
+        // ---- judge frame base + wave - kSW - kRT: its window [t - kRT, t + kRT] was complete at the last barrier ----
+        const int t = f - kSW - kRT;
         if (t >= s0 && t < s1) {
             int st = slot - kSW - kRT;
             if (st < 0) st += kRing;
@@ -547,21 +685,21 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
             if (rs < 0) rs += kRing;
             float rr[2 * kRT + 1];
             const float* cell = &L.ring[0][pk];
-            if (rs + 2 * kRT < kRing) {                    // the window does not wrap: one address, 15 offsets
+            if (rs + 2 * kRT < kRing) {                    // the window does not wrap: one address, 15 immediates
                 const float* c0 = cell + rs * kWangBins;
 #pragma unroll
                 for (int d = 0; d <= 2 * kRT; d++) rr[d] = c0[d * kWangBins];
-            } else {
+            } else {                                       // rows rs .. kRing-1, then 0 ..: two addresses
+                const float* c0 = cell + rs * kWangBins;
+                const float* c1 = c0 - kRing * kWangBins;
+                const int w = kRing - rs;                  // rows d < w sit before the wrap
 #pragma unroll
-                for (int d = 0; d <= 2 * kRT; d++) {
-                    const int r = rs + d >= kRing ? rs + d - kRing : rs + d;
-                    rr[d] = cell[r * kWangBins];
-                }
+                for (int d = 0; d <= 2 * kRT; d++) rr[d] = (d < w ? c0 : c1)[d * kWangBins];
             }
             if (t < kRT || t + kRT >= total) {             // rows outside [0, total) duplicate rows inside: drop them
 #pragma unroll
                 for (int d = 0; d <= 2 * kRT; d++) {
-                    const long tt = t + d - kRT;
+                    const int tt = t + d - kRT;
                     if (tt < 0 || tt >= total) rr[d] = -1.0f;
                 }
             }
@@ -573,14 +711,14 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
             }
             const bool is_peak = (uint32_t)lane < n && mb < pv && ma <= pv;
             // one counter bump per wave (all its peaks share the frame, hence the second); the returned base is
-            // consumed a round later by flush(), so the L2 round trip overlaps the next FFT.  The address is hidden
+            // consumed a round later by flush_take(), so the L2 round trip overlaps the next FFT.  The address is hidden
             // from the compiler: for a uniform address it aggregates by itself and reads the result back at once
             // (s_waitcnt vmcnt(0) + v_readfirstlane right behind the atomic), which parks every wave for the trip.
             const uint64_t pm = __ballot(is_peak);
             if (pm) {
-                const uint32_t sec = sec0 + (uint32_t)(((size_t)t * kWangHop) / kWangSr);
+                const uint32_t sec = sec0 + ((uint32_t)t * kWangHop) / kWangSr;
                 pend = is_peak;
-                pend_sec = sec;
+                pend_off = sec * (uint32_t)kCandCap;
                 pend_t = (uint32_t)t;
                 pend_k = pk;
                 pend_v = pv;
@@ -598,27 +736,25 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
         }
         // ---- produce frame base + wave ----
         if (f < f_hi) {
-            f32x2 z[kWangN / 128];
-            {
-                // frame start in the ring, in units of 128 dwords (the hop): wave-uniform
-                const uint32_t fs = (uint32_t)(((uint64_t)f * kWangHop) & (uint64_t)(kSmpRing - 1)) >> 7;
 #pragma unroll
-                for (int i = 0; i < kWangN / 128; i++) {
-                    const uint32_t ri = __brev((uint32_t)i) >> 29;                       // 3-bit reversal: n = (ri << 6) | nb
-                    const uint32_t blk = (fs + ri) & (uint32_t)(kSmpRing / 128 - 1);     // scalar
-                    const float2 v = *reinterpret_cast<const float2*>(&L.smp[(blk << 7) | nb2]);
-                    z[i] = f32x2{v.x, v.y} * K.win[i];
-                }
+            for (int i = 0; i < kWangN / 128; i++) {
+                const float2 wv = L.win[i][lane];
+                z[i] = z[i] * f32x2{wv.x, wv.y};
             }
             wave_rfft_power<kWangN>(z, K, lane, buf);
             // Row maximum over +-kRK bins and the same-row tie test, blocked: lane L owns bins 8L .. 8L+7.  The
             // window [k-15, k+15] of bin k = 8L + j is  suffix_{L-2}[j+1] u block_{L-1} u block_L u block_{L+1} u
-            // prefix_{L+2}[j-1], and the 15 bins below k are  suffix_{L-2}[j+1] u block_{L-1} u prefix_L[j-1]:
-            // 14 maxima per lane for the prefix / suffix tables, two LDS exchanges, instead of 31 taps per bin.
-            // P >= 0, so -1 stands for "no bin there" (a clamped duplicate never changes a maximum either).
+            // prefix_{L+2}[j-1], so with C = max(block_{L-1}, block_L, block_{L+1}) the row maximum is
+            // max3(C, suffix_{L-2}[j+1], prefix_{L+2}[j-1]): 14 maxima for the prefix / suffix tables, one LDS exchange,
+            // 9 max3 -- instead of 31 taps per bin.  A lane whose neighbour does not exist reads ITS OWN tables
+            // instead (<= its own block maximum, already in C: neutral), so no edge selects are needed here.
+            // A row-local candidate (P == row maximum > 0, no equal value among the 15 bins below) can only be the
+            // FIRST occurrence js of the block maximum v, and it is one iff
+            //     v > max(suffix_{L-2}[js+1], block_{L-1}, 0)   and   v >= max(block_{L+1}, prefix_{L+2}[js-1])
+            // (the bins of its own block before js are < v, those after are <= v, by the choice of js).
             float* row = L.ring[slot];
             float* sx = buf;              // scratch OVER the spectrum (b8 is read first; the LDS keeps a wave's order):
-            float* px = sx + 64 * 7;      // [lane][7] suffix 1..7, [lane][8] prefix (row strides 7 and 9: conflict-free)
+            float* px = sx + 64 * 7;      // [lane][7] suffix 1..7, [lane][9] prefix 0..7 (row strides 7 and 9: conflict-free)
             float b8[8], pre[8], suf[8];
             {
                 const float4 lo4 = *reinterpret_cast<const float4*>(pw + 8 * lane);
@@ -627,8 +763,12 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
                 b8[4] = hi4.x; b8[5] = hi4.y; b8[6] = hi4.z; b8[7] = hi4.w;
             }
             pre[0] = b8[0];
+            uint32_t js = 0;
 #pragma unroll
-            for (int j = 1; j < 8; j++) pre[j] = fmaxf(pre[j - 1], b8[j]);
+            for (int j = 1; j < 8; j++) {
+                js = b8[j] > pre[j - 1] ? (uint32_t)j : js;
+                pre[j] = fmaxf(pre[j - 1], b8[j]);
+            }
             suf[7] = b8[7];
 #pragma unroll
             for (int j = 6; j >= 0; j--) suf[j] = fmaxf(suf[j + 1], b8[j]);
@@ -636,59 +776,49 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 if (j > 0) sx[7 * lane + j - 1] = suf[j];
-                if (j < 7) px[9 * lane + j] = pre[j];
+                px[9 * lane + j] = pre[j];
             }
-            px[9 * lane + 7] = pre[7];
             wave_lds_fence();
-            // every neighbour read is unconditional at a clamped lane (one burst of 16 LDS reads, one wait) and the
-            // out-of-range ones are replaced afterwards: a read under a lane condition becomes a branch of its own
-            const int lm1 = lane >= 1 ? lane - 1 : 0, lp1 = lane <= 62 ? lane + 1 : 63;
-            const int lm2 = lane >= 2 ? lane - 2 : 0, lp2 = lane <= 61 ? lane + 2 : 63;
-            float nb_m1 = px[9 * lm1 + 7], nb_p1 = px[9 * lp1 + 7];     // block maxima of the neighbours
+            const int lm1 = lane >= 1 ? lane - 1 : lane, lp1 = lane <= 62 ? lane + 1 : lane;
+            const int lm2 = lane >= 2 ? lane - 2 : lane, lp2 = lane <= 61 ? lane + 2 : lane;
+            const float nb_m1 = px[9 * lm1 + 7], nb_p1 = px[9 * lp1 + 7];     // block maxima of the neighbours
             float s2v[7], p2v[7];
 #pragma unroll
             for (int j = 0; j < 7; j++) {
                 s2v[j] = sx[7 * lm2 + j];          // suffix_{L-2}[j+1]
                 p2v[j] = px[9 * lp2 + j];          // prefix_{L+2}[j]
             }
-            const float blk_m1 = lane >= 1 ? nb_m1 : -1.0f;
-            const float blk_p1 = lane <= 62 ? nb_p1 : -1.0f;
+            const float s2c = sx[7 * lm2 + (int)js];          // suffix_{L-2}[js+1]  (js = 7: no such bin, dropped below)
+            const float p2c = px[9 * lp2 + (int)js - 1];      // prefix_{L+2}[js-1]  (js = 0: dropped below)
+            const float cmax = fmaxf(fmaxf(nb_m1, pre[7]), nb_p1);
             float rm[8];
-            uint32_t cbits = 0;
+            rm[0] = fmaxf(cmax, s2v[0]);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float s2 = (lane >= 2 && j < 7) ? s2v[j < 7 ? j : 0] : -1.0f;       // suffix_{L-2}[j+1]
-                const float p2 = (lane <= 61 && j > 0) ? p2v[j > 0 ? j - 1 : 0] : -1.0f;  // prefix_{L+2}[j-1]
-                const float below = fmaxf(fmaxf(s2, blk_m1), j > 0 ? pre[j - 1] : -1.0f);
-                const float m = fmaxf(fmaxf(below, pre[7]), fmaxf(blk_p1, p2));
-                rm[j] = m;
-                if (b8[j] > 0.0f && b8[j] == m && below != b8[j]) cbits |= 1u << j;
-            }
+            for (int j = 1; j < 7; j++) rm[j] = fmaxf(fmaxf(cmax, s2v[j]), p2v[j - 1]);
+            rm[7] = fmaxf(cmax, p2v[6]);
+            const float v8 = pre[7];
+            const float lo_side = fmaxf((lane >= 2 && js < 7u) ? s2c : 0.0f, lane >= 1 ? nb_m1 : 0.0f);
+            const float hi_side = fmaxf(nb_p1, js > 0u ? p2c : 0.0f);
             *reinterpret_cast<float4*>(row + 8 * lane) = make_float4(rm[0], rm[1], rm[2], rm[3]);
             *reinterpret_cast<float4*>(row + 8 * lane + 4) = make_float4(rm[4], rm[5], rm[6], rm[7]);
-            // two row-local candidates are >= 16 bins apart, a lane owns 8 bins: at most ONE bit of cbits is set,
-            // and one ballot compacts the row (the list's order is irrelevant: wang_select ranks the peaks)
-            const bool c = cbits != 0;
+            // two row-local candidates are >= 16 bins apart, a lane owns 8 bins: at most one per lane, at most kPl per
+            // row, and one ballot compacts the row (the list's order is irrelevant: wang_select ranks the peaks).  Every
+            // lane stores: a candidate at its rank, the others into this wave's spare slots.
+            const bool c = v8 > lo_side && v8 >= hi_side;
             const uint64_t mask = __ballot(c);
-            if (c) {
-                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t kk = 8u * (uint32_t)lane + (uint32_t)(__ffs((int)cbits) - 1);
-                if (pos < (uint32_t)kPl) {
-                    L.pl_k[slot][pos] = kk;
-                    L.pl_v[slot][pos] = row[kk];   // a candidate equals its row maximum, just stored
-                }
-            }
-            if (lane == 0) {
-                const uint32_t npl = (uint32_t)__popcll(mask);
-                L.pl_cnt[slot] = npl < (uint32_t)kPl ? npl : (uint32_t)kPl;
-            }
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            uint32_t* kp = c ? &L.pl_k[slot][pos & (uint32_t)(kPl - 1)] : &L.spare_k[wave][lane & (kPl - 1)];
+            float* vp = c ? &L.pl_v[slot][pos & (uint32_t)(kPl - 1)] : &L.spare_v[wave][lane & (kPl - 1)];
+            *kp = 8u * (uint32_t)lane + js;
+            *vp = v8;
+            L.pl_cnt[slot] = (uint32_t)__popcll(mask);       // every lane, the same word
         }
         store(kBatch);     // the samples of the next round's frames (requested at the top of this round)
         __syncthreads();   // the only one per round: rows base .. base + kSW - 1 and the next samples are complete
         slot = slot + kSW >= kRing ? slot + kSW - kRing : slot + kSW;
     }
-    flush();
+    flush_take();
+    flush_put();
 }
 
 // one wave per second: keep the `pps` strongest, ordered by (t, k)
@@ -1022,7 +1152,7 @@ WangWs wang_ws_layout(size_t n_src_total, size_t n_clips, uint32_t sr_in, uint32
 // clips' sample rate (8000: taken as is; anything else: resampled to 8 kHz inside the stream kernel, A1);
 // d_out_off: n_clips + 1 hash offsets (may be nullptr); out_count: total hashes produced (may be nullptr)
 int launch_wang_batch(const float* pcm, const uint64_t* d_offsets, size_t n_src_total, size_t n_clips, uint32_t sr_in,
-                      const float* frac_tab, uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
+                      uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
                       float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* d_out_off,
                       uint64_t* out_count, hipStream_t stream) {
     if (n_clips == 0 || pps == 0) {
@@ -1051,14 +1181,14 @@ int launch_wang_batch(const float* pcm, const uint64_t* d_offsets, size_t n_src_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(wang_stream_kernel<false>, dim3(w.n_seg), dim3(kSW * 64), lds, stream, pcm,
                            (const WangClip*)clips, (const uint32_t*)u32(w.seg_clip), (const uint32_t*)u32(w.seg_base),
-                           (const uint32_t*)u32(w.sec_base), n_segs_total, w.seg, sr_in, frac_tab, u32(w.cand_cnt),
+                           (const uint32_t*)u32(w.sec_base), n_segs_total, w.seg, sr_in, u32(w.cand_cnt),
                            u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wang_stream_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(wang_stream_kernel<true>, dim3(w.n_seg), dim3(kSW * 64), lds, stream, pcm,
                            (const WangClip*)clips, (const uint32_t*)u32(w.seg_clip), (const uint32_t*)u32(w.seg_base),
-                           (const uint32_t*)u32(w.sec_base), n_segs_total, w.seg, sr_in, frac_tab, u32(w.cand_cnt),
+                           (const uint32_t*)u32(w.sec_base), n_segs_total, w.seg, sr_in, u32(w.cand_cnt),
                            u32(w.cand_t), u32(w.cand_k), f32(w.cand_p));
     }
     hipLaunchKernelGGL(wang_select_kernel, dim3(w.n_sec), dim3(64), 0, stream, u32(w.cand_cnt), u32(w.cand_t),

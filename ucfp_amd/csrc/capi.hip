@@ -60,7 +60,6 @@ struct ucfp_ctx {
     uint8_t* audio_ws = nullptr;
     size_t audio_ws_cap = 0;
     hipEvent_t audio_done = nullptr;
-    float* frac8000 = nullptr;   // A1 interpolation weights (float)((double)rem / 8000.0), rem = 0..7999 (Wang's fused resampler)
 };
 
 namespace {
@@ -131,12 +130,6 @@ int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
     if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->audio_done, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->norm_done, hipEventDisableTiming);
-    if (e2 == hipSuccess) e2 = hipMalloc((void**)&c->frac8000, 8000 * sizeof(float));
-    if (e2 == hipSuccess) {
-        std::vector<float> tab(8000);
-        for (uint32_t r = 0; r < 8000; r++) tab[r] = (float)((double)r / (double)8000);   // the oracle's expression
-        e2 = hipMemcpy(c->frac8000, tab.data(), 8000 * sizeof(float), hipMemcpyHostToDevice);
-    }
     if (e2 != hipSuccess) {
         ucfp_ctx_destroy(c);
         return fail(UCFP_E_INDEX, "context allocation failed: %s", hipGetErrorString(e2));
@@ -155,7 +148,6 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->audio_ws) (void)hipFree(c->audio_ws);
     if (c->audio_done) (void)hipEventDestroy(c->audio_done);
     if (c->norm_done) (void)hipEventDestroy(c->norm_done);
-    if (c->frac8000) (void)hipFree(c->frac8000);
     delete c;
 }
 
@@ -279,7 +271,7 @@ static int wang_batch_impl(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_
     if (n_clips > 0x7fffffffu || n_total > ((size_t)1 << 46))
         return fail(UCFP_E_INVALID, "audio batch too large for one call");
     const ucfp::WangWs w = ucfp::wang_ws_layout(n_total, n_clips, sample_rate, c.peaks_per_sec);
-    if (w.n_seg > 0x7fffffffu || (size_t)w.n_sec * c.peaks_per_sec > 0x7fffffffu)
+    if (w.n_seg > 0x7fffffffu || (size_t)w.n_sec * c.peaks_per_sec > 0x7fffffffu || w.n_sec > 3000000u)   // byte offsets into the candidate arrays are 32-bit
         return fail(UCFP_E_INVALID, "audio batch too large for one call");
     const float floor_p = (float)(65536.0 * pow(10.0, (double)c.min_anchor_mag_db / 10.0));
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -287,7 +279,7 @@ static int wang_batch_impl(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_
     rc = grow(&ctx->audio_ws, &ctx->audio_ws_cap, w.total);
     if (rc) return rc;
     HIP_TRY(hipStreamWaitEvent(st, ctx->audio_done, 0));
-    ucfp::launch_wang_batch(d_pcm, d_offsets, n_total, n_clips, sample_rate, ctx->frac8000, c.fan_out, c.target_zone_t,
+    ucfp::launch_wang_batch(d_pcm, d_offsets, n_total, n_clips, sample_rate, c.fan_out, c.target_zone_t,
                             c.target_zone_f, c.peaks_per_sec, floor_p, ctx->audio_ws, w,
                             reinterpret_cast<uint32_t*>(d_out), cap_hashes, d_out_offsets, d_n_hashes, st);
     HIP_TRY(hipGetLastError());

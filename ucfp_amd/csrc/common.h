@@ -126,7 +126,7 @@ int launch_resample_linear(const float* in, size_t n, uint32_t sr_in, uint32_t s
 size_t audio_stft_frames(size_t n, int N, int hop);
 WangWs wang_ws_layout(size_t n_src_total, size_t n_clips, uint32_t sr_in, uint32_t pps);
 int launch_wang_batch(const float* pcm, const uint64_t* d_offsets, size_t n_src_total, size_t n_clips, uint32_t sr_in,
-                      const float* frac_tab, uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
+                      uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
                       float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* d_out_off,
                       uint64_t* out_count, hipStream_t stream);
 size_t haitsma_ws_bytes(size_t n5k);

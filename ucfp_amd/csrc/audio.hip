@@ -457,8 +457,8 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
 // of those 15 row maxima at bin k and none of the EARLIER rows' maxima equals v (an equal cell earlier in
 // (t, k) order wins the tie; rows outside [0, total) duplicate rows inside the window, so they are simply
 // skipped).  HBM sees the samples once and the peaks -- not 2 x 4 B x 512 bins per frame of spilled spectrum.
-constexpr int kSegMax = 512;    // frames per workgroup segment: long inputs (halo 14 / 512 = 2.7 %); short ones get
-                                // shorter segments so that ~1000 workgroups exist (wang_segment)
+constexpr int kSegMax = 2048;   // frames per workgroup segment: a segment recomputes 14 halo frames and runs ~2 extra rounds to drain the
+                                // judge, so long inputs want long segments (wang_segment); short ones get shorter segments so that ~1000 workgroups exist
 constexpr int kSW = 12;      // waves per workgroup = frames in flight
 constexpr int kRing = 38;    // >= 2 kRT + 2 kSW: the rows being judged (one round behind) + the rows being produced
 constexpr int kPl = 32;      // row-local candidates per frame: two of them are always >= 16 bins apart
@@ -497,10 +497,16 @@ struct WangStreamLds {
 // dword-index bit 4 with bit 6 gives every 16-dword piece its own quarter of the 64 banks.
 __device__ __forceinline__ uint32_t smp_swz(uint32_t s) { return s ^ ((s >> 2) & 16u); }
 
+// Frames per workgroup segment.  Long inputs: as close to kSegMax as gives a whole number of rounds of 256 workgroups
+// (one per CU) -- 4400 segments of 512 frames would run 17 full rounds and an 18th with 48 workgroups; 4608 of 489 run
+// 18 full ones.  Short inputs get shorter segments so that ~1000 workgroups exist.
 inline uint32_t wang_segment(size_t frames) {
     size_t seg = (frames + 1023) / 1024;
     if (seg < 48) seg = 48;
-    if (seg > (size_t)kSegMax) seg = kSegMax;
+    if (seg > (size_t)kSegMax) {
+        const size_t rounds = (frames + (size_t)256 * kSegMax - 1) / ((size_t)256 * kSegMax);
+        seg = (frames + 256 * rounds - 1) / (256 * rounds);
+    }
     return (uint32_t)seg;
 }
 
@@ -679,8 +685,11 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
             //   max(7 earlier rows at k) < v  and  max(7 later rows at k) <= v.
             // All reads are unconditional (lanes past the list read a stale entry and are masked at the end).
             const uint32_t n = L.pl_cnt[st];
-            const uint32_t pk = L.pl_k[st][lane & (kPl - 1)] & (uint32_t)(kWangBins - 1);
+            const uint32_t pk_raw = L.pl_k[st][lane & (kPl - 1)] & (uint32_t)(kWangBins - 1);
             const float pv = L.pl_v[st][lane & (kPl - 1)];
+            // lanes past the list follow lane 0's bin: one address, a broadcast -- their own stale bins would scatter
+            // over the banks and multiply the cycles of each of the 15 row reads below
+            const uint32_t pk = (uint32_t)lane < n ? pk_raw : (uint32_t)__builtin_amdgcn_readfirstlane((int)pk_raw);
             int rs = st - kRT;
             if (rs < 0) rs += kRing;
             float rr[2 * kRT + 1];
@@ -821,7 +830,9 @@ __global__ __launch_bounds__(kSW * 64) void wang_stream_kernel(const float* __re
     flush_put();
 }
 
-// one wave per second: keep the `pps` strongest, ordered by (t, k)
+// one wave per second: keep the `pps` strongest, ordered by (t, k).  A candidate is (p, tk = t << 9 | k) in one 8-byte
+// LDS word, so the rank loop reads one broadcast word per comparison; the survivors (<= pps <= 256) are compacted
+// with a ballot and ordered among themselves only.
 __global__ __launch_bounds__(64) void wang_select_kernel(const uint32_t* __restrict__ cand_cnt,
                                                          const uint32_t* __restrict__ cand_t,
                                                          const uint32_t* __restrict__ cand_k,
@@ -829,9 +840,8 @@ __global__ __launch_bounds__(64) void wang_select_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ n_sec_total,
                                                          uint32_t* __restrict__ sel_cnt, uint32_t* __restrict__ sel_t,
                                                          uint32_t* __restrict__ sel_k, float* __restrict__ sel_p) {
-    __shared__ uint32_t st[kCandCap], sk[kCandCap];
-    __shared__ float sp[kCandCap];
-    __shared__ uint8_t keep[kCandCap];
+    __shared__ float2 sc[kCandCap];       // (p, bits of tk)
+    __shared__ float2 kept[256];
     const uint32_t sec = blockIdx.x;
     const int lane = threadIdx.x;
     if (sec >= *n_sec_total) {            // the grid is a host-side upper bound
@@ -841,34 +851,38 @@ __global__ __launch_bounds__(64) void wang_select_kernel(const uint32_t* __restr
     uint32_t n = cand_cnt[sec];
     n = n < (uint32_t)kCandCap ? n : (uint32_t)kCandCap;
     for (uint32_t i = lane; i < n; i += 64) {
-        st[i] = cand_t[(size_t)sec * kCandCap + i];
-        sk[i] = cand_k[(size_t)sec * kCandCap + i];
-        sp[i] = cand_p[(size_t)sec * kCandCap + i];
+        const uint32_t tk = (cand_t[(size_t)sec * kCandCap + i] << 9) | cand_k[(size_t)sec * kCandCap + i];
+        sc[i] = make_float2(cand_p[(size_t)sec * kCandCap + i], __uint_as_float(tk));
     }
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) {
+    uint32_t nk = 0;                      // survivors so far (wave-uniform)
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const float2 me = sc[i < n ? i : 0];
+        const float p = me.x;
+        const uint32_t tk = __float_as_uint(me.y);
         uint32_t rank = 0;
-        const float p = sp[i];
-        const uint32_t t = st[i], k = sk[i];
         for (uint32_t j = 0; j < n; j++) {
-            const float q = sp[j];
-            const bool before = q > p || (q == p && (st[j] < t || (st[j] == t && sk[j] < k)));
+            const float2 o = sc[j];
+            const bool before = o.x > p || (o.x == p && __float_as_uint(o.y) < tk);
             rank += before ? 1u : 0u;
         }
-        keep[i] = rank < pps ? 1 : 0;
+        const bool keep = i < n && rank < pps;
+        const uint64_t m = __ballot(keep);
+        if (keep) kept[nk + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = me;
+        nk += (uint32_t)__popcll(m);
     }
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) {
-        if (!keep[i]) continue;
+    for (uint32_t i = lane; i < nk; i += 64) {
+        const float2 me = kept[i];
+        const uint32_t tk = __float_as_uint(me.y);
         uint32_t pos = 0;
-        const uint32_t t = st[i], k = sk[i];
-        for (uint32_t j = 0; j < n; j++)
-            if (keep[j] && (st[j] < t || (st[j] == t && sk[j] < k))) pos++;
-        sel_t[(size_t)sec * pps + pos] = t;
-        sel_k[(size_t)sec * pps + pos] = k;
-        sel_p[(size_t)sec * pps + pos] = sp[i];
+        for (uint32_t j = 0; j < nk; j++) pos += __float_as_uint(kept[j].y) < tk ? 1u : 0u;
+        sel_t[(size_t)sec * pps + pos] = tk >> 9;
+        sel_k[(size_t)sec * pps + pos] = tk & 511u;
+        sel_p[(size_t)sec * pps + pos] = me.x;
     }
-    if (lane == 0) sel_cnt[sec] = n < pps ? n : pps;
+    if (lane == 0) sel_cnt[sec] = nk;
 }
 
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
@@ -970,46 +984,46 @@ void launch_exclusive_scan(const uint32_t* in, size_t n, uint32_t* out, uint32_t
 __global__ void wang_compact_kernel(const uint32_t* __restrict__ sel_cnt, const uint32_t* __restrict__ sel_off,
                                     const uint32_t* __restrict__ sel_t, const uint32_t* __restrict__ sel_k,
                                     const float* __restrict__ sel_p, const uint32_t* __restrict__ sec_clip,
-                                    uint32_t n_sec, uint32_t pps, uint32_t* __restrict__ pt, uint32_t* __restrict__ pk,
+                                    uint32_t n_sec, uint32_t pps, uint32_t* __restrict__ ptk,
                                     float* __restrict__ pp, uint32_t* __restrict__ pc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n_sec * pps) return;
     const uint32_t sec = (uint32_t)(i / pps), j = (uint32_t)(i - (size_t)sec * pps);
     if (j >= sel_cnt[sec]) return;
     const uint32_t o = sel_off[sec] + j;
-    pt[o] = sel_t[i];
-    pk[o] = sel_k[i];
+    ptk[o] = (sel_t[i] << 9) | sel_k[i];
     pp[o] = sel_p[i];
     pc[o] = sec_clip[sec];
 }
 
 // ---- A6: pairing (src/modality/audio.rs:965-1003) ------------------------------------------------
+// ptk = t << 9 | k (t < 2^23 frames = 37 h per clip); the peaks of a clip are contiguous, [.., pend[clip]) ends it
 template <bool EMIT>
-__global__ void wang_pair_kernel(const uint32_t* __restrict__ pt, const uint32_t* __restrict__ pk,
-                                 const float* __restrict__ pp, const uint32_t* __restrict__ pc,
-                                 const uint32_t* __restrict__ np_ptr,
+__global__ void wang_pair_kernel(const uint32_t* __restrict__ ptk, const float* __restrict__ pp,
+                                 const uint32_t* __restrict__ pc, const uint32_t* __restrict__ sec_base,
+                                 const uint32_t* __restrict__ sel_off, const uint32_t* __restrict__ np_ptr,
                                  uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, float floor_p,
                                  uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
-                                 uint32_t* __restrict__ out, size_t cap) {
+                                 uint2* __restrict__ out, size_t cap) {
     const uint32_t np = *np_ptr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     uint32_t taken = 0;
     if (pp[i] >= floor_p) {
-        const uint32_t ta = pt[i], ka = pk[i], ca = pc[i];
+        const uint32_t a = ptk[i];
+        const int32_t ta = (int32_t)(a >> 9), ka = (int32_t)(a & 511u);
+        const uint32_t end = sel_off[sec_base[pc[i] + 1]];         // first peak of the next clip
         size_t o = EMIT ? offs[i] : 0;
-        for (uint32_t j = i + 1; j < np && taken < fan_out; j++) {
-            if (pc[j] != ca) break;                        // the peaks of a clip are contiguous: the next clip starts here
-            const int32_t dt = (int32_t)pt[j] - (int32_t)ta;
+        for (uint32_t j = i + 1; j < end && taken < fan_out; j++) {
+            const uint32_t b = ptk[j];
+            const int32_t dt = (int32_t)(b >> 9) - ta;
             if (dt <= 0) continue;
             if (dt > (int32_t)zone_t) break;
-            int32_t df = (int32_t)pk[j] - (int32_t)ka;
+            const int32_t kb = (int32_t)(b & 511u);
+            int32_t df = kb - ka;
             df = df < 0 ? -df : df;
             if (df > (int32_t)zone_f) continue;
-            if (EMIT && o < cap) {
-                out[2 * o] = (ka << 23) | (pk[j] << 14) | ((uint32_t)dt & 0x3fffu);
-                out[2 * o + 1] = ta;
-            }
+            if (EMIT && o < cap) out[o] = make_uint2(((uint32_t)ka << 23) | ((uint32_t)kb << 14) | ((uint32_t)dt & 0x3fffu), (uint32_t)ta);
             o++;
             taken++;
         }
@@ -1031,7 +1045,7 @@ __global__ void wang_clip_prep_kernel(const uint64_t* __restrict__ offsets, uint
     cl.src_n = offsets ? offsets[c + 1] - offsets[c] : n_single;
     cl.n8k = sr_in == (uint32_t)kWangSr ? cl.src_n : (uint64_t)(((unsigned __int128)cl.src_n * kWangSr) / sr_in);
     const uint64_t fr = cl.n8k >= (uint64_t)kWangN ? 1 + (cl.n8k - kWangN) / kWangHop : 0;
-    cl.frames = (uint32_t)fr;
+    cl.frames = (uint32_t)(fr < (1u << 23) ? fr : (1u << 23) - 1);     // (t << 9 | k) packing: 37 h per clip (the C ABI rejects longer single clips)
     cl.n_sec = fr ? (uint32_t)(((fr - 1) * kWangHop) / kWangSr + 1) : 0;
     cl.n_seg = (uint32_t)((fr + seg - 1) / seg);
     cl.pad = 0;
@@ -1197,17 +1211,19 @@ int launch_wang_batch(const float* pcm, const uint64_t* d_offsets, size_t n_src_
     launch_exclusive_scan(u32(w.sel_cnt), (size_t)w.n_sec, u32(w.sel_off), u32(w.scan_tmp), stream);
     hipLaunchKernelGGL(wang_compact_kernel, dim3(blocks_for((size_t)w.n_sec * pps, 256)), dim3(256), 0, stream,
                        u32(w.sel_cnt), u32(w.sel_off), u32(w.sel_t), u32(w.sel_k), f32(w.sel_p),
-                       (const uint32_t*)u32(w.sec_clip), w.n_sec, pps, u32(w.pt), u32(w.pk), f32(w.pp), u32(w.pc));
+                       (const uint32_t*)u32(w.sec_clip), w.n_sec, pps, u32(w.pt), f32(w.pp), u32(w.pc));
     const size_t maxp = (size_t)w.n_sec * pps;
     const uint32_t* np_ptr = u32(w.sel_off) + w.n_sec;  // total peaks
     (void)hipMemsetAsync(u32(w.pair_cnt), 0, (maxp + 1) * 4, stream);
-    hipLaunchKernelGGL(wang_pair_kernel<false>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
-                       u32(w.pk), f32(w.pp), (const uint32_t*)u32(w.pc), np_ptr, fan_out, zone_t, zone_f, floor_power,
-                       u32(w.pair_cnt), (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
+    hipLaunchKernelGGL(wang_pair_kernel<false>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream,
+                       (const uint32_t*)u32(w.pt), (const float*)f32(w.pp), (const uint32_t*)u32(w.pc),
+                       (const uint32_t*)u32(w.sec_base), (const uint32_t*)u32(w.sel_off), np_ptr, fan_out, zone_t, zone_f,
+                       floor_power, u32(w.pair_cnt), (const uint32_t*)nullptr, (uint2*)nullptr, (size_t)0);
     launch_exclusive_scan(u32(w.pair_cnt), maxp, u32(w.pair_off), u32(w.scan_tmp), stream);
-    hipLaunchKernelGGL(wang_pair_kernel<true>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream, u32(w.pt),
-                       u32(w.pk), f32(w.pp), (const uint32_t*)u32(w.pc), np_ptr, fan_out, zone_t, zone_f, floor_power,
-                       (uint32_t*)nullptr, (const uint32_t*)u32(w.pair_off), out, cap);
+    hipLaunchKernelGGL(wang_pair_kernel<true>, dim3(blocks_for(maxp, 256)), dim3(256), 0, stream,
+                       (const uint32_t*)u32(w.pt), (const float*)f32(w.pp), (const uint32_t*)u32(w.pc),
+                       (const uint32_t*)u32(w.sec_base), (const uint32_t*)u32(w.sel_off), np_ptr, fan_out, zone_t, zone_f,
+                       floor_power, (uint32_t*)nullptr, (const uint32_t*)u32(w.pair_off), reinterpret_cast<uint2*>(out), cap);
     if (out_count)
         hipLaunchKernelGGL(copy_u32_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)(u32(w.pair_off) + maxp),
                            out_count);

@@ -271,6 +271,9 @@ static int wang_batch_impl(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_
     if (n_clips > 0x7fffffffu || n_total > ((size_t)1 << 46))
         return fail(UCFP_E_INVALID, "audio batch too large for one call");
     const ucfp::WangWs w = ucfp::wang_ws_layout(n_total, n_clips, sample_rate, c.peaks_per_sec);
+    if (n_clips == 1 && w.frames >= ((size_t)1 << 23))
+        return fail(UCFP_E_INVALID, "a clip of %zu frames exceeds 2^23 (37 h at 8 kHz): split it", w.frames);
+    if (cap_hashes && ((uintptr_t)d_out & 7u)) return fail(UCFP_E_INVALID, "the hash buffer must be 8-byte aligned");
     if (w.n_seg > 0x7fffffffu || (size_t)w.n_sec * c.peaks_per_sec > 0x7fffffffu || w.n_sec > 3000000u)   // byte offsets into the candidate arrays are 32-bit
         return fail(UCFP_E_INVALID, "audio batch too large for one call");
     const float floor_p = (float)(65536.0 * pow(10.0, (double)c.min_anchor_mag_db / 10.0));

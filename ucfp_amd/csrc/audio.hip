@@ -1014,18 +1014,32 @@ __global__ void wang_pair_kernel(const uint32_t* __restrict__ ptk, const float* 
         const int32_t ta = (int32_t)(a >> 9), ka = (int32_t)(a & 511u);
         const uint32_t end = sel_off[sec_base[pc[i] + 1]];         // first peak of the next clip
         size_t o = EMIT ? offs[i] : 0;
-        for (uint32_t j = i + 1; j < end && taken < fan_out; j++) {
-            const uint32_t b = ptk[j];
-            const int32_t dt = (int32_t)(b >> 9) - ta;
-            if (dt <= 0) continue;
-            if (dt > (int32_t)zone_t) break;
-            const int32_t kb = (int32_t)(b & 511u);
-            int32_t df = kb - ka;
-            df = df < 0 ? -df : df;
-            if (df > (int32_t)zone_f) continue;
-            if (EMIT && o < cap) out[o] = make_uint2(((uint32_t)ka << 23) | ((uint32_t)kb << 14) | ((uint32_t)dt & 0x3fffu), (uint32_t)ta);
-            o++;
-            taken++;
+        // the walk is a chain of dependent decisions but not of dependent loads: eight following peaks are fetched at
+        // once (a peak past the clip reads as "infinitely late" and ends the walk)
+        bool done = false;
+        for (uint32_t j0 = i + 1; j0 < end && !done; j0 += 8) {
+            uint32_t bb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) bb[u] = j0 + u < end ? ptk[j0 + u] : 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (done) continue;
+                const uint32_t b = bb[u];
+                const int32_t dt = (int32_t)(b >> 9) - ta;
+                if (dt <= 0) continue;
+                if (dt > (int32_t)zone_t) {
+                    done = true;
+                    continue;
+                }
+                const int32_t kb = (int32_t)(b & 511u);
+                int32_t df = kb - ka;
+                df = df < 0 ? -df : df;
+                if (df > (int32_t)zone_f) continue;
+                if (EMIT && o < cap) out[o] = make_uint2(((uint32_t)ka << 23) | ((uint32_t)kb << 14) | ((uint32_t)dt & 0x3fffu), (uint32_t)ta);
+                o++;
+                taken++;
+                if (taken >= fan_out) done = true;
+            }
         }
     }
     if (!EMIT) counts[i] = taken;

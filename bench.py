@@ -429,8 +429,9 @@ def bench_cosine(args, rank, world, dev, ctx):
 
 
 def bench_audio(args, rank, world, dev, ctx):
-    """Secondary leg (BASELINE configs[2]): Wang landmarks over synthetic 44.1 kHz mono PCM:
-    linear resample to 8 kHz, STFT, peaks, pairs -- one stream per GPU."""
+    """Secondary leg (BASELINE configs[2]): Wang landmarks over synthetic 44.1 kHz mono PCM through the ragged-batch
+    entry point (ucfp_audio_wang_batch_dev): the stream kernel resamples to 8 kHz itself, cuts the STFT frames from an
+    LDS ring, picks peaks; pairs follow -- one stream per GPU, HBM sees the samples once."""
     import numpy as np
     import torch
     from ucfp_amd import _lib
@@ -447,28 +448,47 @@ def bench_audio(args, rank, world, dev, ctx):
     x += 0.0158 * torch.randn(n, dtype=torch.float32, device=dev, generator=g)
     x.clamp_(-0.5, 0.5)
     lib = _lib.load()
-    m = int(lib.ucfp_audio_resample_len(n, sr, 8000))
-    x8 = torch.empty(m, dtype=torch.float32, device=dev)
-    cap = int(lib.ucfp_audio_wang_max_hashes(m, None))
+    offs = torch.tensor([0, n], dtype=torch.int64, device=dev)
+    cap = int(lib.ucfp_audio_wang_batch_max_hashes(n, 1, sr, None))
     out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    oo = torch.zeros(2, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        _lib.check(lib.ucfp_audio_resample_linear_dev(ctx.handle, x.data_ptr(), n, sr, 8000, x8.data_ptr(), m, stream))
-        _lib.check(lib.ucfp_audio_wang_dev(ctx.handle, x8.data_ptr(), m, 8000, None, out.data_ptr(), cap,
-                                           cnt.data_ptr(), stream))
+        _lib.check(lib.ucfp_audio_wang_batch_dev(ctx.handle, x.data_ptr(), offs.data_ptr(), n, 1, sr, None, out.data_ptr(),
+                                                 cap, oo.data_ptr(), stream))
     step()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    steps = 3
+    steps = 5
     ev[0].record()
     for _ in range(steps):
         step()
     ev[1].record()
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / steps
-    nh = int(cnt.item())
+    nh = int(oo[1].item())
+    # the reference's request shape: a corpus of 4-second clips at 8 kHz (benches/end_to_end.rs:55-75), one call
+    clip_n, n_clips = 4 * 8000, 8192
+    xc = x[:n_clips * clip_n]
+    coffs = (torch.arange(n_clips + 1, dtype=torch.int64, device=dev) * clip_n).contiguous()
+    ccap = int(lib.ucfp_audio_wang_batch_max_hashes(n_clips * clip_n, n_clips, 8000, None))
+    cout = torch.empty((ccap, 2), dtype=torch.int32, device=dev)
+    coo = torch.zeros(n_clips + 1, dtype=torch.int64, device=dev)
+
+    def cstep():
+        _lib.check(lib.ucfp_audio_wang_batch_dev(ctx.handle, xc.data_ptr(), coffs.data_ptr(), n_clips * clip_n, n_clips, 8000,
+                                                 None, cout.data_ptr(), ccap, coo.data_ptr(), stream))
+    cstep()
+    torch.cuda.synchronize()
+    cev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    cev[0].record()
+    for _ in range(steps):
+        cstep()
+    cev[1].record()
+    torch.cuda.synchronize()
+    cms = cev[0].elapsed_time(cev[1]) / steps
+    del cout, coo
     # Haitsma-Kalker over the first hour (reference row a4): resample to 5 kHz, 2048-point STFT, 33 bands
     hsecs = min(secs, 3600)
     hn = sr * hsecs
@@ -489,12 +509,19 @@ def bench_audio(args, rank, world, dev, ctx):
     hev[1].record()
     torch.cuda.synchronize()
     hms = hev[0].elapsed_time(hev[1]) / steps
+    algo_bytes = n * 4 + nh * 8            # 176 400 B read per audio-second + 8 B per hash written
     res = {"haitsma": {"seconds": hsecs, "ms_per_pass": hms, "x_real_time": hsecs / (hms / 1e3) * world,
                        "frames": hframes},
-           "metric": "audio-seconds/s (Wang landmarks incl. 44.1k->8k linear resample)",
+           "metric": "audio-seconds/s (Wang landmarks incl. 44.1k->8k linear resample, fused)",
            "value": secs / (ms / 1e3) * world, "unit": "x real time", "seconds_per_gpu": secs, "ms_per_pass": ms,
-           "hashes": nh, "algorithmic_GBs": (n * 4 + nh * 8) / (ms / 1e3) / 1e9,
-           "note": "peaks are picked inside the STFT kernel (LDS ring of row maxima); no spectrogram spill"}
+           "hashes": nh, "algorithmic_GBs": algo_bytes / (ms / 1e3) / 1e9,
+           "roofline": {"bound": "hbm", "achieved": algo_bytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "the SURVEY 8(d) yardstick; the stream kernel itself is bound by VALU + LDS issue "
+                                "(profiles/r02/audio_*): 446 frames x (real 1024-point FFT + peak picking) per ms per CU"},
+           "clips_4s_8k": {"clips": n_clips, "ms_per_batch": cms, "clips_per_s": n_clips / (cms / 1e3) * world},
+           "note": "one launch sequence per batch; the resampler runs inside the STFT kernel (LDS sample ring); peaks are "
+                   "picked in the same kernel (LDS ring of row maxima); no spectrogram spill"}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle
         s = 60 * sr
@@ -502,14 +529,14 @@ def bench_audio(args, rank, world, dev, ctx):
         t0 = time.perf_counter()
         o = oracle.wang(oracle.resample_linear(xs, sr, 8000))
         dt = time.perf_counter() - t0
-        d8 = torch.empty(int(lib.ucfp_audio_resample_len(s, sr, 8000)), dtype=torch.float32, device=dev)
-        _lib.check(lib.ucfp_audio_resample_linear_dev(ctx.handle, x.data_ptr(), s, sr, 8000, d8.data_ptr(), d8.numel(), stream))
-        _lib.check(lib.ucfp_audio_wang_dev(ctx.handle, d8.data_ptr(), d8.numel(), 8000, None, out.data_ptr(), cap,
-                                           cnt.data_ptr(), stream))
+        so = torch.tensor([0, s], dtype=torch.int64, device=dev)
+        _lib.check(lib.ucfp_audio_wang_batch_dev(ctx.handle, x.data_ptr(), so.data_ptr(), s, 1, sr, None, out.data_ptr(), cap,
+                                                 oo.data_ptr(), stream))
         torch.cuda.synchronize()
-        gh = out[:int(cnt.item())].cpu().numpy().view(np.uint32)
-        res["cpu_baseline"] = {"value": 60.0 / dt, "unit": "x real time", "cores": oracle.num_threads(), "kind": "port",
-                               "sample": "first 60 s", "gpu_matches_oracle_on_sample": bool(np.array_equal(gh, o))}
+        gh = out[:int(oo[1].item())].cpu().numpy().view(np.uint32)
+        res["cpu_baseline"] = {"value": 60.0 / dt, "unit": "x real time", "threads": oracle.num_threads(), "kind": "port",
+                               "sample": "first 60 s (resample + Wang, C restatement under OpenMP)",
+                               "gpu_matches_oracle_on_sample": bool(np.array_equal(gh, o))}
     return res
 
 

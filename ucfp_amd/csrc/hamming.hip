@@ -85,10 +85,16 @@ __global__ void hamming_hist_reduce(uint32_t* __restrict__ hist, uint32_t parts,
 }
 
 // stride_b / stride_q: hist[b * stride_b + q * stride_q]  ([q][65] on the few-query path, [bin][padded q] otherwise)
+// also empties the candidate lists and the overflow flag of the search that starts here (cand_cnt may be null)
 __global__ void hamming_tau0(const uint32_t* __restrict__ hist, uint32_t nq, uint32_t k, uint32_t stride_b,
-                             uint32_t stride_q, uint32_t* __restrict__ tau0) {
+                             uint32_t stride_q, uint32_t* __restrict__ tau0, uint32_t* __restrict__ cand_cnt,
+                             uint32_t* __restrict__ overflow) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
+    if (cand_cnt) {
+        cand_cnt[q] = 0;
+        if (q == 0) *overflow = 0;
+    }
     uint32_t c[65];
 #pragma unroll
     for (int b = 0; b < 65; b++) c[b] = hist[(size_t)b * stride_b + (size_t)q * stride_q];   // 65 loads in flight
@@ -801,7 +807,8 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     p.cap = k <= 16 ? 24 : k <= 40 ? 64 : 160;
     if (n == 0) return p;  // empty shard: nothing to launch
     // sample: the first 32k codes. A lane then accepts ~k*n/sample items over the robust range,
-    // i.e. a wave leaves its fast path on ~64*k/sample = 2 % of the codes (k = 10).
+    // i.e. a wave leaves its fast path on ~64*k/sample = 2 % of the codes (k = 10).  (Sizing the sample so that a
+    // whole number of 4x stages ends exactly at n -- one stage fewer at 10 M and 12.5 M -- measured the same.)
     size_t s = 32768;
     if (s > n) s = n;
     p.sample_n = s;
@@ -899,7 +906,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         hipLaunchKernelGGL(hamming_sample_hist_lanes, dim3((unsigned)((p.sample_n + 1023) / 1024)), dim3(256), 0, stream,
                            codes, p.sample_n, queries, nq, u32(w.hist));
         hipLaunchKernelGGL(hamming_tau0, dim3((nq + 255) / 256), dim3(256), 0, stream, (const uint32_t*)u32(w.hist), nq,
-                           k, 1u, 65u, u32(w.tau0));
+                           k, 1u, 65u, u32(w.tau0), p.fast ? u32(w.cand_cnt) : (uint32_t*)nullptr, u32(w.overflow));
     } else {
         hipLaunchKernelGGL(hamming_sample_hist, dim3(p.sample_parts, p.qgroups), dim3(256), 0, stream, codes,
                            p.sample_n, p.per_part, queries, nq, u32(w.hist));
@@ -907,7 +914,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         hipLaunchKernelGGL(hamming_hist_reduce, dim3((65 * nqp + 255) / 256), dim3(256), 0, stream, u32(w.hist),
                            p.sample_parts, nqp);
         hipLaunchKernelGGL(hamming_tau0, dim3((nq + 63) / 64), dim3(64), 0, stream, (const uint32_t*)u32(w.hist), nq, k,
-                           nqp, 1u, u32(w.tau0));
+                           nqp, 1u, u32(w.tau0), p.fast ? u32(w.cand_cnt) : (uint32_t*)nullptr, u32(w.overflow));
     }
     if (!p.fast) {
         // robust tier over the whole (small) corpus: exact top-k straight into the outputs
@@ -919,12 +926,9 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
     } else {
         const uint32_t passes = (nq + kQP - 1) / kQP;
         const size_t lds = hamming_mfma_lds_bytes(nq);
-        const uint32_t slices = hamming_log_slices(nq);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_scan_mfma),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(hamming_reset_lists, dim3((nq + 255) / 256), dim3(256), 0, stream, nq, u32(w.cand_cnt),
-                           u32(w.overflow));
         i32x4* qimg = reinterpret_cast<i32x4*>(ws + w.qimg);
         if (nq > (uint32_t)kFewQueries)
             hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 128 + 255) / 256), dim3(256), 0, stream, queries,
@@ -945,11 +949,12 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                                    end, queries, nq, (const uint32_t*)tau_cur, u32(w.cand_cnt), u32(w.cand_d),
                                    u64(w.cand_id), p.cand_cap, u32(w.overflow));
             } else {
-            (void)hipMemsetAsync(u32(w.log_cnt), 0, (size_t)slices * 4, stream);
+            // every wave of the scan writes its slice's record count, and the slices of a launch are 0 .. wgs * passes *
+            // kMW - 1: the rescan covers exactly those (no memset of the counters)
             hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(kMW * 64), lds, stream, codes, begin, end,
                                queries, nq, (const i32x4*)qimg, (const uint32_t*)tau_cur,
                                reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow));
-            hipLaunchKernelGGL(hamming_rescan, dim3(slices), dim3(256), 0, stream, codes, ids, begin, end, queries,
+            hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * (unsigned)kMW), dim3(256), 0, stream, codes, ids, begin, end, queries,
                                (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
                                u64(w.cand_id), p.cand_cap, u32(w.overflow));

@@ -31,6 +31,37 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+_SO_NATIVE = os.path.join(_HERE, "_build", "libucfp_oracle_native.so")
+
+
+def _cpu_tag() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def use_native() -> str:
+    """Switch this process to the TIMED build (-O3 -march=native), compiled on THIS machine (a stamp file
+    records the CPU it was built for; a library built elsewhere is rebuilt).  Same sources, same float results
+    (-ffp-contract=off, no fast-math).  bench.py's cpu_baseline legs call this; tests use the portable build."""
+    global _lib
+    stamp = _SO_NATIVE + ".cpu"
+    tag = _cpu_tag()
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    fresh = (os.path.exists(_SO_NATIVE) and os.path.exists(stamp) and open(stamp).read() == tag and
+             all(os.path.getmtime(s) <= os.path.getmtime(_SO_NATIVE) for s in srcs))
+    if not fresh:
+        subprocess.run(["make", "-C", _HERE, "-B", "native"], check=True, capture_output=True)
+        open(stamp, "w").write(tag)
+    _lib = C.CDLL(_SO_NATIVE)
+    _declare(_lib)
+    return _SO_NATIVE
+
+
 _lib = None
 
 
@@ -81,6 +112,42 @@ def cosine_knn(ids, rows, query, k, ref_fold=False):
     m = f(ids.ctypes.data, rows.ctypes.data, n, dim, query.ctypes.data, k, out_ids.ctypes.data,
           out_sc.ctypes.data)
     return out_ids[:m].copy(), out_sc[:m].copy()
+
+
+def cosine_knn_batch_omp(ids, rows, queries, k):
+    """Timed-baseline form: nq queries, OpenMP over (row chunk, query) tiles with the reference's dot_product /
+    insert_topk, merged in (score desc, id asc).  -> (ids u64 [nq,k], scores f32 [nq,k], counts u32 [nq])."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, rows.shape[1])
+    nq = queries.shape[0]
+    o_ids = np.zeros((nq, max(k, 1)), np.uint64)
+    o_sc = np.zeros((nq, max(k, 1)), np.float32)
+    o_c = np.zeros(nq, np.uint32)
+    f = lib().ucfp_oracle_cosine_knn_batch_omp
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                  C.c_void_p, C.c_void_p]
+    f(ids.ctypes.data, rows.ctypes.data, rows.shape[0], rows.shape[1], queries.ctypes.data, nq, k, o_ids.ctypes.data,
+      o_sc.ctypes.data, o_c.ctypes.data)
+    return o_ids[:, :k], o_sc[:, :k], o_c
+
+
+def hamming_topk_omp(ids, codes, queries, k):
+    """Timed-baseline form of hamming_topk: OpenMP over (corpus slice, query) tiles, so one query uses every core."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    codes = np.ascontiguousarray(codes, dtype=np.uint64)
+    queries = np.ascontiguousarray(queries, dtype=np.uint64).reshape(-1)
+    nq = queries.shape[0]
+    o_ids = np.zeros((nq, max(k, 1)), np.uint64)
+    o_d = np.zeros((nq, max(k, 1)), np.uint32)
+    o_c = np.zeros(nq, np.uint32)
+    f = lib().ucfp_oracle_hamming_topk_omp
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(ids.ctypes.data, codes.ctypes.data, codes.shape[0], queries.ctypes.data, nq, k, o_ids.ctypes.data, o_d.ctypes.data,
+      o_c.ctypes.data)
+    return o_ids[:, :k], o_d[:, :k], o_c
 
 
 def hamming_topk(ids, codes, queries, k):

@@ -176,3 +176,111 @@ void ucfp_oracle_hamming_topk(const uint64_t* ids, const uint64_t* codes, size_t
         free(best);
     }
 }
+
+
+/* ---- timed CPU baselines (bench.py cpu_baseline legs) ---------------------------------------------------
+ * The reference's knn phase 2 is `par_iter().fold(local top-k via insert_topk).reduce(merge)` over the candidate
+ * vectors (src/index/embedded/mod.rs:324-340); rayon becomes OpenMP here: row chunks are folded in parallel with the
+ * reference's own dot_product / l2_norm / insert_topk, the per-chunk lists of a query are merged in the total order
+ * (score desc, id asc).  Scores are bit-identical to ucfp_oracle_cosine_knn. */
+void ucfp_oracle_cosine_knn_batch_omp(const uint64_t* ids, const float* rows, size_t n, size_t dim, const float* queries,
+                                      size_t nq, size_t k, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+    for (size_t q = 0; q < nq; q++) out_counts[q] = 0;
+    if (dim == 0 || k == 0 || nq == 0) return;
+    const size_t chunk = nq >= 64 ? 4096 : 512;     /* enough (chunk, query) tiles for every core at nq = 1 too */
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    float* vnorm = (float*)malloc((n ? n : 1) * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) vnorm[i] = l2_norm(rows + i * dim, dim);
+    hit_t* part = (hit_t*)malloc((nchunks ? nchunks : 1) * nq * (k + 1) * sizeof(hit_t));
+    size_t* plen = (size_t*)calloc((nchunks ? nchunks : 1) * nq, sizeof(size_t));
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (size_t c = 0; c < nchunks; c++)
+        for (size_t q = 0; q < nq; q++) {
+            const float* qv = queries + q * dim;
+            const float q_norm = l2_norm(qv, dim);
+            hit_t* local = part + (c * nq + q) * (k + 1);
+            size_t len = 0;
+            if (q_norm != 0.0f) {
+                const size_t i1 = (c + 1) * chunk < n ? (c + 1) * chunk : n;
+                for (size_t i = c * chunk; i < i1; i++) {
+                    if (vnorm[i] == 0.0f) continue;
+                    const float score = dot_product(qv, rows + i * dim, dim) / (q_norm * vnorm[i]);
+                    if (score != score) continue;
+                    insert_topk(local, &len, ids[i], score, k);
+                }
+            }
+            plen[c * nq + q] = len;
+        }
+#pragma omp parallel for schedule(static)
+    for (size_t q = 0; q < nq; q++) {
+        size_t m = 0;
+        for (size_t c = 0; c < nchunks; c++) m += plen[c * nq + q];
+        hit_t* all = (hit_t*)malloc((m ? m : 1) * sizeof(hit_t));
+        size_t w = 0;
+        for (size_t c = 0; c < nchunks; c++)
+            for (size_t e = 0; e < plen[c * nq + q]; e++) all[w++] = part[(c * nq + q) * (k + 1) + e];
+        qsort(all, m, sizeof(hit_t), cmp_hit_total);
+        const size_t len = m < k ? m : k;
+        for (size_t e = 0; e < k; e++) {
+            out_ids[q * k + e] = e < len ? all[e].id : ~0ull;
+            out_scores[q * k + e] = e < len ? all[e].score : 0.0f;
+        }
+        out_counts[q] = (uint32_t)len;
+        free(all);
+    }
+    free(part);
+    free(plen);
+    free(vnorm);
+}
+
+/* Hamming top-k parallel over corpus slices as well (a single query must still use every core): slices x queries
+ * tiles keep k-best lists, merged per query in (d asc, id asc).  Same answer as ucfp_oracle_hamming_topk. */
+void ucfp_oracle_hamming_topk_omp(const uint64_t* ids, const uint64_t* codes, size_t n, const uint64_t* queries, size_t nq,
+                                  size_t k, uint64_t* out_ids, uint32_t* out_dist, uint32_t* out_counts) {
+    if (k == 0 || nq == 0) return;
+    const size_t slice = (size_t)1 << 16;
+    const size_t ns = n ? (n + slice - 1) / slice : 1;
+    hd_t* part = (hd_t*)malloc(ns * nq * k * sizeof(hd_t));
+    uint32_t* plen = (uint32_t*)calloc(ns * nq, sizeof(uint32_t));
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (size_t sl = 0; sl < ns; sl++)
+        for (size_t q = 0; q < nq; q++) {
+            hd_t* best = part + (sl * nq + q) * k;
+            size_t len = 0;
+            const size_t i1 = (sl + 1) * slice < n ? (sl + 1) * slice : n;
+            const uint64_t qv = queries[q];
+            for (size_t i = sl * slice; i < i1; i++) {
+                hd_t c;
+                c.d = (uint32_t)__builtin_popcountll(qv ^ codes[i]);
+                if (len == k && c.d > best[len - 1].d) continue;      /* the common case: one compare */
+                c.id = ids[i];
+                if (len == k && cmp_hd(&c, &best[len - 1]) >= 0) continue;
+                size_t pos = len;
+                while (pos > 0 && cmp_hd(&c, &best[pos - 1]) < 0) pos--;
+                if (len < k) len++;
+                memmove(best + pos + 1, best + pos, (len - 1 - pos) * sizeof(hd_t));
+                best[pos] = c;
+            }
+            plen[sl * nq + q] = (uint32_t)len;
+        }
+#pragma omp parallel for schedule(static)
+    for (size_t q = 0; q < nq; q++) {
+        size_t m = 0;
+        for (size_t sl = 0; sl < ns; sl++) m += plen[sl * nq + q];
+        hd_t* all = (hd_t*)malloc((m ? m : 1) * sizeof(hd_t));
+        size_t w = 0;
+        for (size_t sl = 0; sl < ns; sl++)
+            for (size_t e = 0; e < plen[sl * nq + q]; e++) all[w++] = part[(sl * nq + q) * k + e];
+        qsort(all, m, sizeof(hd_t), cmp_hd);
+        const size_t len = m < k ? m : k;
+        for (size_t e = 0; e < k; e++) {
+            out_ids[q * k + e] = e < len ? all[e].id : ~0ull;
+            out_dist[q * k + e] = e < len ? all[e].d : 0xffffffffu;
+        }
+        out_counts[q] = (uint32_t)len;
+        free(all);
+    }
+    free(part);
+    free(plen);
+}

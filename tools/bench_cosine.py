@@ -11,11 +11,16 @@ from ucfp_amd import _lib, index  # noqa: E402
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nq", type=int, nargs="+", default=[1, 4, 8, 16, 32, 48, 64, 256])
+    ap.add_argument("--shapes", type=str, nargs="+", default=["1000000x768", "4000000x384"])
+    a = ap.parse_args()
     torch.cuda.set_device(0)
     ctx = _lib.default_context(0)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
-    for n, dim in ((1_000_000, 768), (4_000_000, 384)):
+    for n, dim in [tuple(int(v) for v in sh.split("x")) for sh in a.shapes]:
         g = torch.Generator(device=dev)
         g.manual_seed(1)
         rows = torch.randn((n, dim), dtype=torch.float32, device=dev, generator=g)
@@ -23,7 +28,7 @@ def main():
         ix = index.DeviceIndex(index.COSINE_F32, dim, index.APPEND_ONLY, ctx)
         ix.append_dev(0, ids.data_ptr(), rows.data_ptr(), n, stream)
         torch.cuda.synchronize()
-        for nq in (1, 16, 64, 256):
+        for nq in a.nq:
             q = torch.randn((nq, dim), dtype=torch.float32, device=dev, generator=g)
             k = 10
             o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)

@@ -262,6 +262,150 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
     }
 }
 
+// ---- 5 .. 48 queries: the row stream through v_mfma_f32_4x4x1_16B_f32 ------------------------------------------
+// The 16x16x4 tile above needs 16 rows per instruction, so a wave load touches 16 rows x 64 B (four lanes per row):
+// 5.4 TB/s at best.  The 4x4x1 form is 16 independent 4x4 outer products ("blocks"; layout measured with
+// tools/probe_mfma4x4.hip: lane = 4 block + i, A_b[i] / B_b[j] one value per lane, D_b[i][j] in register i of lane
+// 4 block + j).  Block b takes the k-slice 4 b .. 4 b + 3 of every 64-float chunk: lane (b, j) loads float4
+// row j, dims 64 c + 4 b .., so ONE wave load is 4 rows x 256 contiguous bytes, and its four components feed four
+// successive MFMAs against the queries' same dims (A: lane (b, i) = query 4 g + i, one ds_read_b128 per chunk and
+// query group from an LDS image whose row stride is 16 mod 64 floats: the read is conflict-free).  Two row tiles
+// (8 rows) share every A read.  The 16 blocks' partial dot products are summed across lanes at the end (two DPP
+// rotations inside a row of 16 lanes, two exchanges across rows).  HBM-bound up to 48 queries: 8 rows x 12 chunks
+// cost 96 G MFMAs (G = query groups of 4) of 8 cycles against 24 KiB of rows.
+struct CosineFilter {
+    const uint32_t* tau;
+    const float* uq;
+    uint32_t* ccnt;
+    uint32_t* ckey;
+    uint32_t* crow;
+    uint32_t cap;
+    uint32_t row_base;
+};
+constexpr int kBW = 8;     // waves per workgroup (one workgroup per CU: the query image fills its LDS)
+// A wave owns SUPERTILES of 32 consecutive rows (four 8-row tiles): the keys of a supertile are collected in LDS and
+// leave as 128-byte runs per query (stored straight from the accumulator lanes they were 16-byte pieces: a fifth of
+// the kernel's time at 16 queries).
+template <int NCH>         // 64-float chunks per row: dim <= 64 NCH
+__global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __restrict__ rows,
+                                                          const float* __restrict__ norms, size_t n, uint32_t dim,
+                                                          const float* __restrict__ queries,
+                                                          const float* __restrict__ qnorm, uint32_t nq_pass,
+                                                          uint32_t qstride, uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [16][qstride] query image, zero-filled past dim / nq_pass;
+    uint32_t* stage = reinterpret_cast<uint32_t*>(qs + 16 * qstride) + (threadIdx.x >> 6) * (16 * 32);   // then [wave][16][32] keys
+    for (uint32_t i = threadIdx.x; i < 16u * qstride; i += kBW * 64) {
+        const uint32_t qt = i / qstride, c = i - qt * qstride;
+        qs[i] = (qt < nq_pass && c < dim) ? queries[(size_t)qt * dim + c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = lane >> 2, j = lane & 3;
+    const size_t tiles = (n + 7) / 8, supers = (n + 31) / 32;
+    const size_t sstep = (size_t)gridDim.x * kBW;
+    const float* __restrict__ qrow = qs + (size_t)j * qstride + 4 * blk;     // this lane's A source: query 4 g + j
+    // A tile's rows are loaded as two halves (H chunks each).  While one half is multiplied the other -- or the same
+    // half of the NEXT tile -- is in flight: a wave always has ~12 KiB of row data outstanding.
+    constexpr int H = NCH / 2;
+    static_assert(NCH % 2 == 0, "two halves");
+    f32x4v xa0[H], xa1[H], xb0[H], xb1[H];
+    auto load_half = [&](f32x4v (&h0)[H], f32x4v (&h1)[H], size_t tile, int c0) {
+        const size_t r0 = tile * 8 + j, r1 = r0 + 4;
+        const float* __restrict__ v0 = rows + (r0 < n ? r0 : n - 1) * (size_t)dim + 4 * blk;   // clamped duplicates are not stored
+        const float* __restrict__ v1 = rows + (r1 < n ? r1 : n - 1) * (size_t)dim + 4 * blk;
+#pragma unroll
+        for (int c = 0; c < H; c++) {
+            const bool in = 64u * (c0 + c) + 4u * blk < dim;
+            h0[c] = in ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v0 + 64 * (c0 + c))) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            h1[c] = in ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v1 + 64 * (c0 + c))) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    size_t sup = (size_t)blockIdx.x * kBW + wave;
+    if (sup < supers) {
+        load_half(xa0, xa1, sup * 4, 0);
+        load_half(xb0, xb1, sup * 4, H);
+    }
+    for (; sup < supers; sup += sstep) {
+#pragma unroll 1
+        for (int t = 0; t < 4; t++) {
+            const size_t tile = sup * 4 + t;
+            // the tile after this one: the supertile's next, or the first of the wave's next supertile (past the end
+            // the loads fall on clamped rows and are dropped)
+            const size_t next = t < 3 ? tile + 1 : (sup + sstep) * 4;
+            const bool more = next < tiles;
+            const size_t r0 = tile * 8 + j, r1 = r0 + 4;
+            const float vn0 = norms[r0 < n ? r0 : n - 1], vn1 = norms[r1 < n ? r1 : n - 1];
+            f32x4v acc0[4], acc1[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc0[g] = acc1[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            auto mul_half = [&](const f32x4v (&h0)[H], const f32x4v (&h1)[H], int c0) {
+#pragma unroll
+                for (int c = 0; c < H; c++) {
+                    f32x4v a[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        a[g] = *reinterpret_cast<const f32x4v*>(qrow + (size_t)g * 4 * qstride + 64 * (c0 + c));
+                    // the eight accumulators are independent: each MFMA's successor on the same accumulator is eight
+                    // instructions away (issued back to back a dependent pair waits for the first one's passes)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            acc0[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g][e], h0[c][e], acc0[g], 0, 0, 0);
+                            acc1[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g][e], h1[c][e], acc1[g], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            mul_half(xa0, xa1, 0);
+            if (more) load_half(xa0, xa1, next, 0);
+            mul_half(xb0, xb1, H);
+            if (more) load_half(xb0, xb1, next, H);
+            // sum over the 16 blocks: lanes with the same j.  Inside a row of 16 lanes two rotations; across the four
+            // rows two exchanges.  Afterwards every lane holds the full dot products of its j.
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float a0 = acc0[g][i], a1 = acc1[g][i];
+                    a0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x124, 0xf, 0xf, false));   // row_ror:4
+                    a1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0x124, 0xf, 0xf, false));
+                    a0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x128, 0xf, 0xf, false));   // row_ror:8
+                    a1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0x128, 0xf, 0xf, false));
+                    a0 += __shfl_xor(a0, 16, 64);
+                    a1 += __shfl_xor(a1, 16, 64);
+                    a0 += __shfl_xor(a0, 32, 64);
+                    a1 += __shfl_xor(a1, 32, 64);
+                    // lanes of block b = 2 g + {0, 1} key rows j / 4 + j of the tile for query 4 g + i
+                    const uint32_t qt = g * 4 + i;
+                    if ((blk >> 1) == g) {
+                        const bool second = blk & 1;
+                        const float dot = second ? a1 : a0, vn = second ? vn1 : vn0, qn = qt < nq_pass ? qnorm[qt] : 0.f;
+                        uint32_t key = 0xffffffffu;
+                        if (vn != 0.f && qn != 0.f) {
+                            const float sc = dot / (qn * vn);
+                            if (sc == sc) key = score_to_key(sc);
+                        }
+                        stage[qt * 32 + 8 * t + (second ? 4 : 0) + j] = key;
+                    }
+                }
+            }
+        }
+        // the supertile's keys: 16 queries x 32 rows, two queries (2 x 128 B) per store
+        wave_lds_fence();
+        const size_t row = sup * 32 + (lane & 31);
+#pragma unroll
+        for (int qq = 0; qq < 16; qq += 2) {
+            const uint32_t qt = qq + (lane >> 5);
+            const uint32_t key = stage[qt * 32 + (lane & 31)];
+            if (qt < nq_pass && row < n) keys[(size_t)qt * n + row] = key;
+        }
+        wave_lds_fence();
+    }
+}
+
 // ---- streaming variant for a handful of queries (the reference's own shape: one query per request) ----
 // The MFMA tile above feeds a wave-load with 16 rows x 64 B; for NQ <= 4 queries the matrix pipes do nothing
 // useful and the row stream is all that matters.  Here a wave reads a ROW as contiguous 1 KiB wave-loads (lane l
@@ -357,15 +501,6 @@ __device__ __forceinline__ void lds_wait(f32x4v& reg) {
 // tau is the k-th best key of a sample of the corpus, so about k n / sample rows per query pass; the test costs four
 // VALU operations per result (acc against uq[q] * |row|, uq = score(tau) * |q|, with a 2^-21 relative slack for the
 // roundings of the exact path) and only the passers pay for the division and the exact key.
-struct CosineFilter {
-    const uint32_t* tau;
-    const float* uq;
-    uint32_t* ccnt;
-    uint32_t* ckey;
-    uint32_t* crow;
-    uint32_t cap;
-    uint32_t row_base;
-};
 template <int NG, bool FILT, int RT>
 __global__ __launch_bounds__(kGW * 64) __attribute__((amdgpu_waves_per_eu(4 / RT, 4 / RT))) void cosine_keys_gemm(const float* __restrict__ rows,
                                                              const float* __restrict__ norms, size_t n, uint32_t dim,
@@ -620,6 +755,36 @@ __global__ void cosine_tau_kernel(const uint32_t* __restrict__ base_key, uint32_
 }
 }  // namespace
 
+namespace {
+// 5 .. 16 queries over rows of at most 1024 floats: the 4x4x1 row-stream kernel (beyond 16 queries its four times
+// smaller matrix instruction costs more issue slots than the 16x16x4 tile's narrower loads cost bandwidth)
+bool blocks_path(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n) {
+    return mfma_ok(rows, dim) && dim >= 512 && dim <= 1024 && nq_pass > 4 && nq_pass <= 16 && n >= 4096 &&
+           (reinterpret_cast<uintptr_t>(queries) & 15u) == 0;
+}
+void launch_blocks(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
+                   uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag, hipStream_t stream) {
+    const uint32_t nch = ((dim + 63) / 64 + 1) & ~1u;      // whole chunks, an even number of them
+    const uint32_t qstride = nch * 64 + 16;                // >= dim, and 16 mod 64 floats: conflict-free A reads
+    const size_t lds = (size_t)16 * qstride * sizeof(float) + (size_t)kBW * 16 * 32 * sizeof(uint32_t);
+    const size_t supers = (n + 31) / 32;
+    unsigned grid = (unsigned)((supers + kBW - 1) / kBW);
+    if (grid > 256) grid = 256;
+    auto go = [&](auto kern) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBW * 64), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass, qstride,
+                           keys, run_flag);
+    };
+    if (nch <= 2) go(cosine_keys_blocks<2>);
+    else if (nch <= 4) go(cosine_keys_blocks<4>);
+    else if (nch <= 6) go(cosine_keys_blocks<6>);
+    else if (nch <= 8) go(cosine_keys_blocks<8>);
+    else if (nch <= 12) go(cosine_keys_blocks<12>);
+    else go(cosine_keys_blocks<16>);
+}
+}  // namespace
+
 bool cosine_filter_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n) {
     return gemm_path(rows, dim, queries, nq_pass) && n >= ((size_t)1 << 18) && n < ((size_t)1 << 32);
 }
@@ -673,6 +838,10 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
             else if (nb == 3) go(cosine_keys_stream<4, 3>);
             else go(cosine_keys_stream<4, 4>);
         }
+        return 0;
+    }
+    if (blocks_path(rows, dim, queries, nq_pass, n)) {
+        launch_blocks(rows, norms, n, dim, queries, qnorm, nq_pass, keys, run_flag, stream);
         return 0;
     }
     if (mfma_ok(rows, dim)) {

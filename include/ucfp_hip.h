@@ -189,6 +189,19 @@ int ucfp_audio_wang_batch_dev(ucfp_ctx* ctx, const float* d_pcm, const uint64_t*
                               uint32_t sample_rate, const ucfp_wang_config* cfg, uint8_t* d_out, size_t cap_hashes,
                               uint64_t* d_out_offsets, void* stream);
 
+/* Host micro-batcher for clips (audio): one clip per request thread (handlers.rs:704-918); concurrent
+ * submit() calls become ONE ucfp_audio_wang_batch_dev call over at most max_batch clips / max_samples samples, flushed
+ * no later than max_delay_us after the first pending clip.  All clips at `sample_rate` (resampled to 8 kHz in the
+ * kernel).  *n_hashes = hashes of this clip (t_anchor relative to the clip); more than cap_hashes -> UCFP_E_INVALID
+ * with the first cap_hashes written (as ucfp_audio_wang). */
+typedef struct ucfp_audio_batcher ucfp_audio_batcher;
+int ucfp_audio_batcher_create(ucfp_ctx* ctx, uint32_t sample_rate, const ucfp_wang_config* cfg, size_t max_batch,
+                              size_t max_samples, uint32_t max_delay_us, ucfp_audio_batcher** out);
+void ucfp_audio_batcher_destroy(ucfp_audio_batcher* b);
+int ucfp_audio_batcher_submit(ucfp_audio_batcher* b, const float* pcm, size_t n, uint8_t* out, size_t cap_hashes,
+                              size_t* n_hashes);
+int ucfp_audio_batcher_stats(ucfp_audio_batcher* b, uint64_t* batches, uint64_t* items);
+
 size_t ucfp_audio_haitsma_frames(size_t n_samples, uint32_t sample_rate);
 int ucfp_audio_haitsma(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate,
                        const ucfp_haitsma_config* cfg, uint32_t* out, size_t cap_frames, size_t* n_frames);
@@ -231,6 +244,22 @@ int ucfp_text_simhash_batch_dev(ucfp_ctx* ctx, const uint8_t* d_utf8, const uint
                                 int mode, uint8_t* d_out, int32_t* d_status, void* stream);
 int ucfp_text_simhash_batch(ucfp_ctx* ctx, const uint8_t* utf8, const uint64_t* offsets, size_t n, int mode,
                             uint8_t* out, int32_t* status);
+
+/* Host micro-batcher for documents: the caller side of handlers::ingest_text
+ * (src/server/handlers.rs:304-460) fingerprints one document per request thread, up to 512 in flight
+ * (src/bin/ucfp.rs:267).  submit() is BLOCKING and thread-safe: concurrent calls are packed back to back into one
+ * pinned blob + offset table, one H2D copy, one ucfp_text_*_batch_dev launch and one D2H copy -- at most max_batch
+ * documents or max_bytes of text per flush, flushed no later than max_delay_us after the first pending document.
+ * One (algorithm, mode, k) per batcher: the host keeps one for RAW_ASCII and one for PRETOKENIZED documents.
+ * `out` receives UCFP_MINHASH_BYTES or UCFP_SIMHASH_BYTES; *status as in the batch calls. */
+#define UCFP_TEXT_ALGO_MINHASH 1
+#define UCFP_TEXT_ALGO_SIMHASH 2
+typedef struct ucfp_text_batcher ucfp_text_batcher;
+int ucfp_text_batcher_create(ucfp_ctx* ctx, uint32_t algo, int mode, uint32_t shingle_k, size_t max_batch, size_t max_bytes,
+                             uint32_t max_delay_us, ucfp_text_batcher** out);
+void ucfp_text_batcher_destroy(ucfp_text_batcher* b);
+int ucfp_text_batcher_submit(ucfp_text_batcher* b, const uint8_t* utf8, size_t len, uint8_t* out, int32_t* status);
+int ucfp_text_batcher_stats(ucfp_text_batcher* b, uint64_t* batches, uint64_t* items);
 
 /* ---- banded MinHash LSH (the reference only re-tags the record, text.rs:437-446) ----
  * key_b = FNV-style fold of slots [b*rows, (b+1)*rows) + splitmix64 finaliser; bands*rows <= 128.

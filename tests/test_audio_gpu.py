@@ -237,3 +237,28 @@ def test_wang_batch_long_clip_between_short_ones(gpu_ctx, oracle):
     for c, g in zip(clips, got):
         o = oracle.wang(c)
         assert g.shape == o.shape and np.array_equal(g, o)
+
+
+@pytest.mark.parametrize("sr", [8000, 44100])
+def test_micro_batcher_coalesces_concurrent_clips(gpu_ctx, oracle, sr):
+    """32 threads each submit one clip at a time (handlers.rs:704-918); every thread gets the
+    hashes of ITS clip (t_anchor relative to the clip), bit-exact, from far fewer launch sequences than clips."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ucfp_amd import audio
+    rng = np.random.default_rng(sr)
+    lens = rng.integers(0, 5 * sr, size=300)
+    lens[:4] = [0, 1, sr // 8, 4 * sr]
+    clips = [_clip(rng, int(n), i % 4) for i, n in enumerate(lens)]
+    ref = [oracle.wang(c if sr == 8000 else oracle.resample_linear(c, sr, 8000)) for c in clips]
+    b = audio.WangBatcher(sr, max_batch=64, max_samples=64 * 5 * sr, max_delay_us=3000, ctx=gpu_ctx)
+    try:
+        with ThreadPoolExecutor(32) as pool:
+            got = list(pool.map(b.submit, clips))
+        for i, (g, o) in enumerate(zip(got, ref)):
+            assert g.shape == o.shape and np.array_equal(g, o), (i, clips[i].size, g.shape, o.shape)
+        batches, items = b.stats()
+        assert items == len(clips) and batches < len(clips) // 3, (batches, items)
+        g = b.submit(clips[3])                          # a lone clip is flushed by the deadline
+        assert np.array_equal(g, ref[3])
+    finally:
+        b.close()

@@ -124,3 +124,61 @@ def test_minhash_estimates_jaccard(gpu_ctx):
     est = float((slots[0] == slots[1]).mean())
     assert abs(est - j) < 0.15, (est, j)
     assert (slots[0] == slots[2]).mean() < 0.1
+
+
+@pytest.mark.parametrize("kind", ["minhash", "simhash"])
+def test_micro_batcher_coalesces_concurrent_documents(gpu_ctx, oracle, kind):
+    """48 threads each submit one document at a time (the reference's per-request shape,
+    handlers.rs:304-460); every thread gets ITS record, bit-exact, from far fewer launches than documents.  ASCII and
+    host-canonicalised documents are mixed: they flow through the two C batchers behind TextBatcher."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ucfp_amd import text
+    rng = random.Random(48)
+    docs = [_doc(rng, rng.choice([30, 200, 900, 4096, 12000])) for _ in range(900)]
+    for i in range(0, len(docs), 9):
+        docs[i] = "Café naïve façade — " + docs[i] + " straße ﬁne 你好 世界"
+    docs[5], docs[6] = "", "  ... !!"                    # no tokens: status -1 for that document only
+    fo = oracle.text_minhash_batch if kind == "minhash" else oracle.text_simhash_batch
+    ref, ref_st = [], []
+    for d in docs:
+        b, mode = text._prepare(d, text.TextOpts())
+        o, s = fo([b], mode=mode)
+        ref.append(o[0].tobytes())
+        ref_st.append(int(s[0]))
+    b = text.TextBatcher(kind, max_batch=128, max_bytes=256 << 10, max_delay_us=2000, ctx=gpu_ctx)
+    try:
+        with ThreadPoolExecutor(48) as pool:
+            got = list(pool.map(b.submit, docs))
+        for i, (rec, st) in enumerate(got):
+            assert st == ref_st[i], (i, st, ref_st[i])
+            if st == 0:
+                assert rec == ref[i], i
+        assert ref_st[5] == -1 and ref_st[6] == -1
+        batches, items = b.stats()
+        assert items == len(docs) and batches < len(docs) // 4, (batches, items)
+        # a lone request is flushed by the deadline; one larger than the blob is refused, not truncated
+        rec, st = b.submit(docs[1])
+        assert st == 0 and rec == ref[1]
+        from ucfp_amd.errors import UcfpError
+        with pytest.raises(UcfpError):
+            b.submit("word " * (60 << 10))
+    finally:
+        b.close()
+
+
+def test_micro_batcher_byte_budget_closes_the_set(gpu_ctx, oracle):
+    """Documents that together exceed max_bytes never share a flush: the set is closed early and the rest follow."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ucfp_amd import text
+    rng = random.Random(7)
+    docs = [_doc(rng, 3000) for _ in range(64)]
+    o, _ = oracle.text_minhash_batch([d.encode() for d in docs])
+    b = text.TextBatcher("minhash", max_batch=1024, max_bytes=10_000, max_delay_us=50_000, ctx=gpu_ctx)
+    try:
+        with ThreadPoolExecutor(16) as pool:
+            got = list(pool.map(b.submit, docs))
+        assert all(st == 0 and rec == o[i].tobytes() for i, (rec, st) in enumerate(got))
+        batches, items = b.stats()
+        assert items == 64 and batches >= 64 // 3        # at most three 3000-byte documents fit one flush
+    finally:
+        b.close()

@@ -116,6 +116,17 @@ SIGNATURES = {
     "ucfp_image_batcher_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                             C.POINTER(C.c_int32)]),
     "ucfp_image_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ucfp_text_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_size_t, C.c_size_t,
+                                           C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ucfp_text_batcher_destroy": (None, [C.c_void_p]),
+    "ucfp_text_batcher_submit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32)]),
+    "ucfp_text_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ucfp_audio_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(WangConfig), C.c_size_t, C.c_size_t,
+                                            C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ucfp_audio_batcher_destroy": (None, [C.c_void_p]),
+    "ucfp_audio_batcher_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.POINTER(C.c_size_t)]),
+    "ucfp_audio_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                        C.c_uint32, C.c_size_t, C.c_void_p]),

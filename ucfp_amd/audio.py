@@ -107,6 +107,49 @@ def wang_hashes_batch(clips, sample_rate: int, cfg: Optional[WangConfig] = None,
     return [out[oo[i]:oo[i + 1]].copy() for i in range(len(arrs))]
 
 
+class WangBatcher:
+    """Host micro-batcher for clips (handlers.rs:704-918 fingerprints one clip per request): concurrent
+    `submit` calls become one ucfp_audio_wang_batch_dev launch sequence.  All clips at `sample_rate`."""
+
+    def __init__(self, sample_rate: int = WANG_SR, cfg: Optional[WangConfig] = None, *, max_batch: int = 1024,
+                 max_samples: int = 64 << 20, max_delay_us: int = 500, ctx=None):
+        _check_rate(sample_rate)
+        self._lib = _lib.load()
+        self.ctx = ctx or _lib.current_context()
+        self.sample_rate = sample_rate
+        self._cfg = (cfg or WangConfig())._c()
+        h = C.c_void_p()
+        _lib.check(self._lib.ucfp_audio_batcher_create(self.ctx.handle, sample_rate, C.byref(self._cfg), max_batch,
+                                                       max_samples, max_delay_us, C.byref(h)))
+        self.handle = h
+
+    def submit(self, samples) -> np.ndarray:
+        """-> uint32 [n, 2] hashes of this clip.  Blocks until they are ready."""
+        x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+        cap = max(1, int(self._lib.ucfp_audio_wang_batch_max_hashes(x.size, 1, self.sample_rate, C.byref(self._cfg))))
+        out = np.zeros((cap, 2), np.uint32)
+        n = C.c_size_t(0)
+        _lib.check(self._lib.ucfp_audio_batcher_submit(self.handle, x.ctypes.data, x.size, out.ctypes.data, cap,
+                                                       C.byref(n)))
+        return out[: n.value].copy()
+
+    def stats(self):
+        b, i = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.ucfp_audio_batcher_stats(self.handle, C.byref(b), C.byref(i)))
+        return int(b.value), int(i.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_audio_batcher_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def haitsma_frames(samples, sample_rate: int, cfg: Optional[HaitsmaConfig] = None, ctx=None) -> np.ndarray:
     ctx = ctx or _lib.current_context()
     _check_rate(sample_rate)

@@ -161,6 +161,60 @@ def simhash_batch(texts: Sequence[str], opts: Optional[TextOpts] = None, ctx=Non
     return _batch("simhash", texts, opts or TextOpts(), ctx)
 
 
+ALGO_MINHASH, ALGO_SIMHASH = 1, 2
+
+
+class TextBatcher:
+    """Host micro-batcher (handlers.rs:304-460 fingerprints one document per request): many request
+    threads call `submit` concurrently, the library packs them into one GPU launch.  Two C batchers sit behind this
+    object -- one for raw ASCII documents, one for the documents the host had to canonicalise and tokenise."""
+
+    def __init__(self, kind: str = "minhash", opts: Optional[TextOpts] = None, *, max_batch: int = 4096,
+                 max_bytes: int = 8 << 20, max_delay_us: int = 200, ctx=None):
+        if kind not in ("minhash", "simhash"):
+            raise UnsupportedError(f"text batcher kind `{kind}`")
+        self._lib = _lib.load()
+        self.ctx = ctx or _lib.current_context()
+        self.opts = opts or TextOpts()
+        self.kind = kind
+        self.rec = MINHASH_BYTES if kind == "minhash" else SIMHASH_BYTES
+        algo = ALGO_MINHASH if kind == "minhash" else ALGO_SIMHASH
+        self._handles = {}
+        for mode in (RAW_ASCII, PRETOKENIZED):
+            h = C.c_void_p()
+            _lib.check(self._lib.ucfp_text_batcher_create(self.ctx.handle, algo, mode, self.opts.k, max_batch, max_bytes,
+                                                          max_delay_us, C.byref(h)))
+            self._handles[mode] = h
+
+    def submit(self, text: str):
+        """-> (record bytes, status).  Blocks until this document's record is ready."""
+        doc, mode = _prepare(text, self.opts)
+        out = (C.c_uint8 * self.rec)()
+        st = C.c_int32(0)
+        _lib.check(self._lib.ucfp_text_batcher_submit(self._handles[mode], doc, len(doc), out, C.byref(st)))
+        return bytes(out), int(st.value)
+
+    def stats(self):
+        """-> (launches, documents) summed over both modes."""
+        tb = ti = 0
+        for h in self._handles.values():
+            b, i = C.c_uint64(0), C.c_uint64(0)
+            _lib.check(self._lib.ucfp_text_batcher_stats(h, C.byref(b), C.byref(i)))
+            tb, ti = tb + int(b.value), ti + int(i.value)
+        return tb, ti
+
+    def close(self):
+        for h in getattr(self, "_handles", {}).values():
+            self._lib.ucfp_text_batcher_destroy(h)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _raise_for(status: int):
     if status == -1:
         raise ModalityError("text has no tokens after canonicalisation")

@@ -332,6 +332,44 @@ def image_hash_batch(frames: np.ndarray, algo: int, pixfmt: int = 0, exact=None,
     return out, status
 
 
+PNG_OK, PNG_NEEDS_HOST, PNG_CORRUPT = 0, 1, -1
+
+
+def inflate(z: bytes, cap: int):
+    """zlib stream -> (status, bytes) by the restated RFC 1950/1951 decoder (ucfp_oracle_png.c)."""
+    f = lib().ucfp_oracle_inflate
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    out = np.zeros(max(cap, 1), np.uint8)
+    n = C.c_size_t(0)
+    rc = f(z, len(z), out.ctypes.data, cap, C.byref(n))
+    return rc, out[: n.value].tobytes()
+
+
+def png_probe(png: bytes):
+    """-> (status, width, height, pixfmt)."""
+    f = lib().ucfp_oracle_png_probe
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    w, h, fmt = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+    rc = f(png, len(png), C.byref(w), C.byref(h), C.byref(fmt))
+    return rc, w.value, h.value, fmt.value
+
+
+def png_decode(png: bytes):
+    """-> (status, pixels uint8 [h, w] or [h, w, c] (None unless status == PNG_OK))."""
+    rc, w, h, fmt = png_probe(png)
+    if rc != PNG_OK:
+        return rc, None
+    c = _BPP[fmt]
+    px = np.zeros((h, w) if c == 1 else (h, w, c), np.uint8)
+    f = lib().ucfp_oracle_png_decode
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    rc = f(png, len(png), px.ctypes.data, px.size)
+    return rc, (px if rc == PNG_OK else None)
+
+
 def image_normalize(frame: np.ndarray, pixfmt: int = 0) -> np.ndarray:
     frame = np.ascontiguousarray(frame, dtype=np.uint8)
     h, w = frame.shape[:2]

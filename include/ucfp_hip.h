@@ -120,6 +120,33 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
                           size_t frame_stride, int pixfmt, const ucfp_image_preprocess* pre,
                           const uint8_t* exact, uint8_t* out, int32_t* status);
 
+/* ---- PNG front end ----
+ * The reference decodes the upload inside the SDK call (src/modality/image.rs:68-70, :176-179: imgfprint ->
+ * image::load_from_memory); BASELINE config 1 (1 k 256x256 PNGs) is decode-bound on the CPU.  These entry points take
+ * the ENCODED files: one blob + n + 1 byte offsets (like the text calls), all announced with ONE geometry and pixel
+ * format -- the host reads those 24 bytes of each upload with ucfp_png_probe and groups by them.  One wave per file:
+ * chunk walk, inflate (RFC 1950/1951, speculative parallel Huffman decoding), PNG filter reconstruction.
+ * Decoded on the device: 8-bit greyscale / RGB / RGBA, non-interlaced, without tRNS.  status[i]:
+ *   0                      decoded (and hashed)
+ *   UCFP_IMAGE_NEEDS_HOST  a valid PNG of another kind (palette, 16-bit, grey+alpha, interlaced, tRNS) or of another
+ *                          geometry / format than announced: decode it with the host's decoder, submit the pixels
+ *   UCFP_E_MODALITY        not a PNG / damaged stream (the reference answers 400)
+ * Chunk CRCs and the Adler-32 trailer are not verified on the device.
+ * png_bytes = d_offsets[n] (the host knows it; sizes the context's workspace: about png_bytes + n x (2 x frame bytes)). */
+#define UCFP_IMAGE_NEEDS_HOST 1
+/* Host-side: geometry and pixel format of a PNG from its IHDR.  UCFP_OK, UCFP_IMAGE_NEEDS_HOST or UCFP_E_MODALITY. */
+int ucfp_png_probe(const uint8_t* png, size_t len, uint32_t* width, uint32_t* height, int* pixfmt);
+/* Encoded files -> frames (frame i at d_frames + i*frame_stride, rows row_stride apart). */
+int ucfp_image_png_decode_batch_dev(ucfp_ctx* ctx, const uint8_t* d_png, const uint64_t* d_offsets, size_t n,
+                                    size_t png_bytes, uint32_t width, uint32_t height, int pixfmt, uint8_t* d_frames,
+                                    size_t row_stride, size_t frame_stride, int32_t* d_status, void* stream);
+/* Encoded files -> records: decode into the context's workspace, then ucfp_image_hash_batch_dev's kernels.
+ * d_exact as there (n x 32 bytes: BLAKE3 of each file, or NULL).  Records of files that did not decode are zero. */
+int ucfp_image_png_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_png, const uint64_t* d_offsets, size_t n,
+                                  size_t png_bytes, uint32_t width, uint32_t height, int pixfmt,
+                                  const ucfp_image_preprocess* pre, const uint8_t* d_exact, uint8_t* d_out,
+                                  int32_t* d_status, void* stream);
+
 /* Host micro-batcher: the caller side of handlers::ingest_image
  * (src/server/handlers.rs:232-302) hashes one image per request thread, up to 512 in flight
  * (src/bin/ucfp.rs:267).  submit() is BLOCKING and thread-safe: concurrent calls are coalesced

@@ -183,7 +183,7 @@ static int inflate_raw(Bits* b, uint8_t* out, size_t cap, size_t* produced) {
             int r = huff_build(&ll, lens, nlen);
             if (r < 0 || (r > 0 && nlen - ll.count[0] != 1)) return PNG_CORRUPT;   /* incomplete only with one code */
             r = huff_build(&dd, lens + nlen, ndist);
-            if (r < 0 || (r > 0 && ndist - dd.count[0] != 1)) return PNG_CORRUPT;
+            if (r < 0 || (r > 0 && ndist - dd.count[0] > 1)) return PNG_CORRUPT;   /* no distance code at all: a block of literals */
             int rc = inflate_codes(b, &ll, &dd, out, cap, &op);
             if (rc) return rc;
         } else {

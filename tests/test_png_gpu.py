@@ -1,0 +1,186 @@
+"""GPU parity of the PNG front end (ucfp_image_png_*): decoded pixels bit-equal to Pillow's and to the oracle's,
+records equal to the oracle's records of those pixels."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PIL = pytest.importorskip("PIL.Image")
+
+from test_oracle_png import _png, config1_png   # noqa: E402
+
+
+def _chunk(t, d):
+    return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+
+def _raw_png(arr, idat_split=None, comp=None, extra=b""):
+    """PNG with filter type 0 everywhere, a chosen zlib stream maker and IDAT chunking."""
+    h = arr.shape[0]
+    bpp = 1 if arr.ndim == 2 else arr.shape[2]
+    w = arr.shape[1]
+    rows = b"".join(b"\0" + arr[y].tobytes() for y in range(h))
+    z = (comp or (lambda d: zlib.compress(d, 6)))(rows)
+    parts = [z] if not idat_split else [z[i:i + idat_split] for i in range(0, len(z), idat_split)]
+    ctype = {1: 0, 3: 2, 4: 6}[bpp]
+    return (b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + extra +
+            b"".join(_chunk(b"IDAT", p) for p in parts) + _chunk(b"IEND", b""))
+
+
+def test_config1_set_decodes_to_pillow_pixels_and_oracle_records(gpu_ctx, oracle):
+    """BASELINE config 1: 256x256 RGB ramps xor noise (bench.py's generator), compress levels 1 and 6."""
+    from ucfp_amd import image
+    pngs, imgs = [], []
+    for i in range(96):
+        p, im = config1_png(i, level=1 if i % 2 else 6)
+        pngs.append(p)
+        imgs.append(im)
+    fr, st = image.decode_pngs(pngs, 256, 256, image.PIX_RGB8, ctx=gpu_ctx)
+    assert not st.any(), st
+    for i in range(len(pngs)):
+        assert np.array_equal(fr[i], imgs[i]), i
+        assert np.array_equal(fr[i], np.asarray(PIL.open(io.BytesIO(pngs[i])).convert("RGB")))
+    rng = np.random.default_rng(1)
+    ex = rng.integers(0, 256, (len(pngs), 32), dtype=np.uint8)
+    for algo in (image.PHASH, image.MULTI):
+        rec, st = image.fingerprint_pngs(pngs, 256, 256, image.PIX_RGB8, algo=algo, exact=ex, ctx=gpu_ctx)
+        ref, _ = oracle.image_hash_batch(np.stack(imgs), algo, pixfmt=1, exact=ex)
+        assert not st.any() and np.array_equal(rec, ref)
+
+
+@pytest.mark.parametrize("mode,shape,fmt", [("L", (97, 131), 0), ("RGB", (64, 50, 3), 1), ("RGBA", (33, 77, 4), 2),
+                                            ("RGB", (300, 1021, 3), 1), ("L", (1, 1), 0), ("RGBA", (2, 3, 4), 2)])
+def test_colour_types_filters_and_levels(gpu_ctx, oracle, mode, shape, fmt):
+    from ucfp_amd import image
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    base = np.add.outer(np.arange(shape[0]) * 3, np.arange(shape[1]) * 2)
+    if len(shape) == 3:
+        base = base[..., None] + np.arange(shape[2]) * 40
+    smooth = (base & 255).astype(np.uint8)
+    noisy = rng.integers(0, 256, shape, dtype=np.uint8)
+    flat = np.full(shape, 77, np.uint8)
+    pngs, want = [], []
+    for arr in (smooth, noisy, smooth ^ (noisy & 3), flat, (noisy & 0xF0)):
+        for kw in ({"compress_level": 1}, {"compress_level": 9, "optimize": True}, {"compress_level": 0},
+                   {"compress_level": 6}):
+            pngs.append(_png(arr, mode, **kw))
+            want.append(arr)
+    fr, st = image.decode_pngs(pngs, shape[1], shape[0], fmt, ctx=gpu_ctx)
+    assert not st.any(), st
+    for i, wv in enumerate(want):
+        assert np.array_equal(fr[i], wv), (mode, i)
+        rc, px = oracle.png_decode(pngs[i])
+        assert rc == 0 and np.array_equal(px, fr[i])
+
+
+def test_every_filter_type_and_block_type(gpu_ctx, oracle):
+    """Hand-built streams: filter types 0-4 row by row; stored, fixed-code and dynamic blocks; IDAT split into 1-byte,
+    100-byte and 8 KiB chunks (libpng's default); ancillary chunks in between."""
+    from ucfp_amd import image
+    rng = np.random.default_rng(9)
+    h, w, bpp = 70, 53, 3
+    img = rng.integers(0, 256, (h, w * bpp), dtype=np.uint8).astype(np.int32)
+    img[20:40] = (np.arange(w * bpp) * 3) & 255                      # compressible rows
+    rows = []
+    for y in range(h):
+        ft = y % 5
+        cur, up = img[y], (img[y - 1] if y else np.zeros_like(img[0]))
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]])
+        if ft == 0:
+            pred = 0
+        elif ft == 1:
+            pred = a
+        elif ft == 2:
+            pred = up
+        elif ft == 3:
+            pred = (a + up) >> 1
+        else:
+            p = a + up - c
+            pa, pb, pc = abs(p - a), abs(p - up), abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, up, c))
+        rows.append(bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+    raw = b"".join(rows)
+
+    def fixed(d):
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        return co.compress(d) + co.flush()
+
+    def mixed(d):   # stored + dynamic + fixed blocks in one stream
+        co = zlib.compressobj(0)
+        out = co.compress(d[:3000]) + co.flush(zlib.Z_FULL_FLUSH)
+        co2 = zlib.compressobj(9, zlib.DEFLATED, -15)
+        body = co2.compress(d[3000:9000]) + co2.flush(zlib.Z_SYNC_FLUSH)
+        co3 = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+        tail = co3.compress(d[9000:]) + co3.flush()
+        # splice raw deflate pieces after the level-0 stream's header: drop its final block + adler, append
+        co0 = zlib.compressobj(0, zlib.DEFLATED, -15)
+        first = co0.compress(d[:3000]) + co0.flush(zlib.Z_SYNC_FLUSH)
+        return b"\x78\x01" + first + body + tail + struct.pack(">I", zlib.adler32(d))
+    pngs = []
+    ihdr = _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+    for comp in (lambda d: zlib.compress(d, 0), lambda d: zlib.compress(d, 1), lambda d: zlib.compress(d, 9), fixed, mixed):
+        z = comp(raw)
+        assert zlib.decompress(z) == raw
+        for split in (None, 1, 100, 8192):
+            parts = [z] if not split else [z[i:i + split] for i in range(0, len(z), split)]
+            pngs.append(b"\x89PNG\r\n\x1a\n" + ihdr + _chunk(b"tEXt", b"k\0v") + _chunk(b"pHYs", bytes(9)) +
+                        b"".join(_chunk(b"IDAT", p) for p in parts) + _chunk(b"tIME", bytes(7)) + _chunk(b"IEND", b""))
+    fr, st = image.decode_pngs(pngs, w, h, image.PIX_RGB8, ctx=gpu_ctx)
+    assert not st.any(), st
+    want = img.astype(np.uint8).reshape(h, w, bpp)
+    for i in range(len(pngs)):
+        assert np.array_equal(fr[i], want), i
+        assert np.array_equal(np.asarray(PIL.open(io.BytesIO(pngs[i]))), want)
+
+
+def test_dense_matches_and_long_distances(gpu_ctx, oracle):
+    """Streams made almost entirely of matches (flat and periodic images: dist 1, dist = row, dist up to 32 KiB), where
+    one subsequence of the speculative decoder expands to kilobytes."""
+    from ucfp_amd import image
+    rng = np.random.default_rng(21)
+    h, w = 256, 1024
+    tile = rng.integers(0, 256, (8, w), dtype=np.uint8)
+    cases = [np.zeros((h, w), np.uint8), np.tile(tile, (h // 8, 1)), np.tile(rng.integers(0, 256, (h, 4), dtype=np.uint8), (1, w // 4)),
+             np.tile(rng.integers(0, 256, (31, w), dtype=np.uint8), (9, 1))[:h]]   # period 31 rows = 31 775 bytes back
+    pngs = [_raw_png(c, comp=lambda d: zlib.compress(d, 9)) for c in cases] + [_png(c, "L", compress_level=9) for c in cases]
+    fr, st = image.decode_pngs(pngs, w, h, image.PIX_GRAY8, ctx=gpu_ctx)
+    assert not st.any(), st
+    for i in range(len(pngs)):
+        assert np.array_equal(fr[i], cases[i % len(cases)]), i
+
+
+def test_needs_host_and_damaged_files(gpu_ctx, oracle):
+    from ucfp_amd import image
+    rng = np.random.default_rng(5)
+    good, img = config1_png(7, side=64)
+    pal = io.BytesIO()
+    PIL.fromarray(rng.integers(0, 256, (64, 64), dtype=np.uint8), "L").convert("P").save(pal, "PNG")
+    deep = io.BytesIO()
+    PIL.fromarray(rng.integers(0, 65535, (64, 64), dtype=np.uint16)).save(deep, "PNG")
+    other_geom, _ = config1_png(8, side=32)
+    gray = _png(rng.integers(0, 256, (64, 64), dtype=np.uint8), "L")
+    truncated = good[: len(good) // 2]
+    z = bytearray(good)
+    z[len(z) // 2] ^= 0x40            # flips a bit inside the deflate stream: wrong length or invalid code (CRC not checked)
+    trns = _raw_png(img, extra=_chunk(b"tRNS", bytes(6)))
+    too_short = _raw_png(img[:40])    # IHDR says 64 rows... built with 40: patch the header
+    too_short = too_short[:16] + struct.pack(">II", 64, 64) + too_short[24:]
+    pngs = [good, pal.getvalue(), deep.getvalue(), other_geom, gray, truncated, b"GIF89a" + bytes(80), trns, too_short, good]
+    assert image.png_probe(good) == (0, 64, 64, image.PIX_RGB8)
+    assert image.png_probe(pal.getvalue())[0] == image.NEEDS_HOST and image.png_probe(b"GIF89a" + bytes(80))[0] < 0
+    rec, st = image.fingerprint_pngs(pngs, 64, 64, image.PIX_RGB8, algo=image.MULTI, ctx=gpu_ctx)
+    assert list(st[:5]) == [0, 1, 1, 1, 1], st
+    assert st[5] < 0 and st[6] < 0 and st[7] == 1 and st[8] < 0 and st[9] == 0, st
+    ref, _ = oracle.image_hash_batch(img[None], 7, pixfmt=1)
+    assert np.array_equal(rec[0], ref[0]) and np.array_equal(rec[9], ref[0])
+    assert not rec[1:9].any()
+    for i in (1, 2, 7):
+        assert oracle.png_decode(pngs[i])[0] == oracle.PNG_NEEDS_HOST
+    for i in (5, 6, 8):
+        assert oracle.png_decode(pngs[i])[0] == oracle.PNG_CORRUPT
+    _, st2 = image.fingerprint_pngs([bytes(z)], 64, 64, image.PIX_RGB8, ctx=gpu_ctx)   # must not hang or fault
+    assert st2[0] in (0, -1)

@@ -127,6 +127,14 @@ SIGNATURES = {
     "ucfp_audio_batcher_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                             C.POINTER(C.c_size_t)]),
     "ucfp_audio_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ucfp_png_probe": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                 C.POINTER(C.c_int)]),
+    "ucfp_image_png_decode_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                                  C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                  C.c_void_p]),
+    "ucfp_image_png_hash_batch_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                C.c_uint32, C.c_uint32, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                        C.c_uint32, C.c_size_t, C.c_void_p]),

@@ -60,6 +60,10 @@ struct ucfp_ctx {
     uint8_t* audio_ws = nullptr;
     size_t audio_ws_cap = 0;
     hipEvent_t audio_done = nullptr;
+    // PNG front end: gathered zlib streams, filtered scanlines, decoded frames of the last batch
+    uint8_t* png_ws = nullptr;
+    size_t png_ws_cap = 0;
+    hipEvent_t png_done = nullptr;
 };
 
 namespace {
@@ -129,6 +133,7 @@ int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
     hipError_t e2 = hipMalloc((void**)&c->norm_ws, kNormWsFrames * 65536);
     if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->audio_done, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->png_done, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->norm_done, hipEventDisableTiming);
     if (e2 != hipSuccess) {
         ucfp_ctx_destroy(c);
@@ -147,6 +152,8 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->host_stream) (void)hipStreamDestroy(c->host_stream);
     if (c->audio_ws) (void)hipFree(c->audio_ws);
     if (c->audio_done) (void)hipEventDestroy(c->audio_done);
+    if (c->png_done) (void)hipEventDestroy(c->png_done);
+    if (c->png_ws) (void)hipFree(c->png_ws);
     if (c->norm_done) (void)hipEventDestroy(c->norm_done);
     delete c;
 }
@@ -187,6 +194,106 @@ int ucfp_image_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frame
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, frames, n, width, height, row_stride, frame_stride, pixfmt,
                                                  min_dim, max_dim, exact, out, status, (hipStream_t)stream));
+    return UCFP_OK;
+}
+
+// ---------------------------------- PNG front end ----------------------------------------------
+
+int ucfp_png_probe(const uint8_t* png, size_t len, uint32_t* width, uint32_t* height, int* pixfmt) {
+    if (!png || !width || !height || !pixfmt) return fail(UCFP_E_INVALID, "NULL argument");
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    auto be = [&](size_t o) { return (uint32_t)png[o] << 24 | (uint32_t)png[o + 1] << 16 | (uint32_t)png[o + 2] << 8 | png[o + 3]; };
+    if (len < 8 + 25 || memcmp(png, sig, 8) != 0 || be(8) != 13 || memcmp(png + 12, "IHDR", 4) != 0)
+        return fail(UCFP_E_MODALITY, "not a PNG file");
+    *width = be(16);
+    *height = be(20);
+    const int depth = png[24], ctype = png[25], comp = png[26], filt = png[27], lace = png[28];
+    if (*width == 0 || *height == 0 || comp != 0 || filt != 0 || lace > 1) return fail(UCFP_E_MODALITY, "damaged IHDR");
+    if (depth != 8 || lace != 0) return UCFP_IMAGE_NEEDS_HOST;
+    if (ctype == 0) *pixfmt = UCFP_PIX_GRAY8;
+    else if (ctype == 2) *pixfmt = UCFP_PIX_RGB8;
+    else if (ctype == 6) *pixfmt = UCFP_PIX_RGBA8;
+    else return UCFP_IMAGE_NEEDS_HOST;
+    return UCFP_OK;
+}
+
+static int png_check(ucfp_ctx* ctx, const void* d_png, const void* d_offsets, size_t n, size_t png_bytes, uint32_t w, uint32_t h,
+                     int pixfmt) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (n && (!d_png || !d_offsets)) return fail(UCFP_E_INVALID, "png/offsets is NULL");
+    if (pixfmt < UCFP_PIX_GRAY8 || pixfmt > UCFP_PIX_RGBA8) return fail(UCFP_E_INVALID, "unknown pixfmt %d", pixfmt);
+    if (w == 0 || h == 0 || w > 16384 || h > 16384) return fail(UCFP_E_MODALITY, "PNG geometry %ux%u outside 1 .. 16384", w, h);
+    if (n > 0x7fffffffu || png_bytes >= ((size_t)1 << 32)) return fail(UCFP_E_INVALID, "PNG batch too large for one call");
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    if ((size_t)h * ((size_t)w * bpp + 1) >= ((size_t)1 << 31)) return fail(UCFP_E_INVALID, "PNG frame too large for the device decoder");
+    if ((size_t)w * bpp > 60000) return fail(UCFP_E_INVALID, "PNG rows of %zu bytes exceed the decoder's row buffer", (size_t)w * bpp);
+    return UCFP_OK;
+}
+
+// Decode into caller frames (frames != NULL) or into the workspace's own frame area; returns the layout used.
+static int png_decode_impl(ucfp_ctx* ctx, const uint8_t* d_png, const uint64_t* d_offsets, size_t n, size_t png_bytes,
+                           uint32_t w, uint32_t h, int pixfmt, uint8_t* frames, size_t row_stride, size_t frame_stride,
+                           int32_t* d_status, hipStream_t st, ucfp::PngWs* layout, uint8_t** own_frames) {
+    // callers hold ctx->mu
+    ucfp::PngWs l;
+    size_t need = ucfp::png_ws_bytes(n, png_bytes, w, h, pixfmt, &l);
+    const size_t frames_off = need;
+    if (!frames) need += n * frame_stride;
+    int rc = grow(&ctx->png_ws, &ctx->png_ws_cap, need);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, ctx->png_done, 0));
+    uint8_t* fr = frames ? frames : ctx->png_ws + frames_off;
+    ucfp::launch_png_decode(d_png, d_offsets, n, w, h, pixfmt, ctx->png_ws, l, fr, row_stride, frame_stride, d_status, st);
+    HIP_TRY(hipGetLastError());
+    if (layout) *layout = l;
+    if (own_frames) *own_frames = fr;
+    return UCFP_OK;
+}
+
+int ucfp_image_png_decode_batch_dev(ucfp_ctx* ctx, const uint8_t* d_png, const uint64_t* d_offsets, size_t n,
+                                    size_t png_bytes, uint32_t width, uint32_t height, int pixfmt, uint8_t* d_frames,
+                                    size_t row_stride, size_t frame_stride, int32_t* d_status, void* stream) {
+    int rc = png_check(ctx, d_png, d_offsets, n, png_bytes, width, height, pixfmt);
+    if (rc) return rc;
+    if (n == 0) return UCFP_OK;
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    if (!d_frames) return fail(UCFP_E_INVALID, "frames is NULL");
+    if (row_stride < (size_t)width * bpp || (n > 1 && frame_stride < row_stride * (size_t)(height - 1) + (size_t)width * bpp))
+        return fail(UCFP_E_INVALID, "row_stride / frame_stride too small for %ux%u", width, height);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = png_decode_impl(ctx, d_png, d_offsets, n, png_bytes, width, height, pixfmt, d_frames, row_stride, frame_stride,
+                         d_status, (hipStream_t)stream, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->png_done, (hipStream_t)stream));
+    return UCFP_OK;
+}
+
+int ucfp_image_png_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_png, const uint64_t* d_offsets, size_t n,
+                                  size_t png_bytes, uint32_t width, uint32_t height, int pixfmt,
+                                  const ucfp_image_preprocess* pre, const uint8_t* d_exact, uint8_t* d_out,
+                                  int32_t* d_status, void* stream) {
+    int rc = png_check(ctx, d_png, d_offsets, n, png_bytes, width, height, pixfmt);
+    if (rc) return rc;
+    const size_t rec = ucfp_image_record_bytes(algo);
+    if (!rec) return fail(UCFP_E_UNSUPPORTED, "image algo mask %u is not one of ahash|phash|dhash|multi", algo);
+    if (n == 0) return UCFP_OK;
+    if (!d_out) return fail(UCFP_E_INVALID, "out is NULL");
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    const size_t row = ((size_t)width * bpp + 15) & ~(size_t)15, frame = row * height;   // 16-byte rows: the fused hash path
+    const uint32_t min_dim = pre ? pre->min_dimension : 32u, max_dim = pre ? pre->max_dimension : 8192u;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ucfp::PngWs l;
+    uint8_t* fr = nullptr;
+    rc = png_decode_impl(ctx, d_png, d_offsets, n, png_bytes, width, height, pixfmt, nullptr, row, frame, nullptr, st, &l, &fr);
+    if (rc) return rc;
+    HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, fr, n, width, height, row, frame, pixfmt, min_dim, max_dim, d_exact,
+                                                 d_out, d_status, st));
+    ucfp::launch_png_merge_status(ctx->png_ws, l, n, d_out, (uint32_t)rec, d_status, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->png_done, st));
     return UCFP_OK;
 }
 

@@ -34,6 +34,17 @@ int launch_image_record_codes(const uint8_t* records, size_t n, uint32_t rec_byt
 int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,
                        hipStream_t stream);
 
+// png.hip
+struct PngWs {
+    size_t zbuf = 0, info = 0, raw = 0, raw_stride = 0, raw_n = 0, total = 0;
+};
+size_t png_ws_bytes(size_t n, size_t png_bytes, uint32_t w, uint32_t h, int pixfmt, PngWs* ws);
+int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, int pixfmt, uint8_t* ws,
+                      const PngWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
+                      hipStream_t stream);
+int launch_png_merge_status(const uint8_t* ws, const PngWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
+                            hipStream_t stream);
+
 // hamming.hip
 struct HammingPlan {
     uint32_t qgroups = 0;       // ceil(nq / 64)

@@ -1,0 +1,806 @@
+// png.hip -- PNG front end on the GPU: compressed uploads in, decoded frames out, so that BASELINE
+// config 1 ("?algorithm=phash on 1 k 256x256 PNGs") no longer leaves the GPU waiting on a host decoder.
+//
+// The reference decodes inside the SDK call (src/modality/image.rs:68-70, :176-179: imgfprint -> image::load_from_memory
+// -> png crate).  Here a batch of PNG files takes three kernels, ONE WAVE PER IMAGE each:
+//
+//   png_scan      walks the chunks (PNG 5.3), checks IHDR against the geometry the batch was announced with, gathers
+//                 the IDAT payloads into one contiguous zlib stream.
+//   png_inflate   RFC 1950/1951.  Huffman decoding is serial in the bit stream, so the wave SPECULATES: the next
+//                 64 x B bits are cut into 64 subsequences, lane j decodes from a guessed bit offset j*B.  Huffman
+//                 codes self-synchronise: after a few symbols a wrong parse falls into step with the right one, so
+//                 lane j's exit position is usually right even though its start was not.  Lane j+1 restarts from lane
+//                 j's exit until the chain of (start == predecessor's exit) reaches from lane 0 (whose start is known)
+//                 to the end -- by construction the accepted parse IS the sequential one.  Then every lane decodes its
+//                 subsequence once more into the LDS window (literals directly; matches are listed and resolved in
+//                 stream order, 64 at a time where they do not depend on each other).
+//   png_unfilter  PNG 9.2 filters.  Average and Paeth chain along the row AND need the row above: lane j takes row
+//                 64 k + j one pixel behind lane j-1, so "above" and "above-left" are the neighbour lane's last two
+//                 outputs (a diagonal wavefront, 64 rows in flight).
+//
+// Scope: 8-bit greyscale / RGB / RGBA, non-interlaced, no tRNS -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
+// the host's decoder (like non-ASCII text).  Chunk CRCs and the Adler-32 trailer are NOT verified on the device (a
+// damaged file that still inflates to exactly height x (1 + row bytes) is hashed, where the reference rejects it).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ucfp_hip.h"
+#include "common.h"
+
+namespace ucfp {
+
+namespace {
+
+constexpr int kRoot = 10, kDRoot = 8;                  // bits indexed by the first-level tables
+constexpr uint32_t kIterOut = 4096;                    // output bytes one speculation round may add
+constexpr uint32_t kRing = 32768 + kIterOut + 64;      // LDS window: the 32 KiB deflate history + one round (multiple of 4)
+constexpr uint32_t kMatchCap = 512;                    // matches listed per round
+constexpr int kStageWords = 288;                       // compressed words staged per round: 64 x 128 bits + overshoot + refill
+constexpr int kMaxB = 128;                             // bits per subsequence
+
+// table entries: value (literal / length base / distance base) | extra bits << 16 | code length << 20 | kind << 24
+constexpr uint32_t kLit = 0, kLen = 1, kEob = 2, kSlow = 3;
+constexpr uint32_t kInvalid = kSlow << 24;             // code length 0: resolved (or rejected) by the canonical slow path
+
+struct InflateLds {
+    uint32_t lit[1 << kRoot];
+    uint32_t dst[1 << kDRoot];
+    uint32_t stage[kStageWords];
+    uint32_t m_dst[kMatchCap];
+    uint32_t m_ld[kMatchCap];                          // len | dist << 16 ... dist up to 32768 needs 16 bits: len << 16 | (dist - 1)
+    uint16_t ll_sorted[288];
+    uint16_t d_sorted[32];
+    uint16_t ll_count[16];
+    uint16_t d_count[16];
+    uint8_t lens[320];
+    uint8_t ring[kRing];
+};
+
+__device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t len) {
+    if (sym < 256) return sym | len << 20 | kLit << 24;
+    if (sym == 256) return len << 20 | kEob << 24;
+    const uint32_t c = sym - 257;
+    if (c >= 29) return kInvalid;
+    uint32_t ex, base;
+    if (c < 8) ex = 0, base = 3 + c;
+    else if (c == 28) ex = 0, base = 258;
+    else ex = (c - 4) >> 2, base = 3 + ((4 + (c & 3)) << ex);
+    return base | ex << 16 | len << 20 | kLen << 24;
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len) {
+    if (sym >= 30) return kInvalid;
+    uint32_t ex, base;
+    if (sym < 4) ex = 0, base = 1 + sym;
+    else ex = (sym - 2) >> 1, base = 1 + ((2 + (sym & 1)) << ex);
+    return base | ex << 16 | len << 20 | kLit << 24;
+}
+
+// Canonical decode, one bit at a time (codes longer than the root, and the verdict on invalid prefixes).
+__device__ uint32_t slow_code(uint64_t buf, const uint16_t* count, const uint16_t* sorted, bool dist) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; l++) {
+        code |= (int)(buf & 1);
+        buf >>= 1;
+        const int cnt = count[l];
+        if (code - cnt < first) {
+            const uint32_t sym = sorted[index + (code - first)];
+            return dist ? dist_entry(sym, l) : lit_entry(sym, l);
+        }
+        index += cnt;
+        first += cnt;
+        first <<= 1;
+        code <<= 1;
+    }
+    return kInvalid;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Builds one code from lens[0 .. n): first-level table, canonical arrays for the slow path.  Lane j owns symbols
+// [5 j, 5 j + 5).  Returns 0 complete, 1 incomplete, -1 over-subscribed; *used = symbols with a code.
+template <bool DIST>
+__device__ int build_table(const uint8_t* lens, int n, uint32_t* tab, uint16_t* count, uint16_t* sorted, int lane, int* used) {
+    constexpr int R = DIST ? kDRoot : kRoot;
+    for (int i = lane; i < (1 << R); i += 64) tab[i] = kInvalid;
+    // per-lane histogram of the code lengths 1 .. 15, three 10-bit counters per word
+    uint32_t mine[5] = {0, 0, 0, 0, 0};
+    uint8_t l5[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const int s = lane * 5 + t;
+        const uint32_t l = s < n ? lens[s] : 0;
+        l5[t] = (uint8_t)l;
+        if (l) {
+            const uint32_t w = (l - 1) / 3, sh = ((l - 1) % 3) * 10;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (w == (uint32_t)k) mine[k] += 1u << sh;
+        }
+    }
+    uint32_t run[5], tot[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t inc = wave_incl_scan(mine[k], lane);
+        run[k] = inc - mine[k];
+        tot[k] = __shfl(inc, 63, 64);
+    }
+    int left = 1, code = 0, off = 0, total = 0;
+    uint32_t next[16], offs[16];
+    next[0] = offs[0] = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) {
+        const uint32_t c = (tot[(l - 1) / 3] >> (((l - 1) % 3) * 10)) & 1023u;
+        left = (left << 1) - (int)c;
+        next[l] = (uint32_t)code;
+        offs[l] = (uint32_t)off;
+        code = (code + (int)c) << 1;
+        off += (int)c;
+        total += (int)c;
+        if (lane == 0) count[l] = (uint16_t)c;
+    }
+    if (lane == 0) count[0] = 0;
+    *used = total;
+    if (left < 0) return -1;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const uint32_t l = l5[t];
+        if (!l) continue;
+        const uint32_t s = lane * 5 + t;
+        const uint32_t w = (l - 1) / 3, sh = ((l - 1) % 3) * 10;
+        uint32_t rank = 0, nx = 0, of = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (w == (uint32_t)k) {
+                rank = (run[k] >> sh) & 1023u;
+                run[k] += 1u << sh;
+            }
+#pragma unroll
+        for (int q = 1; q <= 15; q++)
+            if (l == (uint32_t)q) nx = next[q], of = offs[q];
+        sorted[of + rank] = (uint16_t)s;
+        const uint32_t cd = nx + rank;
+        const uint32_t rev = __brev(cd) >> (32 - l);          // codes are packed starting from their most significant bit
+        if (l <= (uint32_t)R) {
+            const uint32_t e = DIST ? dist_entry(s, l) : lit_entry(s, l);
+            for (uint32_t i = rev; i < (1u << R); i += 1u << l) tab[i] = e;
+        }                                                     // longer codes: the first-level entry stays "slow"
+    }
+    return left > 0 ? 1 : 0;
+}
+
+// Per-lane bit reader over the staged words.  pos() = bits consumed since the start of the stage.
+struct LaneBits {
+    uint64_t buf;
+    int cnt;
+    uint32_t widx;
+    const uint32_t* stage;
+    __device__ __forceinline__ void init(const uint32_t* st, uint32_t bit) {
+        stage = st;
+        widx = bit >> 5;
+        const uint32_t w = stage[widx < (uint32_t)kStageWords ? widx : kStageWords - 1];
+        widx++;
+        buf = w >> (bit & 31);
+        cnt = 32 - (int)(bit & 31);
+        refill();
+    }
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32) {
+            const uint32_t w = stage[widx < (uint32_t)kStageWords ? widx : kStageWords - 1];
+            widx++;
+            buf |= (uint64_t)w << cnt;
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t pos() const { return widx * 32 - (uint32_t)cnt; }
+    __device__ __forceinline__ void drop(uint32_t n) {
+        buf >>= n;
+        cnt -= (int)n;
+    }
+};
+
+struct SubResult {
+    uint32_t exit;      // bit position of the first symbol this lane did NOT decode
+    uint32_t nbytes, nmatch;
+    bool eob, err;
+};
+
+// Decodes the symbols that START in [start, limit).  EMIT: literals go to the window at out_pos .., matches to the list.
+template <bool EMIT>
+__device__ SubResult decode_sub(InflateLds& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint32_t m_idx) {
+    SubResult r{start, 0, 0, false, false};
+    if (start >= limit) return r;
+    LaneBits b;
+    b.init(L.stage, start);
+    uint32_t pos = start;
+    while (pos < limit) {
+        b.refill();
+        uint32_t e = L.lit[b.buf & ((1u << kRoot) - 1)];
+        if ((e >> 24) == kSlow) e = slow_code(b.buf, L.ll_count, L.ll_sorted, false);
+        const uint32_t cl = (e >> 20) & 15u;
+        if (cl == 0) {
+            r.err = true;
+            break;
+        }
+        b.drop(cl);
+        const uint32_t kind = e >> 24;
+        if (kind == kLit) {
+            if (EMIT) L.ring[(out_pos + r.nbytes) % kRing] = (uint8_t)e;
+            r.nbytes++;
+        } else if (kind == kEob) {
+            r.eob = true;
+            pos = b.pos();
+            break;
+        } else {
+            const uint32_t ex = (e >> 16) & 15u;
+            const uint32_t len = (e & 0xffffu) + ((uint32_t)b.buf & ((1u << ex) - 1u));
+            b.drop(ex);
+            b.refill();
+            uint32_t d = L.dst[b.buf & ((1u << kDRoot) - 1)];
+            if ((d >> 24) == kSlow) d = slow_code(b.buf, L.d_count, L.d_sorted, true);
+            const uint32_t dl = (d >> 20) & 15u;
+            if (dl == 0) {
+                r.err = true;
+                break;
+            }
+            b.drop(dl);
+            const uint32_t dex = (d >> 16) & 15u;
+            const uint32_t dist = (d & 0xffffu) + ((uint32_t)b.buf & ((1u << dex) - 1u));
+            b.drop(dex);
+            if (EMIT) {
+                if (dist > out_pos + r.nbytes) r.err = true;      // reaches back before the first byte of the image
+                const uint32_t mi = m_idx + r.nmatch;
+                if (mi < kMatchCap) {
+                    L.m_dst[mi] = out_pos + r.nbytes;
+                    L.m_ld[mi] = len << 16 | (dist - 1);
+                }
+            }
+            r.nbytes += len;
+            r.nmatch++;
+        }
+        pos = b.pos();
+    }
+    r.exit = pos;
+    return r;
+}
+
+// Uniform (whole-wave) bit reader over the stage for block headers: every lane computes the same values.
+__device__ __forceinline__ uint32_t peek_u(const uint32_t* stage, uint32_t pos, uint32_t n) {
+    const uint32_t w = pos >> 5;
+    const uint64_t two = (uint64_t)stage[w] | (uint64_t)stage[w + 1] << 32;
+    return (uint32_t)(two >> (pos & 31)) & ((1u << n) - 1u);
+}
+
+// Stages kStageWords words of the stream starting at the word that holds bit `bp`; returns that word's bit offset.
+__device__ __forceinline__ uint32_t stage_load(InflateLds& L, const uint8_t* z, uint32_t zwords, uint32_t bp, int lane) {
+    const uint32_t w0 = bp >> 5;
+    const uint32_t* zw = reinterpret_cast<const uint32_t*>(z);
+    for (int i = lane; i < kStageWords; i += 64) L.stage[i] = (w0 + i < zwords) ? zw[w0 + i] : 0u;
+    wave_lds_sync();
+    return w0 << 5;
+}
+
+// Window -> frame memory for [from, to); ring index and stream position agree modulo 4.
+__device__ __forceinline__ void flush_out(InflateLds& L, uint8_t* out, uint32_t from, uint32_t to, int lane) {
+    uint32_t p = from;
+    const uint32_t head = (4 - (p & 3)) & 3;
+    if (lane < (int)head && p + lane < to) out[p + lane] = L.ring[(p + lane) % kRing];
+    p += head;
+    if (p >= to) return;
+    const uint32_t words = (to - p) >> 2;
+    for (uint32_t i = lane; i < words; i += 64)
+        *reinterpret_cast<uint32_t*>(out + p + 4 * i) = *reinterpret_cast<const uint32_t*>(&L.ring[(p + 4 * i) % kRing]);
+    p += words * 4;
+    if (lane < (int)(to - p)) out[p + lane] = L.ring[(p + lane) % kRing];
+}
+
+// Resolves the listed matches in stream order.  All literals of the round are already in the window.
+__device__ void resolve_matches(InflateLds& L, uint32_t total, int lane) {
+    for (uint32_t g0 = 0; g0 < total; g0 += 64) {
+        const uint32_t mi = g0 + lane;
+        const bool have = mi < total;
+        const uint32_t dst = have ? L.m_dst[mi] : 0, ld = have ? L.m_ld[mi] : 0;
+        const uint32_t len = ld >> 16, dist = (ld & 0xffffu) + 1;
+        uint64_t pending = __ballot(have);
+        while (pending) {
+            const int f = __builtin_ctzll(pending);
+            const uint32_t f_dst = __shfl(dst, f, 64), f_len = __shfl(len, f, 64), f_dist = __shfl(dist, f, 64);
+            if (f_len > 16 || f_dist < f_len) {
+                // a long or self-overlapping match: the whole wave copies it (byte k comes from k mod dist)
+                for (uint32_t k = lane; k < f_len; k += 64)
+                    L.ring[(f_dst + k) % kRing] = L.ring[(f_dst - f_dist + (k % f_dist)) % kRing];
+                wave_lds_sync();
+                pending &= ~(1ull << f);
+                continue;
+            }
+            // short matches whose source lies entirely below the first unresolved destination: one per lane, together
+            const bool ready = have && ((pending >> lane) & 1) && len <= 16 && dist >= len && dst - dist + len <= f_dst;
+            uint8_t tmp[16];
+            if (ready) {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if ((uint32_t)k < len) tmp[k] = L.ring[(dst - dist + k) % kRing];
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if ((uint32_t)k < len) L.ring[(dst + k) % kRing] = tmp[k];
+            }
+            wave_lds_sync();
+            pending &= ~__ballot(ready);
+        }
+    }
+}
+
+struct PngInfo {
+    uint32_t zlen;      // bytes of the gathered zlib stream
+    int32_t status;
+};
+
+__device__ __forceinline__ uint32_t be32(const uint8_t* p) {
+    return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3];
+}
+
+// One wave per file: validate, gather IDAT payloads to zbuf + align16(offsets[i]).
+__global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict__ png, const uint64_t* __restrict__ offsets,
+                                                     size_t n, uint32_t width, uint32_t height, int pixfmt,
+                                                     uint8_t* __restrict__ zbuf, PngInfo* __restrict__ info) {
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    const uint8_t* p = png + offsets[img];
+    const size_t len = (size_t)(offsets[img + 1] - offsets[img]);
+    uint8_t* z = zbuf + ((offsets[img] + 15) & ~(uint64_t)15);
+    int32_t status = 0;
+    uint32_t zn = 0;
+    if (len < 8 + 25 + 12 || p[0] != 137 || p[1] != 80 || p[2] != 78 || p[3] != 71 || p[4] != 13 || p[5] != 10 || p[6] != 26 ||
+        p[7] != 10 || be32(p + 8) != 13 || p[12] != 'I' || p[13] != 'H' || p[14] != 'D' || p[15] != 'R') {
+        status = UCFP_E_MODALITY;
+    } else {
+        const uint32_t w = be32(p + 16), h = be32(p + 20);
+        const int depth = p[24], ctype = p[25], comp = p[26], filt = p[27], lace = p[28];
+        const int fmt = ctype == 0 ? UCFP_PIX_GRAY8 : ctype == 2 ? UCFP_PIX_RGB8 : ctype == 6 ? UCFP_PIX_RGBA8 : -1;
+        if (w == 0 || h == 0 || comp != 0 || filt != 0 || lace > 1) status = UCFP_E_MODALITY;
+        else if (depth != 8 || lace != 0 || fmt < 0 || fmt != pixfmt || w != width || h != height) status = UCFP_IMAGE_NEEDS_HOST;
+    }
+    if (status == 0) {
+        size_t pos = 8 + 25;
+        bool seen_idat = false, idat_done = false, seen_end = false;
+        while (pos + 12 <= len) {
+            const uint32_t cl = be32(p + pos);
+            const uint8_t t0 = p[pos + 4], t1 = p[pos + 5], t2 = p[pos + 6], t3 = p[pos + 7];
+            if (cl > 0x7fffffffu || pos + 12 + (size_t)cl > len) {
+                status = UCFP_E_MODALITY;
+                break;
+            }
+            if (t0 == 'I' && t1 == 'D' && t2 == 'A' && t3 == 'T') {
+                if (idat_done) {
+                    status = UCFP_E_MODALITY;
+                    break;
+                }
+                seen_idat = true;
+                const uint8_t* src = p + pos + 8;
+                for (uint32_t i = lane; i < cl; i += 64) z[zn + i] = src[i];
+                zn += cl;
+            } else {
+                if (seen_idat) idat_done = true;
+                if (t0 == 'I' && t1 == 'E' && t2 == 'N' && t3 == 'D') {
+                    seen_end = true;
+                    break;
+                }
+                if (t0 == 't' && t1 == 'R' && t2 == 'N' && t3 == 'S') status = UCFP_IMAGE_NEEDS_HOST;
+                else if (!(t0 & 0x20) && !(t0 == 'P' && t1 == 'L' && t2 == 'T' && t3 == 'E')) status = UCFP_E_MODALITY;   // unknown critical chunk
+                if (status == UCFP_E_MODALITY) break;
+            }
+            pos += 12 + (size_t)cl;
+        }
+        if (status == 0 && (!seen_idat || !seen_end)) status = UCFP_E_MODALITY;
+    }
+    // zero the tail word so that a staged partial word holds no stale bytes
+    if (lane < 4) z[zn + lane] = 0;
+    if (lane == 0) info[img] = PngInfo{zn, status};
+}
+
+// One wave per image: zlib stream -> filtered scanlines (raw_n bytes expected).
+__global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets,
+                                                        size_t n, PngInfo* __restrict__ info, uint8_t* __restrict__ raw,
+                                                        size_t raw_stride, uint32_t raw_n) {
+    __shared__ InflateLds L;
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    if (info[img].status != 0) return;
+    const uint8_t* z = zbuf + ((offsets[img] + 15) & ~(uint64_t)15);
+    const uint32_t zlen = info[img].zlen;
+    const uint32_t zwords = (zlen + 3) / 4, total_bits = zlen * 8;
+    uint8_t* out = raw + img * raw_stride;
+    bool bad = zlen < 6;
+    if (!bad) {
+        const uint32_t cmf = z[0], flg = z[1];
+        bad = (cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8 | flg) % 31) != 0 || (flg & 0x20);
+    }
+    uint32_t bp = 16, outpos = 0;
+    bool last = false;
+    int B = kMaxB;
+    while (!bad && !last) {
+        uint32_t s0 = stage_load(L, z, zwords, bp, lane);
+        uint32_t rel = bp - s0;
+        last = peek_u(L.stage, rel, 1);
+        const uint32_t type = peek_u(L.stage, rel + 1, 2);
+        rel += 3;
+        if (type == 3 || bp + 3 > total_bits) {
+            bad = true;
+            break;
+        }
+        if (type == 0) {
+            // stored: to the byte boundary, LEN, NLEN, then LEN bytes through the window
+            uint32_t byte = (s0 + rel + 7) >> 3;
+            if (byte + 4 > zlen) {
+                bad = true;
+                break;
+            }
+            const uint32_t len = z[byte] | (uint32_t)z[byte + 1] << 8, nlen = z[byte + 2] | (uint32_t)z[byte + 3] << 8;
+            byte += 4;
+            if ((len ^ 0xffffu) != nlen || byte + len > zlen || outpos + len > raw_n) {
+                bad = true;
+                break;
+            }
+            for (uint32_t k = lane; k < len; k += 64) {
+                const uint8_t v = z[byte + k];
+                L.ring[(outpos + k) % kRing] = v;
+                out[outpos + k] = v;
+            }
+            wave_lds_sync();
+            outpos += len;
+            bp = (byte + len) * 8;
+            continue;
+        }
+        // ---- the block's two codes ----
+        int used = 0;
+        if (type == 1) {
+            for (int s = lane; s < 320; s += 64) L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
+            wave_lds_sync();
+            build_table<false>(L.lens, 288, L.lit, L.ll_count, L.ll_sorted, lane, &used);
+            build_table<true>(L.lens + 288, 30, L.dst, L.d_count, L.d_sorted, lane, &used);
+        } else {
+            const uint32_t nlen = peek_u(L.stage, rel, 5) + 257, ndist = peek_u(L.stage, rel + 5, 5) + 1,
+                           ncode = peek_u(L.stage, rel + 10, 4) + 4;
+            rel += 14;
+            if (nlen > 286 || ndist > 30) {
+                bad = true;
+                break;
+            }
+            // the code-length code: 19 symbols in the permuted order of 3.2.7, decoded through the distance-table slots
+            if (lane < 19) L.lens[lane] = 0;
+            wave_lds_sync();
+            if (lane < (int)ncode) {
+                const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                L.lens[order[lane]] = (uint8_t)peek_u(L.stage, rel + 3 * lane, 3);
+            }
+            rel += 3 * ncode;
+            wave_lds_sync();
+            // a 7-bit table in L.dst (entries: symbol | code length << 20)
+            {
+                for (int i = lane; i < 128; i += 64) L.dst[i] = 0;
+                const uint32_t l = lane < 19 ? L.lens[lane] : 0;
+                uint32_t cnt[8], next[8];
+                int left = 1, code = 0;
+                cnt[0] = next[0] = 0;
+#pragma unroll
+                for (int q = 1; q <= 7; q++) {
+                    cnt[q] = (uint32_t)__popcll(__ballot(l == (uint32_t)q));
+                    left = (left << 1) - (int)cnt[q];
+                    next[q] = (uint32_t)code;
+                    code = (code + (int)cnt[q]) << 1;
+                }
+                if (left != 0) {   // the code-length code must be complete
+                    bad = true;
+                    break;
+                }
+                uint32_t rank = 0, nx = 0;
+#pragma unroll
+                for (int q = 1; q <= 7; q++)
+                    if (l == (uint32_t)q) {
+                        rank = (uint32_t)__popcll(__ballot(l == (uint32_t)q) & ((1ull << lane) - 1));
+                        nx = next[q];
+                    }
+                wave_lds_sync();
+                if (l) {
+                    const uint32_t rev = __brev(nx + rank) >> (32 - l);
+                    for (uint32_t i = rev; i < 128; i += 1u << l) L.dst[i] = (uint32_t)lane | l << 20;
+                }
+                wave_lds_sync();
+            }
+            // the nlen + ndist code lengths, run-length coded (uniform: every lane walks the same bits)
+            uint32_t idx = 0, prev = 0;
+            const uint32_t want = nlen + ndist;
+            while (idx < want) {
+                if (rel + 14 > (uint32_t)(kStageWords - 2) * 32) {   // a header is at most ~4.5 kbit: cannot happen in a valid stream
+                    bad = true;
+                    break;
+                }
+                const uint32_t e = L.dst[peek_u(L.stage, rel, 7)];
+                const uint32_t cl = e >> 20, sym = e & 31u;
+                if (cl == 0) {
+                    bad = true;
+                    break;
+                }
+                rel += cl;
+                if (sym < 16) {
+                    if (lane == 0) L.lens[idx] = (uint8_t)sym;
+                    prev = sym;
+                    idx++;
+                } else {
+                    uint32_t rep, v = 0;
+                    if (sym == 16) {
+                        if (idx == 0) {
+                            bad = true;
+                            break;
+                        }
+                        v = prev;
+                        rep = 3 + peek_u(L.stage, rel, 2);
+                        rel += 2;
+                    } else if (sym == 17) {
+                        rep = 3 + peek_u(L.stage, rel, 3);
+                        rel += 3;
+                        prev = 0;
+                    } else {
+                        rep = 11 + peek_u(L.stage, rel, 7);
+                        rel += 7;
+                        prev = 0;
+                    }
+                    if (idx + rep > want) {
+                        bad = true;
+                        break;
+                    }
+                    if (lane < (int)rep) L.lens[idx + lane] = (uint8_t)v;
+                    if (lane + 64 < (int)rep) L.lens[idx + lane + 64] = (uint8_t)v;
+                    if (lane + 128 < (int)rep) L.lens[idx + lane + 128] = (uint8_t)v;
+                    idx += rep;
+                }
+            }
+            if (bad) break;
+            wave_lds_sync();
+            if (L.lens[256] == 0) {
+                bad = true;
+                break;
+            }
+            // distance lengths move to their own 32-aligned place: lens[288 ..)
+            const uint32_t dl = lane < (int)ndist ? L.lens[nlen + lane] : 0;
+            wave_lds_sync();
+            if (lane < 32) L.lens[288 + lane] = (uint8_t)dl;
+            for (int s = nlen + lane; s < 288; s += 64) L.lens[s] = 0;
+            wave_lds_sync();
+            int r = build_table<false>(L.lens, 288, L.lit, L.ll_count, L.ll_sorted, lane, &used);
+            if (r < 0 || (r > 0 && used != 1)) {
+                bad = true;
+                break;
+            }
+            r = build_table<true>(L.lens + 288, 30, L.dst, L.d_count, L.d_sorted, lane, &used);
+            if (r < 0 || (r > 0 && used > 1)) {
+                bad = true;
+                break;
+            }
+        }
+        wave_lds_sync();
+        bp = s0 + rel;
+        // ---- the block's symbols, one speculation round after the other ----
+        bool eob = false;
+        while (!eob && !bad) {
+            s0 = stage_load(L, z, zwords, bp, lane);
+            const uint32_t r0 = bp - s0;
+            uint32_t start = r0 + (uint32_t)(lane * B);
+            const uint32_t limit = r0 + (uint32_t)((lane + 1) * B);
+            bool dirty = true;
+            SubResult res{start, 0, 0, false, false};
+            int nvalid = 0;
+            for (;;) {
+                if (dirty) res = decode_sub<false>(L, start, limit, 0, 0);
+                const uint32_t prev_exit = __shfl_up(res.exit, 1, 64);
+                dirty = lane > 0 && prev_exit != start;
+                if (dirty) start = prev_exit;
+                const uint64_t dm = __ballot(dirty);
+                const int f = dm ? __builtin_ctzll(dm) : 64;                 // lanes below f continue lane 0's parse
+                const uint64_t stop = __ballot(res.eob || res.err) & (f == 64 ? ~0ull : ((1ull << f) - 1));
+                if (stop) {
+                    nvalid = __builtin_ctzll(stop) + 1;
+                    break;
+                }
+                if (f == 64) {
+                    nvalid = 64;
+                    break;
+                }
+            }
+            // how many of the confirmed lanes fit this round's window and match list
+            const bool in = lane < nvalid;
+            const uint32_t cb = wave_incl_scan(in ? res.nbytes : 0, lane), cm = wave_incl_scan(in ? res.nmatch : 0, lane);
+            const bool fits = in && cb <= kIterOut && cm <= kMatchCap && outpos + cb <= raw_n;
+            const int take = __popcll(__ballot(fits));                        // a prefix: the sums are monotonic
+            if (take == 0) {
+                const uint32_t b0 = __shfl(res.nbytes, 0, 64);
+                if (outpos + b0 > raw_n || B <= 8) {                          // more output than the image has rows for
+                    bad = true;
+                    break;
+                }
+                B = B / 4 < 8 ? 8 : B / 4;                                    // extremely dense matches: shorter subsequences
+                continue;
+            }
+            const uint32_t my_out = outpos + cb - res.nbytes, my_m = cm - res.nmatch;
+            bool far = false;
+            if (lane < take) far = decode_sub<true>(L, start, limit, my_out, my_m).err && !res.err;
+            wave_lds_sync();
+            if (__ballot(far)) {
+                bad = true;
+                break;
+            }
+            const uint32_t add = __shfl(cb, take - 1, 64), nm = __shfl(cm, take - 1, 64);
+            resolve_matches(L, nm, lane);
+            flush_out(L, out, outpos, outpos + add, lane);
+            outpos += add;
+            const bool t_eob = __shfl((int)res.eob, take - 1, 64), t_err = __shfl((int)res.err, take - 1, 64);
+            bp = s0 + __shfl(res.exit, take - 1, 64);
+            if (t_err || bp > total_bits) bad = true;
+            eob = t_eob;
+            if (take == 64 && add < kIterOut / 4 && B < kMaxB) B *= 2;
+        }
+    }
+    if (!bad && outpos != raw_n) bad = true;
+    if (bad && lane == 0) info[img].status = UCFP_E_MODALITY;
+}
+
+// One wave per image: PNG 9.2 reconstruction.  Lane j takes rows j, j + 64, ...; it works one pixel behind lane j - 1
+// (lane 0 one pixel behind lane 63's previous row, kept in LDS), so the pixel above is the neighbour's last output.
+template <int BPP>
+__global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restrict__ raw, size_t raw_stride,
+                                                         PngInfo* __restrict__ info, size_t n, uint32_t w, uint32_t h,
+                                                         uint8_t* __restrict__ frames, size_t row_stride, size_t frame_stride,
+                                                         int32_t* __restrict__ status) {
+    extern __shared__ uint8_t uprow[];      // w * BPP bytes: the last row lane 63 finished
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    const int32_t st = info[img].status;
+    if (st != 0) {
+        if (lane == 0 && status) status[img] = st;
+        return;
+    }
+    const uint8_t* src = raw + img * raw_stride;
+    uint8_t* dst = frames + img * frame_stride;
+    const uint32_t rowb = w * BPP;
+    const uint32_t W = w > 64 ? w : 64;                       // steps per row: lane 63 must be done with x before lane 0 needs it
+    const uint32_t rounds = (h + 63) / 64;
+    const uint32_t steps = rounds * W + 64;
+    bool bad = false;
+    uint32_t a[BPP], b[BPP], c[BPP], prev_out[BPP];            // left, above, above-left, this lane's last output
+#pragma unroll
+    for (int ch = 0; ch < BPP; ch++) a[ch] = b[ch] = c[ch] = prev_out[ch] = 0;
+    uint32_t ft = 0;
+    for (uint32_t t = 0; t < steps; t++) {
+        // what the lane above produced in the previous step (lane 0: lane 63's stored row)
+        uint32_t up[BPP];
+#pragma unroll
+        for (int ch = 0; ch < BPP; ch++) up[ch] = __shfl_up(prev_out[ch], 1, 64);
+        const int tt = (int)t - lane;
+        const bool live = tt >= 0;
+        const uint32_t k = live ? (uint32_t)tt / W : 0, x = live ? (uint32_t)tt % W : 0;
+        const uint32_t row = k * 64 + lane;
+        const bool on = live && row < h && x < w;
+        if (on) {
+            const uint8_t* sp = src + (size_t)row * (rowb + 1);
+            if (x == 0) {
+                ft = sp[0];
+                if (ft > 4) bad = true;
+#pragma unroll
+                for (int ch = 0; ch < BPP; ch++) a[ch] = c[ch] = 0;
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < BPP; ch++) c[ch] = b[ch];
+            }
+#pragma unroll
+            for (int ch = 0; ch < BPP; ch++) {
+                if (row == 0) b[ch] = 0;
+                else if (lane == 0) b[ch] = uprow[x * BPP + ch];
+                else b[ch] = up[ch];
+            }
+            uint32_t o[BPP];
+#pragma unroll
+            for (int ch = 0; ch < BPP; ch++) {
+                const int v = sp[1 + x * BPP + ch];
+                const int A = (int)a[ch], Bv = (int)b[ch], C = (int)c[ch];
+                int pred = 0;
+                if (ft == 1) pred = A;
+                else if (ft == 2) pred = Bv;
+                else if (ft == 3) pred = (A + Bv) >> 1;
+                else if (ft == 4) {
+                    const int p = A + Bv - C;
+                    const int pa = p > A ? p - A : A - p, pb = p > Bv ? p - Bv : Bv - p, pc = p > C ? p - C : C - p;
+                    pred = (pa <= pb && pa <= pc) ? A : (pb <= pc ? Bv : C);
+                }
+                o[ch] = (uint32_t)(v + pred) & 255u;
+            }
+            uint8_t* dp = dst + (size_t)row * row_stride + (size_t)x * BPP;
+#pragma unroll
+            for (int ch = 0; ch < BPP; ch++) {
+                dp[ch] = (uint8_t)o[ch];
+                a[ch] = prev_out[ch] = o[ch];
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int ch = 0; ch < BPP; ch++) uprow[x * BPP + ch] = (uint8_t)o[ch];
+            }
+        }
+        wave_lds_fence();
+    }
+    const bool any_bad = __ballot(bad) != 0;
+    if (lane == 0) {
+        if (any_bad) info[img].status = UCFP_E_MODALITY;
+        if (status) status[img] = any_bad ? UCFP_E_MODALITY : 0;
+    }
+}
+
+// Records of files that did not decode are zeroed and carry the decoder's status.
+__global__ void png_merge_status_kernel(const PngInfo* __restrict__ info, size_t n, uint8_t* __restrict__ out, uint32_t rec,
+                                        int32_t* __restrict__ status) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x / 64 + threadIdx.x / 64;
+    if (i >= n) return;
+    const int32_t st = info[i].status;
+    if (st == 0) return;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t b = lane * 4; b < rec; b += 256) *reinterpret_cast<uint32_t*>(out + i * rec + b) = 0;
+    if (lane == 0 && status) status[i] = st;
+}
+
+}  // namespace
+
+int launch_png_merge_status(const uint8_t* ws, const PngWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
+                            hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(png_merge_status_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
+                       reinterpret_cast<const PngInfo*>(ws + l.info), n, out, rec, status);
+    return 0;
+}
+
+size_t png_ws_bytes(size_t n, size_t png_bytes, uint32_t w, uint32_t h, int pixfmt, PngWs* ws) {
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    const size_t raw_n = (size_t)h * ((size_t)w * bpp + 1);
+    PngWs l;
+    l.raw_n = raw_n;
+    l.raw_stride = (raw_n + 15 + 64) & ~(size_t)15;
+    size_t off = 0;
+    l.zbuf = off;
+    off += (png_bytes + 16 + 64 + 255) & ~(size_t)255;
+    l.info = off;
+    off += (n * sizeof(PngInfo) + 255) & ~(size_t)255;
+    l.raw = off;
+    off += n * l.raw_stride;
+    l.total = off;
+    if (ws) *ws = l;
+    return off;
+}
+
+int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, int pixfmt, uint8_t* ws,
+                      const PngWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
+                      hipStream_t stream) {
+    if (n == 0) return 0;
+    PngInfo* info = reinterpret_cast<PngInfo*>(ws + l.info);
+    hipLaunchKernelGGL(png_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, png, offsets, n, w, h, pixfmt, ws + l.zbuf, info);
+    hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info, ws + l.raw,
+                       l.raw_stride, (uint32_t)l.raw_n);
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    const size_t lds = (size_t)w * bpp;
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, stream, ws + l.raw, l.raw_stride, info, n, w, h, frames,
+                           row_stride, frame_stride, status);
+    };
+    if (bpp == 1) go(png_unfilter_kernel<1>);
+    else if (bpp == 3) go(png_unfilter_kernel<3>);
+    else go(png_unfilter_kernel<4>);
+    return 0;
+}
+
+}  // namespace ucfp

@@ -113,6 +113,80 @@ def fingerprint_frames(frames: np.ndarray, *, algo: int = MULTI, pixfmt: int = P
 
 
 # ------------------------------------------------------------------------------------------
+# encoded PNG files in: chunk walk, inflate and filter reconstruction on the GPU
+# ------------------------------------------------------------------------------------------
+NEEDS_HOST = 1
+
+
+def png_probe(data: bytes):
+    """IHDR of a PNG -> (status, width, height, pixfmt); status 0, NEEDS_HOST (a kind the device decoder hands back)
+    or a negative UCFP_E_* (not a PNG)."""
+    w, h, fmt = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+    rc = _lib.load().ucfp_png_probe(data, len(data), C.byref(w), C.byref(h), C.byref(fmt))
+    return int(rc), int(w.value), int(h.value), int(fmt.value)
+
+
+def _upload_pngs(pngs: Sequence[bytes], dev):
+    import torch
+    offs = np.zeros(len(pngs) + 1, np.int64)
+    np.cumsum([len(p) for p in pngs], out=offs[1:])
+    blob = np.frombuffer(b"".join(pngs) + b"\0" * 16, np.uint8)
+    return torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offs).to(dev), int(offs[-1])
+
+
+def decode_pngs(pngs: Sequence[bytes], width: int, height: int, pixfmt: int, ctx=None):
+    """Decode a batch of PNG files announced as width x height, `pixfmt` on the GPU.
+    -> (frames uint8 [n, h, w(, c)], status int32 [n]); frames of files with status != 0 are undefined."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    dev = f"cuda:{ctx.device}"
+    n, bpp = len(pngs), _BPP[pixfmt]
+    d_blob, d_off, total = _upload_pngs(pngs, dev)
+    shape = (n, height, width) if bpp == 1 else (n, height, width, bpp)
+    d_fr = torch.zeros(shape, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().ucfp_image_png_decode_batch_dev(
+        ctx.handle, d_blob.data_ptr(), d_off.data_ptr(), n, total, width, height, pixfmt, d_fr.data_ptr(), width * bpp,
+        width * bpp * height, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream or None))
+    return d_fr.cpu().numpy(), d_st[:n].cpu().numpy()
+
+
+def fingerprint_pngs_dev(png_ptr: int, offsets_ptr: int, n: int, png_bytes: int, width: int, height: int, pixfmt: int, *,
+                         algo: int = MULTI, exact_ptr: int = 0, out_ptr: int, status_ptr: int = 0, stream: int = 0,
+                         preprocess: Optional[PreprocessConfig] = None, ctx=None) -> None:
+    """Device-resident encoded files -> records; raw device addresses, no sync (ucfp_image_png_hash_batch_dev)."""
+    ctx = ctx or _lib.current_context()
+    pre = (preprocess or PreprocessConfig())._c()
+    _lib.check(_lib.load().ucfp_image_png_hash_batch_dev(
+        ctx.handle, algo, png_ptr, offsets_ptr, n, png_bytes, width, height, pixfmt, C.byref(pre), exact_ptr or None,
+        out_ptr, status_ptr or None, stream or None))
+
+
+def fingerprint_pngs(pngs: Sequence[bytes], width: int, height: int, pixfmt: int, *, algo: int = MULTI,
+                     exact: Optional[np.ndarray] = None, preprocess: Optional[PreprocessConfig] = None, ctx=None):
+    """Host convenience: encoded files -> (records uint8 [n, record_bytes], status int32 [n])."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    dev = f"cuda:{ctx.device}"
+    n = len(pngs)
+    rec = record_bytes(algo)
+    d_blob, d_off, total = _upload_pngs(pngs, dev)
+    d_out = torch.zeros((max(n, 1), rec), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    d_ex = None
+    if exact is not None:
+        ex = np.ascontiguousarray(exact, dtype=np.uint8)
+        if ex.shape != (n, 32):
+            raise ModalityError("exact must be [n, 32] bytes")
+        d_ex = torch.from_numpy(ex).to(dev)
+    fingerprint_pngs_dev(d_blob.data_ptr(), d_off.data_ptr(), n, total, width, height, pixfmt, algo=algo,
+                         exact_ptr=d_ex.data_ptr() if d_ex is not None else 0, out_ptr=d_out.data_ptr(),
+                         status_ptr=d_st.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                         preprocess=preprocess, ctx=ctx)
+    return d_out[:n].cpu().numpy(), d_st[:n].cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------
 # per-request adapters (encoded bytes in, Record out) -- the reference's call shape
 # ------------------------------------------------------------------------------------------
 

@@ -11,8 +11,9 @@
 //                 codes self-synchronise: after a few symbols a wrong parse falls into step with the right one, so
 //                 lane j's exit position is usually right even though its start was not.  Lane j+1 restarts from lane
 //                 j's exit until the chain of (start == predecessor's exit) reaches from lane 0 (whose start is known)
-//                 to the end -- by construction the accepted parse IS the sequential one.  Then every lane decodes its
-//                 subsequence once more into the LDS window (literals directly; matches are listed and resolved in
+//                 to the end -- by construction the accepted parse IS the sequential one.  A lane remembers the parses
+//                 it has made (the candidate starts are few), so later rounds are lookups.  Then every lane decodes its
+//                 subsequence once more into the round buffer (literals directly; matches are listed and resolved in
 //                 stream order, 64 at a time where they do not depend on each other).
 //   png_unfilter  PNG 9.2 filters.  Average and Paeth chain along the row AND need the row above: lane j takes row
 //                 64 k + j one pixel behind lane j-1, so "above" and "above-left" are the neighbour lane's last two
@@ -34,8 +35,7 @@ namespace {
 
 constexpr int kRoot = 10, kDRoot = 8;                  // bits indexed by the first-level tables
 constexpr uint32_t kIterOut = 4096;                    // output bytes one speculation round may add
-constexpr uint32_t kRing = 32768 + kIterOut + 64;      // LDS window: the 32 KiB deflate history + one round (multiple of 4)
-constexpr uint32_t kMatchCap = 512;                    // matches listed per round
+constexpr uint32_t kMatchCap = 1024;                   // matches listed per round
 constexpr int kStageWords = 288;                       // compressed words staged per round: 64 x 128 bits + overshoot + refill
 constexpr int kMaxB = 128;                             // bits per subsequence
 
@@ -43,18 +43,21 @@ constexpr int kMaxB = 128;                             // bits per subsequence
 constexpr uint32_t kLit = 0, kLen = 1, kEob = 2, kSlow = 3;
 constexpr uint32_t kInvalid = kSlow << 24;             // code length 0: resolved (or rejected) by the canonical slow path
 
+// The deflate window is the image itself: bytes of earlier rounds are read back from frame memory (this wave wrote
+// them; a workgroup-scope fence orders the stores before the loads), only the round in flight lives in LDS.  ~15 KiB
+// per wave instead of 48: ten waves per CU hide each other's LDS latency.
 struct InflateLds {
     uint32_t lit[1 << kRoot];
     uint32_t dst[1 << kDRoot];
     uint32_t stage[kStageWords];
     uint32_t m_dst[kMatchCap];
-    uint32_t m_ld[kMatchCap];                          // len | dist << 16 ... dist up to 32768 needs 16 bits: len << 16 | (dist - 1)
+    uint32_t m_ld[kMatchCap];                          // len << 16 | (dist - 1)
     uint16_t ll_sorted[288];
     uint16_t d_sorted[32];
     uint16_t ll_count[16];
     uint16_t d_count[16];
     uint8_t lens[320];
-    uint8_t ring[kRing];
+    uint8_t rb[kIterOut + 8];                          // this round's output; rb[0] is stream position (outpos & ~3)
 };
 
 __device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t len) {
@@ -176,100 +179,113 @@ __device__ int build_table(const uint8_t* lens, int n, uint32_t* tab, uint16_t* 
     return left > 0 ? 1 : 0;
 }
 
-// Per-lane bit reader over the staged words.  pos() = bits consumed since the start of the stage.
-struct LaneBits {
-    uint64_t buf;
-    int cnt;
-    uint32_t widx;
-    const uint32_t* stage;
-    __device__ __forceinline__ void init(const uint32_t* st, uint32_t bit) {
-        stage = st;
-        widx = bit >> 5;
-        const uint32_t w = stage[widx < (uint32_t)kStageWords ? widx : kStageWords - 1];
-        widx++;
-        buf = w >> (bit & 31);
-        cnt = 32 - (int)(bit & 31);
-        refill();
-    }
-    __device__ __forceinline__ void refill() {
-        if (cnt <= 32) {
-            const uint32_t w = stage[widx < (uint32_t)kStageWords ? widx : kStageWords - 1];
-            widx++;
-            buf |= (uint64_t)w << cnt;
-            cnt += 32;
-        }
-    }
-    __device__ __forceinline__ uint32_t pos() const { return widx * 32 - (uint32_t)cnt; }
-    __device__ __forceinline__ void drop(uint32_t n) {
-        buf >>= n;
-        cnt -= (int)n;
-    }
+// 32 bits of the staged stream from bit `pos` on: two adjacent words and one funnel shift.  A lane's only decoder state
+// is its bit position -- every VALU instruction of a 64-wide wave costs four cycles, so the symbol loop is written for
+// instruction count: no bit buffer to maintain, the bits are fetched again where they are needed.
+__device__ __forceinline__ uint32_t bits32(const uint32_t* stage, uint32_t pos) {
+    const uint32_t w = pos >> 5;
+    return __builtin_amdgcn_alignbit(stage[w + 1], stage[w], pos & 31);
+}
+
+// Canonical decode for the rare code longer than the first-level table (and the verdict on invalid prefixes).
+__device__ __noinline__ uint32_t slow_code32(uint32_t x, const uint16_t* count, const uint16_t* sorted, bool dist) {
+    return slow_code(x, count, sorted, dist);
+}
+
+// A lane's parse of its subsequence: the symbols that START in [start, limit).
+struct Parse {
+    uint32_t start, exit;     // exit: bit position of the first symbol this lane did NOT decode
+    uint32_t packed;          // bytes produced | matches << 16 | end-of-block << 30 | invalid code << 31
+    __device__ __forceinline__ uint32_t nbytes() const { return packed & 0xffffu; }
+    __device__ __forceinline__ uint32_t nmatch() const { return (packed >> 16) & 0x3fffu; }
+    __device__ __forceinline__ bool eob() const { return (packed >> 30) & 1u; }
+    __device__ __forceinline__ bool err() const { return packed >> 31; }
+    __device__ __forceinline__ bool stopped() const { return packed >> 30; }
 };
 
-struct SubResult {
-    uint32_t exit;      // bit position of the first symbol this lane did NOT decode
-    uint32_t nbytes, nmatch;
-    bool eob, err;
-};
-
-// Decodes the symbols that START in [start, limit).  EMIT: literals go to the window at out_pos .., matches to the list.
+// EMIT = false: count.  EMIT = true: literals into the round buffer (rb_base = stream position of L.rb[0]), matches onto
+// the list; the err flag of the result then also reports a match that reaches back before the first byte of the image.
 template <bool EMIT>
-__device__ SubResult decode_sub(InflateLds& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint32_t m_idx) {
-    SubResult r{start, 0, 0, false, false};
-    if (start >= limit) return r;
-    LaneBits b;
-    b.init(L.stage, start);
-    uint32_t pos = start;
+__device__ __forceinline__ Parse parse_sub(InflateLds& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint32_t rb_base,
+                                           uint32_t m_idx) {
+    uint32_t pos = start, nb = 0, nm = 0, flags = 0;
     while (pos < limit) {
-        b.refill();
-        uint32_t e = L.lit[b.buf & ((1u << kRoot) - 1)];
-        if ((e >> 24) == kSlow) e = slow_code(b.buf, L.ll_count, L.ll_sorted, false);
+        const uint32_t x = bits32(L.stage, pos);
+        uint32_t e = L.lit[x & ((1u << kRoot) - 1)];
+        if ((e >> 24) == kSlow) e = slow_code32(x, L.ll_count, L.ll_sorted, false);
         const uint32_t cl = (e >> 20) & 15u;
         if (cl == 0) {
-            r.err = true;
+            flags = 2u;
             break;
         }
-        b.drop(cl);
         const uint32_t kind = e >> 24;
         if (kind == kLit) {
-            if (EMIT) L.ring[(out_pos + r.nbytes) % kRing] = (uint8_t)e;
-            r.nbytes++;
-        } else if (kind == kEob) {
-            r.eob = true;
-            pos = b.pos();
-            break;
-        } else {
-            const uint32_t ex = (e >> 16) & 15u;
-            const uint32_t len = (e & 0xffffu) + ((uint32_t)b.buf & ((1u << ex) - 1u));
-            b.drop(ex);
-            b.refill();
-            uint32_t d = L.dst[b.buf & ((1u << kDRoot) - 1)];
-            if ((d >> 24) == kSlow) d = slow_code(b.buf, L.d_count, L.d_sorted, true);
-            const uint32_t dl = (d >> 20) & 15u;
-            if (dl == 0) {
-                r.err = true;
-                break;
-            }
-            b.drop(dl);
-            const uint32_t dex = (d >> 16) & 15u;
-            const uint32_t dist = (d & 0xffffu) + ((uint32_t)b.buf & ((1u << dex) - 1u));
-            b.drop(dex);
-            if (EMIT) {
-                if (dist > out_pos + r.nbytes) r.err = true;      // reaches back before the first byte of the image
-                const uint32_t mi = m_idx + r.nmatch;
-                if (mi < kMatchCap) {
-                    L.m_dst[mi] = out_pos + r.nbytes;
-                    L.m_ld[mi] = len << 16 | (dist - 1);
-                }
-            }
-            r.nbytes += len;
-            r.nmatch++;
+            if (EMIT) L.rb[out_pos + nb - rb_base] = (uint8_t)e;
+            pos += cl;
+            nb++;
+            continue;
         }
-        pos = b.pos();
+        if (kind == kEob) {
+            pos += cl;
+            flags = 1u;
+            break;
+        }
+        const uint32_t ex = (e >> 16) & 15u;
+        const uint32_t len = (e & 0xffffu) + ((x >> cl) & ((1u << ex) - 1u));
+        const uint32_t p2 = pos + cl + ex;
+        const uint32_t y = bits32(L.stage, p2);
+        uint32_t d = L.dst[y & ((1u << kDRoot) - 1)];
+        if ((d >> 24) == kSlow) d = slow_code32(y, L.d_count, L.d_sorted, true);
+        const uint32_t dl = (d >> 20) & 15u;
+        if (dl == 0) {
+            flags = 2u;
+            break;
+        }
+        const uint32_t dex = (d >> 16) & 15u;
+        const uint32_t dist = (d & 0xffffu) + ((y >> dl) & ((1u << dex) - 1u));
+        if (EMIT) {
+            if (dist > out_pos + nb) flags |= 2u;
+            const uint32_t mi = m_idx + nm;
+            if (mi < kMatchCap) {
+                L.m_dst[mi] = out_pos + nb;
+                L.m_ld[mi] = len << 16 | (dist - 1);
+            }
+        }
+        pos = p2 + dl + dex;
+        nb += len;
+        nm++;
     }
-    r.exit = pos;
-    return r;
+    return Parse{start, pos, nb | nm << 16 | flags << 30};
 }
+
+// The parses a lane has already made in this round, by start position: the candidates for a lane's start are few (wrong
+// parses fall into step with one another too), so after two or three passes the chain resolves by lookup alone.
+struct ParseCache {
+    static constexpr int kWays = 4;
+    Parse way[kWays];
+    int next;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < kWays; i++) way[i] = Parse{0xffffffffu, 0, 0};
+        next = 0;
+    }
+    __device__ __forceinline__ bool find(uint32_t start, Parse* out) const {
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < kWays; i++)
+            if (way[i].start == start) {
+                *out = way[i];
+                hit = true;
+            }
+        return hit;
+    }
+    __device__ __forceinline__ void put(const Parse& p) {
+#pragma unroll
+        for (int i = 0; i < kWays; i++)
+            if (next == i) way[i] = p;
+        next = (next + 1) & (kWays - 1);
+    }
+};
 
 // Uniform (whole-wave) bit reader over the stage for block headers: every lane computes the same values.
 __device__ __forceinline__ uint32_t peek_u(const uint32_t* stage, uint32_t pos, uint32_t n) {
@@ -287,22 +303,28 @@ __device__ __forceinline__ uint32_t stage_load(InflateLds& L, const uint8_t* z, 
     return w0 << 5;
 }
 
-// Window -> frame memory for [from, to); ring index and stream position agree modulo 4.
-__device__ __forceinline__ void flush_out(InflateLds& L, uint8_t* out, uint32_t from, uint32_t to, int lane) {
+// Round buffer -> frame memory for [from, to); rb[0] is position (from & ~3), so whole words line up.
+__device__ __forceinline__ void flush_out(const InflateLds& L, uint8_t* out, uint32_t from, uint32_t to, int lane) {
+    const uint32_t base = from & ~3u;
     uint32_t p = from;
     const uint32_t head = (4 - (p & 3)) & 3;
-    if (lane < (int)head && p + lane < to) out[p + lane] = L.ring[(p + lane) % kRing];
+    if (lane < (int)head && p + lane < to) out[p + lane] = L.rb[p + lane - base];
     p += head;
     if (p >= to) return;
     const uint32_t words = (to - p) >> 2;
     for (uint32_t i = lane; i < words; i += 64)
-        *reinterpret_cast<uint32_t*>(out + p + 4 * i) = *reinterpret_cast<const uint32_t*>(&L.ring[(p + 4 * i) % kRing]);
+        *reinterpret_cast<uint32_t*>(out + p + 4 * i) = *reinterpret_cast<const uint32_t*>(&L.rb[p + 4 * i - base]);
     p += words * 4;
-    if (lane < (int)(to - p)) out[p + lane] = L.ring[(p + lane) % kRing];
+    if (lane < (int)(to - p)) out[p + lane] = L.rb[p + lane - base];
 }
 
-// Resolves the listed matches in stream order.  All literals of the round are already in the window.
-__device__ void resolve_matches(InflateLds& L, uint32_t total, int lane) {
+// A byte of the stream: from this round's buffer, or -- written by an earlier round -- from frame memory.
+__device__ __forceinline__ uint8_t window_byte(const InflateLds& L, const uint8_t* out, uint32_t p, uint32_t outpos, uint32_t rb_base) {
+    return p >= outpos ? L.rb[p - rb_base] : out[p];
+}
+
+// Resolves the listed matches in stream order.  All literals of the round are already in the round buffer.
+__device__ void resolve_matches(InflateLds& L, const uint8_t* out, uint32_t outpos, uint32_t rb_base, uint32_t total, int lane) {
     for (uint32_t g0 = 0; g0 < total; g0 += 64) {
         const uint32_t mi = g0 + lane;
         const bool have = mi < total;
@@ -312,25 +334,23 @@ __device__ void resolve_matches(InflateLds& L, uint32_t total, int lane) {
         while (pending) {
             const int f = __builtin_ctzll(pending);
             const uint32_t f_dst = __shfl(dst, f, 64), f_len = __shfl(len, f, 64), f_dist = __shfl(dist, f, 64);
-            if (f_len > 16 || f_dist < f_len) {
+            if (f_len > 8 || f_dist < f_len) {
                 // a long or self-overlapping match: the whole wave copies it (byte k comes from k mod dist)
-                for (uint32_t k = lane; k < f_len; k += 64)
-                    L.ring[(f_dst + k) % kRing] = L.ring[(f_dst - f_dist + (k % f_dist)) % kRing];
+                for (uint32_t k0 = 0; k0 < f_len; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    uint8_t v = 0;
+                    if (k < f_len) v = window_byte(L, out, f_dst - f_dist + (k % f_dist), outpos, rb_base);
+                    if (k < f_len) L.rb[f_dst + k - rb_base] = v;
+                }
                 wave_lds_sync();
                 pending &= ~(1ull << f);
                 continue;
             }
             // short matches whose source lies entirely below the first unresolved destination: one per lane, together
-            const bool ready = have && ((pending >> lane) & 1) && len <= 16 && dist >= len && dst - dist + len <= f_dst;
-            uint8_t tmp[16];
-            if (ready) {
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    if ((uint32_t)k < len) tmp[k] = L.ring[(dst - dist + k) % kRing];
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    if ((uint32_t)k < len) L.ring[(dst + k) % kRing] = tmp[k];
-            }
+            // (sources and destinations of the ready lanes cannot overlap, so bytes are copied in place)
+            const bool ready = ((pending >> lane) & 1) && len <= 8 && dist >= len && dst - dist + len <= f_dst;
+            for (uint32_t k = 0; __ballot(ready && k < len); k++)
+                if (ready && k < len) L.rb[dst + k - rb_base] = window_byte(L, out, dst - dist + k, outpos, rb_base);
             wave_lds_sync();
             pending &= ~__ballot(ready);
         }
@@ -406,6 +426,21 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
     if (lane == 0) info[img] = PngInfo{zn, status};
 }
 
+#ifdef PNG_PROF
+__device__ unsigned long long g_png_prof[16];
+#define PROF_T0() long long _t = clock64()
+#define PROF_ADD(slot) do { const long long _n = clock64(); _acc[slot] += (unsigned long long)(_n - _t); _t = _n; } while (0)
+#define PROF_CNT(slot, v) (_acc[slot] += (unsigned long long)(v))
+#else
+#define PROF_T0()
+#define PROF_ADD(slot)
+#define PROF_CNT(slot, v)
+#endif
+#ifdef PNG_DEBUG
+#define PNG_BAD(code) (bad = true, (lane == 0 ? printf("png img %d bad %d bp %u outpos %u B %d\n", (int)img, code, bp, outpos, B) : 0))
+#else
+#define PNG_BAD(code) (bad = true)
+#endif
 // One wave per image: zlib stream -> filtered scanlines (raw_n bytes expected).
 __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets,
                                                         size_t n, PngInfo* __restrict__ info, uint8_t* __restrict__ raw,
@@ -427,6 +462,10 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
     uint32_t bp = 16, outpos = 0;
     bool last = false;
     int B = kMaxB;
+#ifdef PNG_PROF
+    unsigned long long _acc[16] = {0};
+#endif
+    PROF_T0();
     while (!bad && !last) {
         uint32_t s0 = stage_load(L, z, zwords, bp, lane);
         uint32_t rel = bp - s0;
@@ -434,28 +473,24 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
         const uint32_t type = peek_u(L.stage, rel + 1, 2);
         rel += 3;
         if (type == 3 || bp + 3 > total_bits) {
-            bad = true;
+            PNG_BAD(1);
             break;
         }
         if (type == 0) {
             // stored: to the byte boundary, LEN, NLEN, then LEN bytes through the window
             uint32_t byte = (s0 + rel + 7) >> 3;
             if (byte + 4 > zlen) {
-                bad = true;
+                PNG_BAD(2);
                 break;
             }
             const uint32_t len = z[byte] | (uint32_t)z[byte + 1] << 8, nlen = z[byte + 2] | (uint32_t)z[byte + 3] << 8;
             byte += 4;
             if ((len ^ 0xffffu) != nlen || byte + len > zlen || outpos + len > raw_n) {
-                bad = true;
+                PNG_BAD(3);
                 break;
             }
-            for (uint32_t k = lane; k < len; k += 64) {
-                const uint8_t v = z[byte + k];
-                L.ring[(outpos + k) % kRing] = v;
-                out[outpos + k] = v;
-            }
-            wave_lds_sync();
+            for (uint32_t k = lane; k < len; k += 64) out[outpos + k] = z[byte + k];
+            __threadfence_block();
             outpos += len;
             bp = (byte + len) * 8;
             continue;
@@ -472,7 +507,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                            ncode = peek_u(L.stage, rel + 10, 4) + 4;
             rel += 14;
             if (nlen > 286 || ndist > 30) {
-                bad = true;
+                PNG_BAD(4);
                 break;
             }
             // the code-length code: 19 symbols in the permuted order of 3.2.7, decoded through the distance-table slots
@@ -499,7 +534,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                     code = (code + (int)cnt[q]) << 1;
                 }
                 if (left != 0) {   // the code-length code must be complete
-                    bad = true;
+                    PNG_BAD(5);
                     break;
                 }
                 uint32_t rank = 0, nx = 0;
@@ -521,13 +556,13 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             const uint32_t want = nlen + ndist;
             while (idx < want) {
                 if (rel + 14 > (uint32_t)(kStageWords - 2) * 32) {   // a header is at most ~4.5 kbit: cannot happen in a valid stream
-                    bad = true;
+                    PNG_BAD(6);
                     break;
                 }
                 const uint32_t e = L.dst[peek_u(L.stage, rel, 7)];
                 const uint32_t cl = e >> 20, sym = e & 31u;
                 if (cl == 0) {
-                    bad = true;
+                    PNG_BAD(7);
                     break;
                 }
                 rel += cl;
@@ -539,7 +574,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                     uint32_t rep, v = 0;
                     if (sym == 16) {
                         if (idx == 0) {
-                            bad = true;
+                            PNG_BAD(8);
                             break;
                         }
                         v = prev;
@@ -555,7 +590,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                         prev = 0;
                     }
                     if (idx + rep > want) {
-                        bad = true;
+                        PNG_BAD(9);
                         break;
                     }
                     if (lane < (int)rep) L.lens[idx + lane] = (uint8_t)v;
@@ -567,7 +602,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             if (bad) break;
             wave_lds_sync();
             if (L.lens[256] == 0) {
-                bad = true;
+                PNG_BAD(10);
                 break;
             }
             // distance lengths move to their own 32-aligned place: lens[288 ..)
@@ -578,35 +613,51 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             wave_lds_sync();
             int r = build_table<false>(L.lens, 288, L.lit, L.ll_count, L.ll_sorted, lane, &used);
             if (r < 0 || (r > 0 && used != 1)) {
-                bad = true;
+                PNG_BAD(11);
                 break;
             }
             r = build_table<true>(L.lens + 288, 30, L.dst, L.d_count, L.d_sorted, lane, &used);
             if (r < 0 || (r > 0 && used > 1)) {
-                bad = true;
+                PNG_BAD(12);
                 break;
             }
         }
         wave_lds_sync();
         bp = s0 + rel;
+        PROF_ADD(0);      // block header + tables
+        PROF_CNT(8, 1);
         // ---- the block's symbols, one speculation round after the other ----
         bool eob = false;
         while (!eob && !bad) {
             s0 = stage_load(L, z, zwords, bp, lane);
             const uint32_t r0 = bp - s0;
-            uint32_t start = r0 + (uint32_t)(lane * B);
-            const uint32_t limit = r0 + (uint32_t)((lane + 1) * B);
-            bool dirty = true;
-            SubResult res{start, 0, 0, false, false};
+            const uint32_t vbase = r0 + (uint32_t)(lane * B), limit = vbase + (uint32_t)B;
+            ParseCache cache;
+            cache.clear();
+            Parse P{vbase, vbase, 0};
+            uint32_t start = vbase;
             int nvalid = 0;
+            PROF_ADD(1);  // stage
+            PROF_CNT(9, 1);
             for (;;) {
-                if (dirty) res = decode_sub<false>(L, start, limit, 0, 0);
-                const uint32_t prev_exit = __shfl_up(res.exit, 1, 64);
-                dirty = lane > 0 && prev_exit != start;
+                // the lane before stopped short of its limit (an end-of-block or an invalid code, real or in a parse
+                // from a wrong start): nothing to continue here
+                const bool skip = start < vbase;
+                bool miss = !skip && !cache.find(start, &P);
+                if (skip) P = Parse{start, start, 2u << 30};
+                if (__ballot(miss)) {
+                    PROF_CNT(10, 1);
+                    if (miss) {
+                        P = parse_sub<false>(L, start, limit, 0, 0, 0);
+                        cache.put(P);
+                    }
+                }
+                const uint32_t prev_exit = __shfl_up(P.exit, 1, 64);
+                const bool dirty = lane > 0 && prev_exit != P.start;
                 if (dirty) start = prev_exit;
                 const uint64_t dm = __ballot(dirty);
                 const int f = dm ? __builtin_ctzll(dm) : 64;                 // lanes below f continue lane 0's parse
-                const uint64_t stop = __ballot(res.eob || res.err) & (f == 64 ? ~0ull : ((1ull << f) - 1));
+                const uint64_t stop = __ballot(P.stopped()) & (f == 64 ? ~0ull : ((1ull << f) - 1));
                 if (stop) {
                     nvalid = __builtin_ctzll(stop) + 1;
                     break;
@@ -616,40 +667,52 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                     break;
                 }
             }
-            // how many of the confirmed lanes fit this round's window and match list
+            PROF_ADD(2);  // sync rounds
+            // how many of the confirmed lanes fit this round's buffer and match list
             const bool in = lane < nvalid;
-            const uint32_t cb = wave_incl_scan(in ? res.nbytes : 0, lane), cm = wave_incl_scan(in ? res.nmatch : 0, lane);
+            const uint32_t cb = wave_incl_scan(in ? P.nbytes() : 0, lane), cm = wave_incl_scan(in ? P.nmatch() : 0, lane);
             const bool fits = in && cb <= kIterOut && cm <= kMatchCap && outpos + cb <= raw_n;
             const int take = __popcll(__ballot(fits));                        // a prefix: the sums are monotonic
             if (take == 0) {
-                const uint32_t b0 = __shfl(res.nbytes, 0, 64);
+                const uint32_t b0 = __shfl(P.nbytes(), 0, 64);
                 if (outpos + b0 > raw_n || B <= 8) {                          // more output than the image has rows for
-                    bad = true;
+                    PNG_BAD(13);
                     break;
                 }
                 B = B / 4 < 8 ? 8 : B / 4;                                    // extremely dense matches: shorter subsequences
                 continue;
             }
-            const uint32_t my_out = outpos + cb - res.nbytes, my_m = cm - res.nmatch;
+            const uint32_t rb_base = outpos & ~3u;
             bool far = false;
-            if (lane < take) far = decode_sub<true>(L, start, limit, my_out, my_m).err && !res.err;
+            PROF_ADD(3);  // scans / cut
+            if (lane < take) far = parse_sub<true>(L, P.start, limit, outpos + cb - P.nbytes(), rb_base, cm - P.nmatch()).err() && !P.err();
             wave_lds_sync();
+            PROF_ADD(4);  // emit
+            PROF_CNT(11, take);
             if (__ballot(far)) {
-                bad = true;
+                PNG_BAD(14);
                 break;
             }
             const uint32_t add = __shfl(cb, take - 1, 64), nm = __shfl(cm, take - 1, 64);
-            resolve_matches(L, nm, lane);
+            resolve_matches(L, out, outpos, rb_base, nm, lane);
+            PROF_ADD(5);  // matches
+            PROF_CNT(12, nm);
             flush_out(L, out, outpos, outpos + add, lane);
+            __threadfence_block();                                           // later rounds read these bytes back
+            PROF_ADD(6);  // flush
             outpos += add;
-            const bool t_eob = __shfl((int)res.eob, take - 1, 64), t_err = __shfl((int)res.err, take - 1, 64);
-            bp = s0 + __shfl(res.exit, take - 1, 64);
-            if (t_err || bp > total_bits) bad = true;
+            const bool t_eob = __shfl((int)P.eob(), take - 1, 64), t_err = __shfl((int)P.err(), take - 1, 64);
+            bp = s0 + __shfl(P.exit, take - 1, 64);
+            if (t_err || bp > total_bits) PNG_BAD(15);
             eob = t_eob;
             if (take == 64 && add < kIterOut / 4 && B < kMaxB) B *= 2;
         }
     }
-    if (!bad && outpos != raw_n) bad = true;
+    if (!bad && outpos != raw_n) PNG_BAD(16);
+#ifdef PNG_PROF
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_png_prof[i], _acc[i]);
+#endif
     if (bad && lane == 0) info[img].status = UCFP_E_MODALITY;
 }
 
@@ -764,6 +827,17 @@ int launch_png_merge_status(const uint8_t* ws, const PngWs& l, size_t n, uint8_t
                        reinterpret_cast<const PngInfo*>(ws + l.info), n, out, rec, status);
     return 0;
 }
+
+#ifdef PNG_PROF
+extern "C" int ucfp_debug_png_prof(unsigned long long* out16, int reset) {
+    if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_png_prof), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_png_prof), z, sizeof z);
+    }
+    return 0;
+}
+#endif
 
 size_t png_ws_bytes(size_t n, size_t png_bytes, uint32_t w, uint32_t h, int pixfmt, PngWs* ws) {
     const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;

@@ -423,6 +423,43 @@ int ucfp_index_search_sharded_dev(ucfp_index* idx, ucfp_shard_comm* comm, uint32
  * ImageFingerprint.exact (BLAKE3 of the uploaded bytes). Host code; no device needed. */
 int ucfp_blake3(const uint8_t* data, size_t len, uint8_t out[32]);
 
+/* =============================== STORED TABLES ====================
+ * The reference's source of truth is one redb file: tables ucfp/fingerprints/v1, ucfp/vectors/v1, ucfp/catalog/v2,
+ * all keyed (tenant_id, record_id) and written in one transaction per upsert (src/index/embedded/mod.rs:37-43,
+ * :157-227); EmbeddedBackend::open (:104-125) is where a device mirror has to be rebuilt.  redb's page format lives in
+ * a crate outside the tree, so the drop-in keeps a SIDECAR: an append-only log of exactly those rows (fingerprint
+ * bytes, embedding, the catalog row's serde_json text) that the host appends to right after its redb transaction
+ * commits, and replays at start-up.  Last entry of a key wins; a torn tail is cut on the next open (CRC per entry).
+ * Host-only calls (no GPU involved). */
+typedef struct ucfp_sidecar ucfp_sidecar;
+int ucfp_sidecar_open(const char* path, ucfp_sidecar** out);      /* creates the log if missing, validates it otherwise */
+void ucfp_sidecar_close(ucfp_sidecar* sc);
+/* One call per record of IndexBackend::upsert (mod.rs:176-208): embedding NULL / dim 0 = "no vector" (:184-191). */
+int ucfp_sidecar_append_upsert(ucfp_sidecar* sc, uint32_t tenant, uint64_t record_id, const uint8_t* fingerprint,
+                               uint32_t fp_len, const float* embedding, uint32_t dim, const char* catalog_json,
+                               uint32_t json_len);
+int ucfp_sidecar_append_delete(ucfp_sidecar* sc, uint32_t tenant, uint64_t record_id);   /* IndexBackend::delete :229-266 */
+int ucfp_sidecar_sync(ucfp_sidecar* sc);                           /* fdatasync: call where the host fsyncs redb */
+
+/* Read side: the live rows of a log (after replaying overwrites and deletes), in ascending (tenant, record_id) order
+ * -- the order of the reference's range scans.  Pointers returned by _row point into the mapped file and live until
+ * _close; embedding bytes are not necessarily 4-byte aligned. */
+typedef struct ucfp_sidecar_snapshot ucfp_sidecar_snapshot;
+int ucfp_sidecar_snapshot_open(const char* path, ucfp_sidecar_snapshot** out, uint64_t* live_rows, uint64_t* log_entries,
+                               uint64_t* torn_bytes);
+void ucfp_sidecar_snapshot_close(ucfp_sidecar_snapshot* s);
+int ucfp_sidecar_snapshot_row(ucfp_sidecar_snapshot* s, uint64_t i, uint32_t* tenant, uint64_t* record_id,
+                              const uint8_t** fingerprint, uint32_t* fp_len, const uint8_t** embedding_bytes, uint32_t* dim,
+                              const char** catalog_json, uint32_t* json_len);
+/* Bulk gathers for the rebuild: fingerprints of the rows whose catalog `algorithm` is `algorithm` and whose blob is
+ * fp_len bytes ("only comparable hashes share an index"), or the embeddings of one dimension, packed into caller arrays
+ * (any of which may be NULL).  *n = matching rows; if it exceeds cap only the first cap were written. */
+int ucfp_sidecar_snapshot_gather_fingerprints(ucfp_sidecar_snapshot* s, const char* algorithm, uint32_t fp_len,
+                                              uint32_t* tenants, uint64_t* ids, uint8_t* fingerprints, uint64_t cap,
+                                              uint64_t* n);
+int ucfp_sidecar_snapshot_gather_vectors(ucfp_sidecar_snapshot* s, uint32_t dim, uint32_t* tenants, uint64_t* ids,
+                                         float* rows, uint64_t cap, uint64_t* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,6 +135,22 @@ SIGNATURES = {
     "ucfp_image_png_hash_batch_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                                 C.c_uint32, C.c_uint32, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_sidecar_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ucfp_sidecar_close": (None, [C.c_void_p]),
+    "ucfp_sidecar_append_upsert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint32, C.c_void_p,
+                                             C.c_uint32, C.c_char_p, C.c_uint32]),
+    "ucfp_sidecar_append_delete": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "ucfp_sidecar_sync": (C.c_int, [C.c_void_p]),
+    "ucfp_sidecar_snapshot_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ucfp_sidecar_snapshot_close": (None, [C.c_void_p]),
+    "ucfp_sidecar_snapshot_row": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
+    "ucfp_sidecar_snapshot_gather_fingerprints": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                            C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ucfp_sidecar_snapshot_gather_vectors": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_uint64, C.POINTER(C.c_uint64)]),
     "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                        C.c_uint32, C.c_size_t, C.c_void_p]),

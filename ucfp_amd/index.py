@@ -128,10 +128,14 @@ class GpuIndex:
     like the reference skips rows whose stored length differs from the query's
     (src/index/embedded/mod.rs:307-309)."""
 
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, sidecar=None):
         self.ctx = ctx or _lib.current_context()
         self._cos = {}        # dim -> DeviceIndex
         self._ham = {}        # hash space name -> DeviceIndex
+        self._sidecar = sidecar   # ucfp_amd.store.Sidecar: the stored-table mirror written at upsert (SURVEY 8f N2)
+
+    def attach_sidecar(self, sidecar) -> None:
+        self._sidecar = sidecar
 
     def _cosine(self, dim: int) -> DeviceIndex:
         ix = self._cos.get(dim)
@@ -154,6 +158,8 @@ class GpuIndex:
         (src/index/embedded/mod.rs:184-191), a new dimension or algorithm replaces the old row.  So before inserting,
         the key is removed from every cosine index of another dimension and every hash space the new record does not
         feed.  Within one batch the last record of a key wins, as successive `insert`s in one redb transaction do."""
+        if self._sidecar is not None:     # the log first (the host does this right after its redb commit), then the mirror
+            self._sidecar.append(records)
         last = {}
         for r in records:
             last[(r.tenant_id, r.record_id)] = r
@@ -187,6 +193,8 @@ class GpuIndex:
 
     def delete(self, tenant_id: int, record_ids: Iterable[int]) -> None:
         ids = np.array(list(record_ids), np.uint64)
+        if self._sidecar is not None:
+            self._sidecar.delete(tenant_id, ids.tolist())
         for ix in list(self._cos.values()) + list(self._ham.values()):
             ix.delete(tenant_id, ids)
 
@@ -228,6 +236,8 @@ class GpuIndex:
         return hits
 
     def flush(self) -> None:
+        if self._sidecar is not None:
+            self._sidecar.sync()
         for ix in list(self._cos.values()) + list(self._ham.values()):
             ix.flush()
 

@@ -236,6 +236,16 @@ int ucfp_audio_haitsma(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sampl
 int ucfp_audio_haitsma_dev(ucfp_ctx* ctx, const float* d_pcm5k, size_t n, const ucfp_haitsma_config* cfg,
                            uint32_t* d_out, size_t cap_frames, void* stream);
 
+/* RAGGED BATCH for Haitsma, same shape as ucfp_audio_wang_batch_dev: clip i = d_pcm[d_offsets[i] .. d_offsets[i+1]) at
+ * `sample_rate`; clips at another rate than 5 kHz are resampled (A1) into the context's workspace first, like
+ * audio.rs:194-200 does per clip.  Sub-fingerprints of clip i land in d_out[d_out_offsets[i] .. d_out_offsets[i+1])
+ * (u32 each; a clip's first frame has a zero history); frames past cap_frames are not written (d_out_offsets[n_clips]
+ * tells).  One launch sequence for the whole batch. */
+size_t ucfp_audio_haitsma_batch_max_frames(size_t n_total, size_t n_clips, uint32_t sample_rate);
+int ucfp_audio_haitsma_batch_dev(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_offsets, size_t n_total, size_t n_clips,
+                                 uint32_t sample_rate, const ucfp_haitsma_config* cfg, uint32_t* d_out, size_t cap_frames,
+                                 uint64_t* d_out_offsets, void* stream);
+
 /* audiofp::dsp::resample::linear. Output length = floor(n * sr_out / sr_in). */
 size_t ucfp_audio_resample_len(size_t n, uint32_t sr_in, uint32_t sr_out);
 int ucfp_audio_resample_linear_dev(ucfp_ctx* ctx, const float* d_in, size_t n, uint32_t sr_in, uint32_t sr_out,

@@ -262,3 +262,28 @@ def test_micro_batcher_coalesces_concurrent_clips(gpu_ctx, oracle, sr):
         assert np.array_equal(g, ref[3])
     finally:
         b.close()
+
+
+@pytest.mark.parametrize("sr", [5000, 8000, 44100])
+def test_haitsma_batch_of_random_length_clips_matches_oracle(gpu_ctx, oracle, sr):
+    """700 clips of 0 .. 3 s (empty, shorter than one frame, exactly one frame, several seconds) through ONE call of
+    ucfp_audio_haitsma_batch_dev; every clip's sub-fingerprints equal the oracle's for that clip alone -- in particular a
+    clip's first frame has a zero history whatever clip precedes it."""
+    from ucfp_amd import audio
+    rng = np.random.default_rng(sr + 1)
+    one = (2048 * sr + 4999) // 5000                   # source samples that give one 2048-sample frame at 5 kHz
+    lens = rng.integers(0, 3 * sr, size=700)
+    lens[:8] = [0, 1, one - 2, one, one + 1, one + 64 * sr // 5000 + 2, sr, 2 * sr]
+    clips = [_clip(rng, int(n), i % 4) for i, n in enumerate(lens)]
+    got = audio.haitsma_frames_batch(clips, sr, ctx=gpu_ctx)
+    assert len(got) == len(clips)
+    total = 0
+    for i, (c, g) in enumerate(zip(clips, got)):
+        o = oracle.haitsma(c, sr)
+        assert g.shape == o.shape and np.array_equal(g, o), (i, c.size, g.shape, o.shape)
+        total += o.size
+    assert total > 20_000
+    cfg = audio.HaitsmaConfig(fmin=400.0, fmax=1800.0)
+    got = audio.haitsma_frames_batch(clips[:40], sr, cfg, ctx=gpu_ctx)
+    for c, g in zip(clips[:40], got):
+        assert np.array_equal(g, oracle.haitsma(c, sr, 400.0, 1800.0))

@@ -164,6 +164,34 @@ def haitsma_frames(samples, sample_rate: int, cfg: Optional[HaitsmaConfig] = Non
     return out[: n.value].copy()
 
 
+def haitsma_frames_batch(clips, sample_rate: int, cfg: Optional[HaitsmaConfig] = None, ctx=None) -> List[np.ndarray]:
+    """A list of mono f32 clips (all at `sample_rate`) -> one uint32 [frames_i] array per clip, one launch sequence for
+    the whole batch (ucfp_audio_haitsma_batch_dev)."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    _check_rate(sample_rate)
+    arrs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in clips]
+    if not arrs:
+        return []
+    offs = np.zeros(len(arrs) + 1, np.uint64)
+    np.cumsum([a.size for a in arrs], out=offs[1:])
+    blob = np.concatenate(arrs) if offs[-1] else np.zeros(1, np.float32)
+    c = (cfg or HaitsmaConfig())._c()
+    lib = _lib.load()
+    cap = max(1, int(lib.ucfp_audio_haitsma_batch_max_frames(int(offs[-1]), len(arrs), sample_rate)))
+    dev = f"cuda:{ctx.device}"
+    d_pcm = torch.from_numpy(blob).to(dev)
+    d_off = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_out = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_oo = torch.zeros(len(arrs) + 1, dtype=torch.int64, device=dev)
+    _lib.check(lib.ucfp_audio_haitsma_batch_dev(ctx.handle, d_pcm.data_ptr(), d_off.data_ptr(), int(offs[-1]), len(arrs),
+                                                sample_rate, C.byref(c), d_out.data_ptr(), cap, d_oo.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream or None))
+    oo = d_oo.cpu().numpy()
+    out = d_out.cpu().numpy().view(np.uint32)
+    return [out[oo[i]:oo[i + 1]].copy() for i in range(len(arrs))]
+
+
 def _record(algo: str, payload: bytes, tenant_id: int, record_id: int) -> Record:
     # format_version 1, config_hash 0: audio.rs:89-91
     return Record(tenant_id=tenant_id, record_id=record_id, modality=Modality.Audio, format_version=1,

@@ -36,7 +36,7 @@ namespace {
 __constant__ float c_tw[1024][2] = UCFP_FFT_TW_INIT;
 
 constexpr int kWangN = 1024, kWangHop = 128, kWangBins = 512, kRT = 7, kRK = 15, kWangSr = 8000;
-constexpr int kHkN = 2048, kHkHop = 64, kHkBands = 33;
+constexpr int kHkN = 2048, kHkHop = 64, kHkBands = 33, kHkSr = 5000;
 constexpr int kCandCap = 320;   // > (63/8 + 1) * (512/16) possible peaks per second
 
 // ---- A1 ----------------------------------------------------------------------------------
@@ -397,11 +397,15 @@ struct FftLds {
     float buf[kFftWaves][Rfft<N>::BUF_FLOATS];
 };
 
+// src_map (optional, ragged batches): sample offset of every frame in x, top bit = first frame of its clip, all ones =
+// past the batch's last frame; without it frame f starts at x + f * hop.
+constexpr uint64_t kFrameFirst = 1ull << 63, kFrameNone = ~0ull;
 template <int N, bool HAITSMA>
 __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float* __restrict__ x, size_t first_frame,
                                                          size_t n_frames, int hop, float* __restrict__ out,
                                                          const uint32_t* __restrict__ edges,
-                                                         float* __restrict__ rowmax_out) {
+                                                         float* __restrict__ rowmax_out,
+                                                         const uint64_t* __restrict__ src_map = nullptr) {
     using R = Rfft<N>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     FftLds<N>& L = *reinterpret_cast<FftLds<N>*>(lds_raw);
@@ -415,6 +419,11 @@ __global__ __launch_bounds__(kFftWaves * 64) void stft_power_kernel(const float*
     const size_t step = (size_t)gridDim.x * kFftWaves;
     for (size_t f = (size_t)blockIdx.x * kFftWaves + wave; f < n_frames; f += step) {
         const float* src = x + (first_frame + f) * (size_t)hop;
+        if (src_map) {
+            const uint64_t m = src_map[first_frame + f];
+            if (m == kFrameNone) continue;
+            src = x + (m & ~kFrameFirst);
+        }
         f32x2 z[R::E];
 #pragma unroll
         for (int i = 0; i < R::E; i++) {
@@ -1093,13 +1102,19 @@ __global__ void wang_clip_offsets_kernel(const uint32_t* __restrict__ sec_base, 
 }
 
 // ---- A8 ------------------------------------------------------------------------------------
-__global__ void haitsma_bits_kernel(const float* __restrict__ E, size_t first, size_t n, uint32_t* __restrict__ out) {
+__global__ void haitsma_bits_kernel(const float* __restrict__ E, size_t first, size_t n, uint32_t* __restrict__ out,
+                                    const uint64_t* __restrict__ src_map = nullptr, size_t cap = ~(size_t)0) {
     // E holds frames [first - 1, first + n) when first > 0 (row 0 = previous frame), else [0, n)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || first + i >= cap) return;
     const size_t row = first > 0 ? i + 1 : i;
     const float* cur = E + row * kHkBands;
-    const bool has_prev = first > 0 || i > 0;
+    bool has_prev = first > 0 || i > 0;
+    if (src_map) {
+        const uint64_t m = src_map[first + i];
+        if (m == kFrameNone) return;
+        has_prev = !(m & kFrameFirst);        // a clip's first frame has a zero history (A8), whatever precedes it in the batch
+    }
     const float* prv = cur - kHkBands;
     uint32_t h = 0;
 #pragma unroll
@@ -1110,6 +1125,96 @@ __global__ void haitsma_bits_kernel(const float* __restrict__ E, size_t first, s
         if (dd > 0.0f) h |= 1u << b;
     }
     out[first + i] = h;
+}
+
+// ---- Haitsma over a ragged batch of clips ------------------------------------------------------------------------
+// One workgroup: per clip its length at 5 kHz and its frame count, exclusive-scanned into s5_off / fr_off (n_clips + 1
+// entries each); fr_off is also the caller's output offset table.
+__global__ __launch_bounds__(1024) void haitsma_clip_prep_kernel(const uint64_t* __restrict__ offsets, size_t n_clips, uint32_t sr,
+                                                                 uint64_t* __restrict__ s5_off, uint64_t* __restrict__ fr_off,
+                                                                 uint64_t* __restrict__ out_off) {
+    __shared__ uint64_t part[2][16];
+    __shared__ uint64_t carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry[0] = carry[1] = 0;
+    __syncthreads();
+    for (size_t base = 0; base < n_clips; base += 1024) {
+        const size_t c = base + tid;
+        uint64_t n5 = 0, fr = 0;
+        if (c < n_clips) {
+            const uint64_t len = offsets[c + 1] - offsets[c];
+            n5 = sr == (uint32_t)kHkSr ? len : (uint64_t)(((unsigned __int128)len * kHkSr) / sr);
+            fr = n5 >= (uint64_t)kHkN ? 1 + (n5 - kHkN) / kHkHop : 0;
+        }
+        uint64_t a = n5, b = fr;          // inclusive scans inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t oa = __shfl_up(a, d, 64), ob = __shfl_up(b, d, 64);
+            if (lane >= d) a += oa, b += ob;
+        }
+        if (lane == 63) part[0][wave] = a, part[1][wave] = b;
+        __syncthreads();
+        uint64_t wa = 0, wb = 0;
+        for (int w = 0; w < wave; w++) wa += part[0][w], wb += part[1][w];
+        const uint64_t ca = carry[0], cb = carry[1];
+        if (c < n_clips) {
+            s5_off[c] = ca + wa + a - n5;
+            fr_off[c] = cb + wb + b - fr;
+            if (out_off) out_off[c] = cb + wb + b - fr;
+        }
+        __syncthreads();
+        if (tid == 1023) carry[0] = ca + wa + a, carry[1] = cb + wb + b;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        s5_off[n_clips] = carry[0];
+        fr_off[n_clips] = carry[1];
+        if (out_off) out_off[n_clips] = carry[1];
+    }
+}
+
+__device__ __forceinline__ size_t upper_clip(const uint64_t* __restrict__ off, size_t n_clips, uint64_t g) {
+    size_t lo = 0, hi = n_clips;          // largest c with off[c] <= g (off[0] = 0)
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (off[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// A1 for every clip of the batch at once: output sample g of the concatenated 5 kHz streams.
+__global__ void haitsma_resample_batch_kernel(const float* __restrict__ in, const uint64_t* __restrict__ offsets,
+                                              const uint64_t* __restrict__ s5_off, size_t n_clips, uint32_t sr,
+                                              float* __restrict__ out, size_t m_ub) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= m_ub || g >= s5_off[n_clips]) return;
+    const size_t c = upper_clip(s5_off, n_clips, g);
+    const uint64_t i = g - s5_off[c], n = offsets[c + 1] - offsets[c];
+    const float* src = in + offsets[c];
+    const uint64_t num = i * sr;
+    const size_t idx = (size_t)(num / kHkSr);
+    const uint32_t rem = (uint32_t)(num % kHkSr);
+    const float frac = (float)((double)rem / (double)kHkSr);
+    const float x0 = src[idx], x1 = src[idx + 1 < n ? idx + 1 : n - 1];
+    const float d = x1 - x0;
+    const float mm = d * frac;
+    out[g] = x0 + mm;
+}
+
+// Frame g of the batch -> where its 2048 samples start (in the 5 kHz stream, or in the caller's own when sr = 5000).
+__global__ void haitsma_frame_map_kernel(const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ s5_off,
+                                         const uint64_t* __restrict__ fr_off, size_t n_clips, bool own_stream,
+                                         uint64_t* __restrict__ src_map, size_t frames_ub) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= frames_ub) return;
+    if (g >= fr_off[n_clips]) {
+        src_map[g] = kFrameNone;
+        return;
+    }
+    const size_t c = upper_clip(fr_off, n_clips, g);
+    const uint64_t f = g - fr_off[c];
+    src_map[g] = ((own_stream ? offsets[c] : s5_off[c]) + f * kHkHop) | (f == 0 ? kFrameFirst : 0);
 }
 
 inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -1276,6 +1381,63 @@ int launch_haitsma(const float* pcm5k, size_t n, const uint32_t* h_edges, uint8_
                            E, (const uint32_t*)d_edges, (float*)nullptr);
         hipLaunchKernelGGL(haitsma_bits_kernel, dim3(blocks_for(e1 - e0, 256)), dim3(256), 0, stream, E, e0, e1 - e0,
                            out);
+    }
+    return 0;
+}
+
+HaitsmaBatchWs haitsma_batch_ws(size_t n_total, size_t n_clips, uint32_t sr) {
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    HaitsmaBatchWs w;
+    w.n5_ub = sr == (uint32_t)kHkSr ? n_total : (size_t)(((unsigned __int128)n_total * kHkSr) / sr) + 1;
+    w.frames_ub = w.n5_ub / kHkHop + 1;       // a clip of n5 >= 2048 samples has n5 / 64 - 31 frames
+    const size_t chunk = w.frames_ub < kChunkFrames * 4 ? w.frames_ub : kChunkFrames * 4;
+    size_t off = 0;
+    w.edges = off;   off = align(off + 64 * 4);
+    w.s5_off = off;  off = align(off + (n_clips + 1) * 8);
+    w.fr_off = off;  off = align(off + (n_clips + 1) * 8);
+    w.src_map = off; off = align(off + w.frames_ub * 8);
+    w.pcm5k = off;   off = align(off + (sr == (uint32_t)kHkSr ? 0 : (w.n5_ub + 64) * 4));
+    w.E = off;       off = align(off + (chunk + 1) * kHkBands * 4);
+    w.total = off;
+    return w;
+}
+
+int launch_haitsma_batch(const float* pcm, const uint64_t* d_offsets, size_t n_total, size_t n_clips, uint32_t sr,
+                         const uint32_t* h_edges, uint8_t* ws, const HaitsmaBatchWs& w, uint32_t* out, size_t cap_frames,
+                         uint64_t* d_out_offsets, hipStream_t stream) {
+    uint32_t* d_edges = reinterpret_cast<uint32_t*>(ws + w.edges);
+    uint64_t* s5_off = reinterpret_cast<uint64_t*>(ws + w.s5_off);
+    uint64_t* fr_off = reinterpret_cast<uint64_t*>(ws + w.fr_off);
+    uint64_t* src_map = reinterpret_cast<uint64_t*>(ws + w.src_map);
+    float* E = reinterpret_cast<float*>(ws + w.E);
+    (void)hipMemcpyAsync(d_edges, h_edges, (kHkBands + 1) * 4, hipMemcpyHostToDevice, stream);
+    hipLaunchKernelGGL(haitsma_clip_prep_kernel, dim3(1), dim3(1024), 0, stream, d_offsets, n_clips, sr, s5_off, fr_off,
+                       d_out_offsets);
+    if (n_clips == 0 || n_total == 0) return 0;
+    const bool own = sr == (uint32_t)kHkSr;
+    const float* x = pcm;
+    if (!own) {
+        float* p5 = reinterpret_cast<float*>(ws + w.pcm5k);
+        hipLaunchKernelGGL(haitsma_resample_batch_kernel, dim3(blocks_for(w.n5_ub, 256)), dim3(256), 0, stream, pcm, d_offsets,
+                           s5_off, n_clips, sr, p5, w.n5_ub);
+        x = p5;
+    }
+    hipLaunchKernelGGL(haitsma_frame_map_kernel, dim3(blocks_for(w.frames_ub, 256)), dim3(256), 0, stream, d_offsets, s5_off,
+                       fr_off, n_clips, own, src_map, w.frames_ub);
+    const size_t lds = sizeof(FftLds<kHkN>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stft_power_kernel<kHkN, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t chunk = kChunkFrames * 4;
+    for (size_t e0 = 0; e0 < w.frames_ub; e0 += chunk) {
+        const size_t e1 = e0 + chunk < w.frames_ub ? e0 + chunk : w.frames_ub;
+        const size_t w0 = e0 > 0 ? e0 - 1 : 0;  // one frame of history for the time difference
+        const size_t wn = e1 - w0;
+        unsigned grid = blocks_for(wn, kFftWaves);
+        if (grid > 256) grid = 256;
+        hipLaunchKernelGGL((stft_power_kernel<kHkN, true>), dim3(grid), dim3(kFftWaves * 64), lds, stream, x, w0, wn, kHkHop,
+                           E, (const uint32_t*)d_edges, (float*)nullptr, (const uint64_t*)src_map);
+        hipLaunchKernelGGL(haitsma_bits_kernel, dim3(blocks_for(e1 - e0, 256)), dim3(256), 0, stream, E, e0, e1 - e0,
+                           out, (const uint64_t*)src_map, cap_frames);
     }
     return 0;
 }

@@ -520,6 +520,41 @@ int ucfp_audio_haitsma_dev(ucfp_ctx* ctx, const float* d_pcm5k, size_t n, const 
     return UCFP_OK;
 }
 
+size_t ucfp_audio_haitsma_batch_max_frames(size_t n_total, size_t n_clips, uint32_t sample_rate) {
+    if (sample_rate < 1000 || sample_rate > 384000) return 0;
+    return ucfp::haitsma_batch_ws(n_total, n_clips, sample_rate).frames_ub;
+}
+
+int ucfp_audio_haitsma_batch_dev(ucfp_ctx* ctx, const float* d_pcm, const uint64_t* d_offsets, size_t n_total, size_t n_clips,
+                                 uint32_t sample_rate, const ucfp_haitsma_config* cfg, uint32_t* d_out, size_t cap_frames,
+                                 uint64_t* d_out_offsets, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (!d_out_offsets || (n_clips && !d_offsets) || (n_total && !d_pcm) || (cap_frames && !d_out))
+        return fail(UCFP_E_INVALID, "NULL buffer");
+    if (sample_rate < 1000 || sample_rate > 384000)
+        return fail(UCFP_E_MODALITY, "invalid sample rate %u (1 000 .. 384 000 Hz)", sample_rate);
+    if (n_clips > 0x7fffffffu || n_total > ((size_t)1 << 40)) return fail(UCFP_E_INVALID, "audio batch too large for one call");
+    const float fmin = cfg ? cfg->fmin : 300.0f, fmax = cfg ? cfg->fmax : 2000.0f;
+    if (!(fmin >= 1.0f) || !(fmax > fmin) || !(fmax <= 2500.0f))
+        return fail(UCFP_E_MODALITY, "Haitsma band edges must satisfy 1 <= fmin < fmax <= 2500 Hz");
+    uint32_t edges[34];
+    haitsma_edges(fmin, fmax, edges);
+    const ucfp::HaitsmaBatchWs w = ucfp::haitsma_batch_ws(n_total, n_clips, sample_rate);
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = grow(&ctx->audio_ws, &ctx->audio_ws_cap, w.total);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, ctx->audio_done, 0));
+    static thread_local uint32_t tl_edges[34];      // copied with an async copy from pageable memory: must outlive the call
+    memcpy(tl_edges, edges, sizeof edges);
+    ucfp::launch_haitsma_batch(d_pcm, d_offsets, n_total, n_clips, sample_rate, tl_edges, ctx->audio_ws, w, d_out, cap_frames,
+                               d_out_offsets, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->audio_done, st));
+    return UCFP_OK;
+}
+
 int ucfp_audio_haitsma(ucfp_ctx* ctx, const float* pcm, size_t n, uint32_t sample_rate,
                        const ucfp_haitsma_config* cfg, uint32_t* out, size_t cap_frames, size_t* n_frames) {
     if (!ctx || !n_frames) return fail(UCFP_E_INVALID, "ctx/n_frames is NULL");

@@ -140,6 +140,14 @@ int launch_wang_batch(const float* pcm, const uint64_t* d_offsets, size_t n_src_
                       uint32_t fan_out, uint32_t zone_t, uint32_t zone_f, uint32_t pps,
                       float floor_power, uint8_t* ws, const WangWs& w, uint32_t* out, size_t cap, uint64_t* d_out_off,
                       uint64_t* out_count, hipStream_t stream);
+struct HaitsmaBatchWs {
+    size_t n5_ub = 0, frames_ub = 0;      // upper bounds (the per-clip lengths of a batch live on the device)
+    size_t edges, s5_off, fr_off, src_map, pcm5k, E, total = 0;
+};
+HaitsmaBatchWs haitsma_batch_ws(size_t n_total, size_t n_clips, uint32_t sr);
+int launch_haitsma_batch(const float* pcm, const uint64_t* d_offsets, size_t n_total, size_t n_clips, uint32_t sr,
+                         const uint32_t* h_edges, uint8_t* ws, const HaitsmaBatchWs& w, uint32_t* out, size_t cap_frames,
+                         uint64_t* d_out_offsets, hipStream_t stream);
 size_t haitsma_ws_bytes(size_t n5k);
 int launch_haitsma(const float* pcm5k, size_t n, const uint32_t* h_edges, uint8_t* ws, uint32_t* out,
                    hipStream_t stream);

@@ -271,6 +271,13 @@ int ucfp_audio_resample_linear_dev(ucfp_ctx* ctx, const float* d_in, size_t n, u
 #define UCFP_TEXT_PRETOKENIZED 1
 #define UCFP_TEXT_NEEDS_HOST 1
 #define UCFP_MINHASH_BYTES 1032 /* txtfp::MinHashSig<128>: u16 schema = 1, 6 pad, 128 x u64 LE */
+/* COMPATIBILITY: the LAYOUT is txtfp's, the 128 slot VALUES are not -- txtfp 0.2.0's slot derivation could not be
+ * recovered offline (the reference's golden slot 0, src/server/tests.rs:1153-1157, is not
+ * reproduced).  Records made here must therefore never be compared with upstream `minhash-h128` records: the host
+ * stores them with format_version UCFP_MINHASH_FORMAT_VERSION instead of txtfp::FORMAT_VERSION (text.rs:227), so a
+ * mixed corpus is rejected as incompatible rather than yielding meaningless Jaccard estimates.  SimHash (XXH3-64 per
+ * token, family pinned by tests.rs:1126-1127) carries txtfp's own format_version. */
+#define UCFP_MINHASH_FORMAT_VERSION 0x48500001u
 #define UCFP_SIMHASH_BYTES 8
 
 int ucfp_text_minhash_batch_dev(ucfp_ctx* ctx, const uint8_t* d_utf8, const uint64_t* d_offsets, size_t n,

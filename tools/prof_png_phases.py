@@ -25,6 +25,7 @@ a = np.array(list(acc), dtype=np.float64) / n
 names = ["header+tables", "stage", "sync rounds", "scans/cut", "emit", "matches", "flush"]
 tot = a[:7].sum()
 print(f"ok={not st.any()} per image: total {tot/1e6:.2f} Mcycles; blocks {a[8]:.1f} iterations {a[9]:.1f} sync-rounds/iter {a[10]/max(a[9],1):.2f} "
-      f"lanes taken/iter {a[11]/max(a[9],1):.1f} matches/iter {a[12]/max(a[9],1):.1f}")
+      f"lanes taken/iter {a[11]/max(a[9],1):.1f} matches/iter {a[12]/max(a[9],1):.1f} resolve rounds/iter {a[13]/max(a[9],1):.1f} "
+      f"(whole-wave copies {a[14]/max(a[9],1):.1f})")
 for i, nm in enumerate(names):
     print(f"  {nm:14s} {a[i]/1e3:9.1f} kcycles  {100*a[i]/tot:5.1f}%   per iteration {a[i]/max(a[9],1):8.0f}")

@@ -36,6 +36,7 @@ namespace {
 constexpr int kRoot = 10, kDRoot = 8;                  // bits indexed by the first-level tables
 constexpr uint32_t kIterOut = 4096;                    // output bytes one speculation round may add
 constexpr uint32_t kMatchCap = 1024;                   // matches listed per round
+constexpr uint32_t kHist = 2048;                       // bytes of earlier rounds kept in LDS: a match one image row back (the common distance) never leaves the CU
 constexpr int kStageWords = 288;                       // compressed words staged per round: 64 x 128 bits + overshoot + refill
 constexpr int kMaxB = 128;                             // bits per subsequence
 
@@ -57,7 +58,7 @@ struct InflateLds {
     uint16_t ll_count[16];
     uint16_t d_count[16];
     uint8_t lens[320];
-    uint8_t rb[kIterOut + 8];                          // this round's output; rb[0] is stream position (outpos & ~3)
+    uint8_t rb[kHist + kIterOut + 8];                  // the last kHist bytes of earlier rounds + this round's output; rb[0] is stream position rb_base
 };
 
 __device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t len) {
@@ -205,55 +206,60 @@ struct Parse {
 
 // EMIT = false: count.  EMIT = true: literals into the round buffer (rb_base = stream position of L.rb[0]), matches onto
 // the list; the err flag of the result then also reports a match that reaches back before the first byte of the image.
+// Written straight-line: the loop is uniform (it runs while any lane still has symbols), a lane that is done idles on
+// its start position, and literal / length / distance handling are selects, not branches -- nested divergent regions
+// cost more in exec-mask bookkeeping and serial LDS waits than the work they skip.  One 64-bit window of the stream per
+// symbol (three words, one LDS round trip) serves both the literal/length code and the distance code behind it.
 template <bool EMIT>
 __device__ __forceinline__ Parse parse_sub(InflateLds& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint32_t rb_base,
                                            uint32_t m_idx) {
     uint32_t pos = start, nb = 0, nm = 0, flags = 0;
-    while (pos < limit) {
-        const uint32_t x = bits32(L.stage, pos);
+    bool act = pos < limit;
+    while (__ballot(act)) {
+        const uint32_t p = act ? pos : start;
+        const uint32_t w = p >> 5, sh = p & 31;
+        const uint32_t w0 = L.stage[w], w1 = L.stage[w + 1], w2 = L.stage[w + 2];
+        const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, sh), x2 = __builtin_amdgcn_alignbit(w2, w1, sh);
         uint32_t e = L.lit[x & ((1u << kRoot) - 1)];
-        if ((e >> 24) == kSlow) e = slow_code32(x, L.ll_count, L.ll_sorted, false);
-        const uint32_t cl = (e >> 20) & 15u;
-        if (cl == 0) {
-            flags = 2u;
-            break;
+        if (__ballot(act && (e >> 24) == kSlow)) {
+            if ((e >> 24) == kSlow) e = slow_code32(x, L.ll_count, L.ll_sorted, false);
         }
-        const uint32_t kind = e >> 24;
-        if (kind == kLit) {
-            if (EMIT) L.rb[out_pos + nb - rb_base] = (uint8_t)e;
-            pos += cl;
-            nb++;
-            continue;
-        }
-        if (kind == kEob) {
-            pos += cl;
-            flags = 1u;
-            break;
-        }
-        const uint32_t ex = (e >> 16) & 15u;
+        const uint32_t cl = (e >> 20) & 15u, kind = e >> 24, ex = (e >> 16) & 15u;
+        const uint32_t s1 = cl + ex;                                          // <= 20 bits: code + extra bits (0 for literals)
+        const bool is_len = kind == kLen;
         const uint32_t len = (e & 0xffffu) + ((x >> cl) & ((1u << ex) - 1u));
-        const uint32_t p2 = pos + cl + ex;
-        const uint32_t y = bits32(L.stage, p2);
-        uint32_t d = L.dst[y & ((1u << kDRoot) - 1)];
-        if ((d >> 24) == kSlow) d = slow_code32(y, L.d_count, L.d_sorted, true);
-        const uint32_t dl = (d >> 20) & 15u;
-        if (dl == 0) {
-            flags = 2u;
-            break;
+        uint32_t adv = s1, dist = 0;
+        bool bad = cl == 0;
+        if (__ballot(act && is_len)) {
+            const uint32_t y = __builtin_amdgcn_alignbit(x2, x, s1);         // the 32 bits behind the length: s1 + 28 <= 48 < 64
+            uint32_t d = L.dst[y & ((1u << kDRoot) - 1)];
+            if (__ballot(act && is_len && (d >> 24) == kSlow)) {
+                if (is_len && (d >> 24) == kSlow) d = slow_code32(y, L.d_count, L.d_sorted, true);
+            }
+            const uint32_t dl = (d >> 20) & 15u, dex = (d >> 16) & 15u;
+            dist = (d & 0xffffu) + ((y >> dl) & ((1u << dex) - 1u));
+            adv = is_len ? s1 + dl + dex : adv;
+            bad = bad || (is_len && dl == 0);
         }
-        const uint32_t dex = (d >> 16) & 15u;
-        const uint32_t dist = (d & 0xffffu) + ((y >> dl) & ((1u << dex) - 1u));
+        const bool lit = kind == kLit, eob = kind == kEob;
+        const bool go = act && !bad;
         if (EMIT) {
-            if (dist > out_pos + nb) flags |= 2u;
-            const uint32_t mi = m_idx + nm;
-            if (mi < kMatchCap) {
-                L.m_dst[mi] = out_pos + nb;
-                L.m_ld[mi] = len << 16 | (dist - 1);
+            if (go && lit) L.rb[out_pos + nb - rb_base] = (uint8_t)e;
+            if (go && is_len) {
+                if (dist > out_pos + nb) flags |= 2u;
+                const uint32_t mi = m_idx + nm;
+                if (mi < kMatchCap) {
+                    L.m_dst[mi] = out_pos + nb;
+                    L.m_ld[mi] = len << 16 | (dist - 1);
+                }
             }
         }
-        pos = p2 + dl + dex;
-        nb += len;
-        nm++;
+        flags |= (act && bad) ? 2u : 0u;
+        flags |= (go && eob) ? 1u : 0u;
+        pos += go ? adv : 0u;
+        nb += (go && lit) ? 1u : (go && is_len) ? len : 0u;
+        nm += (go && is_len) ? 1u : 0u;
+        act = go && !eob && pos < limit;
     }
     return Parse{start, pos, nb | nm << 16 | flags << 30};
 }
@@ -303,9 +309,8 @@ __device__ __forceinline__ uint32_t stage_load(InflateLds& L, const uint8_t* z, 
     return w0 << 5;
 }
 
-// Round buffer -> frame memory for [from, to); rb[0] is position (from & ~3), so whole words line up.
-__device__ __forceinline__ void flush_out(const InflateLds& L, uint8_t* out, uint32_t from, uint32_t to, int lane) {
-    const uint32_t base = from & ~3u;
+// Round buffer -> frame memory for [from, to); rb[0] is position `base` (a multiple of 4), so whole words line up.
+__device__ __forceinline__ void flush_out(const InflateLds& L, uint8_t* out, uint32_t from, uint32_t to, uint32_t base, int lane) {
     uint32_t p = from;
     const uint32_t head = (4 - (p & 3)) & 3;
     if (lane < (int)head && p + lane < to) out[p + lane] = L.rb[p + lane - base];
@@ -318,13 +323,14 @@ __device__ __forceinline__ void flush_out(const InflateLds& L, uint8_t* out, uin
     if (lane < (int)(to - p)) out[p + lane] = L.rb[p + lane - base];
 }
 
-// A byte of the stream: from this round's buffer, or -- written by an earlier round -- from frame memory.
-__device__ __forceinline__ uint8_t window_byte(const InflateLds& L, const uint8_t* out, uint32_t p, uint32_t outpos, uint32_t rb_base) {
-    return p >= outpos ? L.rb[p - rb_base] : out[p];
+// A byte of the stream: from the round buffer (this round and the kHist bytes before it), or from frame memory.
+__device__ __forceinline__ uint8_t window_byte(const InflateLds& L, const uint8_t* out, uint32_t p, uint32_t rb_base) {
+    return p >= rb_base ? L.rb[p - rb_base] : out[p];
 }
 
 // Resolves the listed matches in stream order.  All literals of the round are already in the round buffer.
-__device__ void resolve_matches(InflateLds& L, const uint8_t* out, uint32_t outpos, uint32_t rb_base, uint32_t total, int lane) {
+__device__ void resolve_matches(InflateLds& L, const uint8_t* out, uint32_t rb_base, uint32_t total, int lane,
+                                unsigned long long* rounds = nullptr, unsigned long long* coop = nullptr) {
     for (uint32_t g0 = 0; g0 < total; g0 += 64) {
         const uint32_t mi = g0 + lane;
         const bool have = mi < total;
@@ -333,24 +339,32 @@ __device__ void resolve_matches(InflateLds& L, const uint8_t* out, uint32_t outp
         uint64_t pending = __ballot(have);
         while (pending) {
             const int f = __builtin_ctzll(pending);
-            const uint32_t f_dst = __shfl(dst, f, 64), f_len = __shfl(len, f, 64), f_dist = __shfl(dist, f, 64);
+            const uint32_t f_dst = __builtin_amdgcn_readlane(dst, f), f_len = __builtin_amdgcn_readlane(len, f),
+                           f_dist = __builtin_amdgcn_readlane(dist, f);
+            if (rounds) (*rounds)++;
             if (f_len > 8 || f_dist < f_len) {
+                if (coop) (*coop)++;
                 // a long or self-overlapping match: the whole wave copies it (byte k comes from k mod dist)
                 for (uint32_t k0 = 0; k0 < f_len; k0 += 64) {
                     const uint32_t k = k0 + lane;
                     uint8_t v = 0;
-                    if (k < f_len) v = window_byte(L, out, f_dst - f_dist + (k % f_dist), outpos, rb_base);
+                    if (k < f_len) v = window_byte(L, out, f_dst - f_dist + (k % f_dist), rb_base);
                     if (k < f_len) L.rb[f_dst + k - rb_base] = v;
                 }
                 wave_lds_sync();
                 pending &= ~(1ull << f);
                 continue;
             }
-            // short matches whose source lies entirely below the first unresolved destination: one per lane, together
-            // (sources and destinations of the ready lanes cannot overlap, so bytes are copied in place)
+            // short matches whose source lies entirely below the first unresolved destination: one per lane, together.
+            // All source bytes are requested before the first is stored (a source in frame memory is a microsecond away:
+            // one wait per round, not one per byte).
             const bool ready = ((pending >> lane) & 1) && len <= 8 && dist >= len && dst - dist + len <= f_dst;
-            for (uint32_t k = 0; __ballot(ready && k < len); k++)
-                if (ready && k < len) L.rb[dst + k - rb_base] = window_byte(L, out, dst - dist + k, outpos, rb_base);
+            uint8_t tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) tmp[k] = (ready && (uint32_t)k < len) ? window_byte(L, out, dst - dist + k, rb_base) : (uint8_t)0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (ready && (uint32_t)k < len) L.rb[dst + k - rb_base] = tmp[k];
             wave_lds_sync();
             pending &= ~__ballot(ready);
         }
@@ -492,6 +506,12 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             for (uint32_t k = lane; k < len; k += 64) out[outpos + k] = z[byte + k];
             __threadfence_block();
             outpos += len;
+            {
+                // the LDS copy of the last kHist bytes, re-read from what was just written
+                const uint32_t nb2 = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
+                for (uint32_t k = nb2 + lane; k < outpos; k += 64) L.rb[k - nb2] = out[k];
+                wave_lds_sync();
+            }
             bp = (byte + len) * 8;
             continue;
         }
@@ -682,7 +702,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 B = B / 4 < 8 ? 8 : B / 4;                                    // extremely dense matches: shorter subsequences
                 continue;
             }
-            const uint32_t rb_base = outpos & ~3u;
+            const uint32_t rb_base = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
             bool far = false;
             PROF_ADD(3);  // scans / cut
             if (lane < take) far = parse_sub<true>(L, P.start, limit, outpos + cb - P.nbytes(), rb_base, cm - P.nmatch()).err() && !P.err();
@@ -694,13 +714,37 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 break;
             }
             const uint32_t add = __shfl(cb, take - 1, 64), nm = __shfl(cm, take - 1, 64);
-            resolve_matches(L, out, outpos, rb_base, nm, lane);
+#ifdef PNG_PROF
+            resolve_matches(L, out, rb_base, nm, lane, &_acc[13], &_acc[14]);
+#else
+            resolve_matches(L, out, rb_base, nm, lane);
+#endif
             PROF_ADD(5);  // matches
             PROF_CNT(12, nm);
-            flush_out(L, out, outpos, outpos + add, lane);
+            flush_out(L, out, outpos, outpos + add, rb_base, lane);
             __threadfence_block();                                           // later rounds read these bytes back
-            PROF_ADD(6);  // flush
             outpos += add;
+            {
+                // slide the window: the last kHist bytes stay in LDS at the base the next round will use
+                const uint32_t nb2 = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
+                const uint32_t shift = nb2 - rb_base, keep = (outpos - nb2 + 3) / 4;      // words; shift is a multiple of 4
+                if (shift) {
+                    uint32_t wv[(kHist + 4) / 4 / 64 + 1];
+#pragma unroll
+                    for (int i = 0; i < (int)((kHist + 4) / 4 / 64 + 1); i++) {
+                        const uint32_t wi = lane + 64 * i;
+                        wv[i] = wi < keep ? *reinterpret_cast<const uint32_t*>(&L.rb[shift + 4 * wi]) : 0u;
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int i = 0; i < (int)((kHist + 4) / 4 / 64 + 1); i++) {
+                        const uint32_t wi = lane + 64 * i;
+                        if (wi < keep) *reinterpret_cast<uint32_t*>(&L.rb[4 * wi]) = wv[i];
+                    }
+                    wave_lds_sync();
+                }
+            }
+            PROF_ADD(6);  // flush
             const bool t_eob = __shfl((int)P.eob(), take - 1, 64), t_err = __shfl((int)P.err(), take - 1, 64);
             bp = s0 + __shfl(P.exit, take - 1, 64);
             if (t_err || bp > total_bits) PNG_BAD(15);
@@ -718,12 +762,28 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
 
 // One wave per image: PNG 9.2 reconstruction.  Lane j takes rows j, j + 64, ...; it works one pixel behind lane j - 1
 // (lane 0 one pixel behind lane 63's previous row, kept in LDS), so the pixel above is the neighbour's last output.
+// A lane walks its row in blocks of 64 pixels, and the step loop only touches LDS:
+//   in   the filtered bytes of a block (and, in front of block 0, the row's filter-type byte) are fetched as aligned
+//        16-byte pieces TWO blocks ahead into registers and parked in the lane's LDS slot ONE block ahead, byte-shifted so
+//        that pixel data starts on a word -- all lanes at the same steps, so the one wait per 64 steps is for loads
+//        issued 64 steps earlier;
+//   out  a reconstructed byte overwrites the filtered byte it came from; two blocks later (every lane is done with the
+//        block by then) the 64 row segments leave as whole words, 256 contiguous bytes per store instruction.
+template <int BPP>
+struct UnfilterCfg {
+    static constexpr int kPieces = (3 + 1 + 64 * BPP + 15 + 15) / 16;   // 3 pad + the byte before + 64 pixels + misalignment
+    static constexpr int kWords = kPieces * 4;
+    static constexpr int kSlot = kPieces * 16;
+};
 template <int BPP>
 __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restrict__ raw, size_t raw_stride,
                                                          PngInfo* __restrict__ info, size_t n, uint32_t w, uint32_t h,
                                                          uint8_t* __restrict__ frames, size_t row_stride, size_t frame_stride,
                                                          int32_t* __restrict__ status) {
-    extern __shared__ uint8_t uprow[];      // w * BPP bytes: the last row lane 63 finished
+    using Cfg = UnfilterCfg<BPP>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint8_t* slots = lds_raw;                               // [2][64 lanes][kSlot]; byte 3 = the byte before the block, byte 4.. = its pixels
+    uint8_t* uprow = lds_raw + 2 * 64 * Cfg::kSlot;         // w * BPP bytes: the last row lane 63 finished
     const size_t img = blockIdx.x;
     if (img >= n) return;
     const int lane = threadIdx.x;
@@ -735,70 +795,131 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restr
     const uint8_t* src = raw + img * raw_stride;
     uint8_t* dst = frames + img * frame_stride;
     const uint32_t rowb = w * BPP;
-    const uint32_t W = w > 64 ? w : 64;                       // steps per row: lane 63 must be done with x before lane 0 needs it
+    const uint32_t W = ((w > 64 ? w : 64) + 63) & ~63u;       // steps per row: whole blocks, and lane 63 is done with x before lane 0 needs it
+    const uint32_t bpr = W / 64;                              // blocks per row
     const uint32_t rounds = (h + 63) / 64;
-    const uint32_t steps = rounds * W + 64;
+    const uint32_t nblocks = rounds * bpr;                    // lane-local blocks; the stagger adds one global block
     bool bad = false;
-    uint32_t a[BPP], b[BPP], c[BPP], prev_out[BPP];            // left, above, above-left, this lane's last output
+    uint32_t a[BPP], b[BPP], prev_out[BPP];                    // left, above (= the next step's above-left), this lane's last output
 #pragma unroll
-    for (int ch = 0; ch < BPP; ch++) a[ch] = b[ch] = c[ch] = prev_out[ch] = 0;
+    for (int ch = 0; ch < BPP; ch++) a[ch] = b[ch] = prev_out[ch] = 0;
     uint32_t ft = 0;
-    for (uint32_t t = 0; t < steps; t++) {
-        // what the lane above produced in the previous step (lane 0: lane 63's stored row)
-        uint32_t up[BPP];
+    uint32_t pre[Cfg::kWords + 1];                             // the block fetched ahead (+ one zero word for the funnel shift)
+    uint32_t pre_mis = 0;
+    auto fetch = [&](uint32_t bl) {                            // lane-local block bl -> registers
 #pragma unroll
-        for (int ch = 0; ch < BPP; ch++) up[ch] = __shfl_up(prev_out[ch], 1, 64);
-        const int tt = (int)t - lane;
-        const bool live = tt >= 0;
-        const uint32_t k = live ? (uint32_t)tt / W : 0, x = live ? (uint32_t)tt % W : 0;
-        const uint32_t row = k * 64 + lane;
-        const bool on = live && row < h && x < w;
-        if (on) {
-            const uint8_t* sp = src + (size_t)row * (rowb + 1);
-            if (x == 0) {
-                ft = sp[0];
-                if (ft > 4) bad = true;
+        for (int i = 0; i <= Cfg::kWords; i++) pre[i] = 0;
+        pre_mis = 0;
+        if (bl >= nblocks) return;
+        const uint32_t row = (bl / bpr) * 64 + lane, x0 = (bl % bpr) * 64;
+        if (row >= h || x0 >= w) return;
+        const uint8_t* rs = src + (size_t)row * (rowb + 1);
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(rs) + (size_t)x0 * BPP - 3;  // lands the byte before the block at slot byte 3
+        const uintptr_t base = addr & ~(uintptr_t)15, end = reinterpret_cast<uintptr_t>(rs) + rowb + 1;
+        pre_mis = (uint32_t)(addr & 15);
 #pragma unroll
-                for (int ch = 0; ch < BPP; ch++) a[ch] = c[ch] = 0;
-            } else {
-#pragma unroll
-                for (int ch = 0; ch < BPP; ch++) c[ch] = b[ch];
+        for (int p = 0; p < Cfg::kPieces; p++)
+            if (base + 16 * p < end) {                         // (the first piece of row 0 may start in the 16 bytes before the image: workspace)
+                const uint4 v = *reinterpret_cast<const uint4*>(base + 16 * p);
+                pre[4 * p] = v.x, pre[4 * p + 1] = v.y, pre[4 * p + 2] = v.z, pre[4 * p + 3] = v.w;
             }
+    };
+    const bool words_ok = (row_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
+    auto flush_block = [&](uint32_t bl) {
+        const uint32_t k = bl / bpr, x0 = (bl % bpr) * 64;
+        if (x0 >= w) return;
+        const uint32_t px = w - x0 < 64 ? w - x0 : 64, len = px * BPP;         // bytes per row segment
+        const uint8_t* t0 = slots + (size_t)(bl & 1) * 64 * Cfg::kSlot + 4;
+        const uint32_t wpr = words_ok ? len / 4 : 0;                           // <= 64: one word per lane and row
+        const uint32_t rows = h - k * 64 < 64 ? h - k * 64 : 64;
+        for (uint32_t r = 0; r < rows; r++) {
+            uint8_t* d = dst + (size_t)(k * 64 + r) * row_stride + (size_t)x0 * BPP;
+            const uint8_t* t = t0 + (size_t)r * Cfg::kSlot;
+            if ((uint32_t)lane < wpr) *reinterpret_cast<uint32_t*>(d + 4 * lane) = *reinterpret_cast<const uint32_t*>(t + 4 * lane);
+            for (uint32_t bi = 4 * wpr + lane; bi < len; bi += 64) d[bi] = t[bi];   // bytes the words did not cover
+        }
+    };
+    // the lane's own position (it starts `lane` steps late): block in its row, row group, slot parity
+    uint32_t xb = 0, kk = 0, par = 0, done_blocks = 0;
+    fetch(0);
+    for (uint32_t m = 0; m <= nblocks; m++) {
+        // block m - 2 is complete in every lane (lane 63 finished it 2 steps ago); its slot is the one block m parks in
+        if (m >= 2) flush_block(m - 2);
+        {
+            uint32_t* slot = reinterpret_cast<uint32_t*>(slots + ((m & 1) * 64 + lane) * Cfg::kSlot);
+            const uint32_t bsh = pre_mis & 3, dsh = pre_mis >> 2;
+#pragma unroll
+            for (int i = 0; i < Cfg::kWords; i++) {
+                const uint32_t v = __builtin_amdgcn_alignbyte(pre[i + 1], pre[i], bsh);
+                if ((uint32_t)i >= dsh) slot[i - dsh] = v;
+            }
+            fetch(m + 1);
+        }
+        wave_lds_fence();
+        for (uint32_t s = 0; s < 64; s++) {
+            const uint32_t t = m * 64 + s;
+            // what the lane above produced in the previous step (lane 0: lane 63's stored row)
+            uint32_t up[BPP];
+#pragma unroll
+            for (int ch = 0; ch < BPP; ch++) up[ch] = __shfl_up(prev_out[ch], 1, 64);
+            const int tt = (int)t - lane;
+            const bool live = tt >= 0;
+            const uint32_t xi = (uint32_t)tt & 63u;
+            const uint32_t x = xb * 64 + xi;
+            const uint32_t row = kk * 64 + lane;
+            const bool on = live && done_blocks < nblocks && row < h && x < w;
+            // Straight-line from here: every LDS read of the step is issued at once (idle lanes read their own slot's
+            // start), the four predictors are computed side by side and picked by the filter type with selects.  The
+            // branchy version spent the step in exec-mask bookkeeping and six serial LDS round trips.
+            uint8_t* sp = slots + (par * 64 + lane) * Cfg::kSlot + 3;               // sp[0]: the byte before the block
+            const uint32_t xr = on ? xi : 0, xu = on ? x : 0;
+            const uint32_t ftb = sp[0];
+            uint32_t v[BPP], ur[BPP];
 #pragma unroll
             for (int ch = 0; ch < BPP; ch++) {
-                if (row == 0) b[ch] = 0;
-                else if (lane == 0) b[ch] = uprow[x * BPP + ch];
-                else b[ch] = up[ch];
+                v[ch] = sp[1 + xr * BPP + ch];
+                ur[ch] = uprow[xu * BPP + ch];
             }
+            const bool first = x == 0;
+            ft = (on && first) ? ftb : ft;
+            if (on && first && ftb > 4) bad = true;
             uint32_t o[BPP];
 #pragma unroll
             for (int ch = 0; ch < BPP; ch++) {
-                const int v = sp[1 + x * BPP + ch];
-                const int A = (int)a[ch], Bv = (int)b[ch], C = (int)c[ch];
+                const int A = first ? 0 : (int)a[ch];
+                const int C = first ? 0 : (int)b[ch];                               // last step's "above" is this step's "above-left"
+                const int Bv = row == 0 ? 0 : (lane == 0 ? (int)ur[ch] : (int)up[ch]);
+                const int pp = A + Bv - C;
+                const int pa = pp > A ? pp - A : A - pp, pb = pp > Bv ? pp - Bv : Bv - pp, pc = pp > C ? pp - C : C - pp;
+                const int paeth = (pa <= pb && pa <= pc) ? A : (pb <= pc ? Bv : C);
                 int pred = 0;
-                if (ft == 1) pred = A;
-                else if (ft == 2) pred = Bv;
-                else if (ft == 3) pred = (A + Bv) >> 1;
-                else if (ft == 4) {
-                    const int p = A + Bv - C;
-                    const int pa = p > A ? p - A : A - p, pb = p > Bv ? p - Bv : Bv - p, pc = p > C ? p - C : C - p;
-                    pred = (pa <= pb && pa <= pc) ? A : (pb <= pc ? Bv : C);
+                pred = ft == 1 ? A : pred;
+                pred = ft == 2 ? Bv : pred;
+                pred = ft == 3 ? (A + Bv) >> 1 : pred;
+                pred = ft == 4 ? paeth : pred;
+                o[ch] = ((uint32_t)v[ch] + (uint32_t)pred) & 255u;
+                if (on) {
+                    b[ch] = (uint32_t)Bv;
+                    a[ch] = prev_out[ch] = o[ch];
                 }
-                o[ch] = (uint32_t)(v + pred) & 255u;
             }
-            uint8_t* dp = dst + (size_t)row * row_stride + (size_t)x * BPP;
+            if (on) {
 #pragma unroll
-            for (int ch = 0; ch < BPP; ch++) {
-                dp[ch] = (uint8_t)o[ch];
-                a[ch] = prev_out[ch] = o[ch];
-            }
-            if (lane == 63) {
+                for (int ch = 0; ch < BPP; ch++) sp[1 + xi * BPP + ch] = (uint8_t)o[ch];   // in place: the filtered byte is spent
+                if (lane == 63) {
 #pragma unroll
-                for (int ch = 0; ch < BPP; ch++) uprow[x * BPP + ch] = (uint8_t)o[ch];
+                    for (int ch = 0; ch < BPP; ch++) uprow[x * BPP + ch] = (uint8_t)o[ch];
+                }
             }
+            if (live && xi == 63) {                               // on to the lane's next block
+                done_blocks++;
+                par ^= 1;
+                if (++xb == bpr) xb = 0, kk++;
+            }
+            wave_lds_fence();
         }
-        wave_lds_fence();
     }
+    if (nblocks >= 1) flush_block(nblocks - 1);               // the loop flushed blocks 0 .. nblocks - 2
     const bool any_bad = __ballot(bad) != 0;
     if (lane == 0) {
         if (any_bad) info[img].status = UCFP_E_MODALITY;
@@ -866,8 +987,10 @@ int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uin
     hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info, ws + l.raw,
                        l.raw_stride, (uint32_t)l.raw_n);
     const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
-    const size_t lds = (size_t)w * bpp;
+    const size_t lds = (size_t)w * bpp + 2 * 64 * (size_t)((3 + 1 + 64 * bpp + 15 + 15) / 16) * 16;
     auto go = [&](auto kern) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, stream, ws + l.raw, l.raw_stride, info, n, w, h, frames,
                            row_stride, frame_stride, status);
     };

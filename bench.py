@@ -618,7 +618,8 @@ def bench_audio(args, rank, world, dev, ctx):
     ms = ev[0].elapsed_time(ev[1]) / steps
     nh = int(oo[1].item())
     # the reference's request shape: a corpus of 4-second clips at 8 kHz (benches/end_to_end.rs:55-75), one call
-    clip_n, n_clips = 4 * 8000, 8192
+    clip_n = 4 * 8000
+    n_clips = min(8192, n // clip_n)         # a reduced --audio-seconds holds fewer than 8192 clips' worth of samples
     xc = x[:n_clips * clip_n]
     coffs = (torch.arange(n_clips + 1, dtype=torch.int64, device=dev) * clip_n).contiguous()
     ccap = int(lib.ucfp_audio_wang_batch_max_hashes(n_clips * clip_n, n_clips, 8000, None))
@@ -860,6 +861,22 @@ def main():
     # ---- secondary leg: sharded Hamming ANN (frees the image batch first) ----
     del frames, out, status
     torch.cuda.empty_cache()
+    # At N > 1 the secondary legs below contain the only collectives of the run that go through the library's own RCCL
+    # communicator.  A rank that fails alone would leave the others waiting in a collective for ever and the driver
+    # without any line: a watchdog prints what has been measured (the headline above) and ends the rank instead.
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def _fire():
+            if rank == 0 and res is not None:
+                res["watchdog"] = ("a secondary leg did not finish within 600 s at N > 1; the line carries what was "
+                                   "measured before it")
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(600.0, _fire)
+        watchdog.daemon = True
+        watchdog.start()
     if args.ann_corpus > 0:
         # a failure of this secondary leg (e.g. the RCCL communicator cannot be created on this node) is REPORTED in
         # the line, it does not take the headline measurement above down with it; nothing is substituted for it
@@ -888,6 +905,8 @@ def main():
         if rank == 0:
             res["audio"] = r
         torch.cuda.empty_cache()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -141,11 +141,19 @@ int ucfp_image_png_decode_batch_dev(ucfp_ctx* ctx, const uint8_t* d_png, const u
                                     size_t png_bytes, uint32_t width, uint32_t height, int pixfmt, uint8_t* d_frames,
                                     size_t row_stride, size_t frame_stride, int32_t* d_status, void* stream);
 /* Encoded files -> records: decode into the context's workspace, then ucfp_image_hash_batch_dev's kernels.
- * d_exact as there (n x 32 bytes: BLAKE3 of each file, or NULL).  Records of files that did not decode are zero. */
+ * d_exact: n x 32 bytes, BLAKE3 of each file as computed by the host -- or NULL: the files are on the device, so their
+ * BLAKE3 is computed there (ucfp_blake3_batch_dev's kernel).  Records of files that did not decode are zero. */
 int ucfp_image_png_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_png, const uint64_t* d_offsets, size_t n,
                                   size_t png_bytes, uint32_t width, uint32_t height, int pixfmt,
                                   const ucfp_image_preprocess* pre, const uint8_t* d_exact, uint8_t* d_out,
                                   int32_t* d_status, void* stream);
+
+/* BLAKE3 (32-byte digests) of n byte strings that are already on the device: one blob + n + 1 byte offsets, like the
+ * text calls; blob_bytes = d_offsets[n]; the blob must be readable up to the next multiple of 4 bytes.  This is the
+ * records' `exact` field (image.rs:82: BLAKE3 of the upload) for uploads that were copied to the device encoded.
+ * Host-side single input: ucfp_blake3. */
+int ucfp_blake3_batch_dev(ucfp_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n, size_t blob_bytes,
+                          uint8_t* d_out, void* stream);
 
 /* Host micro-batcher: the caller side of handlers::ingest_image
  * (src/server/handlers.rs:232-302) hashes one image per request thread, up to 512 in flight

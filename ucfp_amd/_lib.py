@@ -154,6 +154,7 @@ SIGNATURES = {
     "ucfp_audio_haitsma_batch_max_frames": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_uint32]),
     "ucfp_audio_haitsma_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
                                                C.POINTER(HaitsmaConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ucfp_blake3_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                        C.c_uint32, C.c_size_t, C.c_void_p]),

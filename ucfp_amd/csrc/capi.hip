@@ -64,6 +64,9 @@ struct ucfp_ctx {
     uint8_t* png_ws = nullptr;
     size_t png_ws_cap = 0;
     hipEvent_t png_done = nullptr;
+    // BLAKE3 chaining values of the last batch (+ the digests when the PNG call computes `exact` itself); ordered by png_done
+    uint8_t* b3_ws = nullptr;
+    size_t b3_ws_cap = 0;
 };
 
 namespace {
@@ -154,6 +157,7 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->audio_done) (void)hipEventDestroy(c->audio_done);
     if (c->png_done) (void)hipEventDestroy(c->png_done);
     if (c->png_ws) (void)hipFree(c->png_ws);
+    if (c->b3_ws) (void)hipFree(c->b3_ws);
     if (c->norm_done) (void)hipEventDestroy(c->norm_done);
     delete c;
 }
@@ -194,6 +198,27 @@ int ucfp_image_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frame
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, frames, n, width, height, row_stride, frame_stride, pixfmt,
                                                  min_dim, max_dim, exact, out, status, (hipStream_t)stream));
+    return UCFP_OK;
+}
+
+// ---------------------------------- BLAKE3 on the device ----------------------------------------
+
+int ucfp_blake3_batch_dev(ucfp_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n, size_t blob_bytes,
+                          uint8_t* d_out, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (n == 0) return UCFP_OK;
+    if (!d_offsets || !d_out || (blob_bytes && !d_blob)) return fail(UCFP_E_INVALID, "NULL buffer");
+    if (n > 0x7fffffffu) return fail(UCFP_E_INVALID, "batch of %zu inputs exceeds one launch", n);
+    if ((uintptr_t)d_out & 3u) return fail(UCFP_E_INVALID, "the digest buffer must be 4-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = grow(&ctx->b3_ws, &ctx->b3_ws_cap, ucfp::blake3_ws_bytes(n, blob_bytes));
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, ctx->png_done, 0));
+    ucfp::launch_blake3_batch(d_blob, d_offsets, n, ctx->b3_ws, d_out, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->png_done, st));
     return UCFP_OK;
 }
 
@@ -289,6 +314,14 @@ int ucfp_image_png_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d
     uint8_t* fr = nullptr;
     rc = png_decode_impl(ctx, d_png, d_offsets, n, png_bytes, width, height, pixfmt, nullptr, row, frame, nullptr, st, &l, &fr);
     if (rc) return rc;
+    if (!d_exact) {
+        // the files are here: their BLAKE3 (the records' `exact` field, image.rs:82) is computed on the device too
+        const size_t cvb = (ucfp::blake3_ws_bytes(n, png_bytes) + 255) & ~(size_t)255;
+        rc = grow(&ctx->b3_ws, &ctx->b3_ws_cap, cvb + n * 32);
+        if (rc) return rc;
+        ucfp::launch_blake3_batch(d_png, d_offsets, n, ctx->b3_ws, ctx->b3_ws + cvb, st);
+        d_exact = ctx->b3_ws + cvb;
+    }
     HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, fr, n, width, height, row, frame, pixfmt, min_dim, max_dim, d_exact,
                                                  d_out, d_status, st));
     ucfp::launch_png_merge_status(ctx->png_ws, l, n, d_out, (uint32_t)rec, d_status, st);

@@ -34,6 +34,10 @@ int launch_image_record_codes(const uint8_t* records, size_t n, uint32_t rec_byt
 int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,
                        hipStream_t stream);
 
+// blake3.hip
+size_t blake3_ws_bytes(size_t n, size_t blob_bytes);
+int launch_blake3_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, uint8_t* ws, uint8_t* out, hipStream_t stream);
+
 // png.hip
 struct PngWs {
     size_t zbuf = 0, info = 0, raw = 0, raw_stride = 0, raw_n = 0, total = 0;

@@ -20,8 +20,8 @@
 //                 outputs (a diagonal wavefront, 64 rows in flight).
 //
 // Scope: 8-bit greyscale / RGB / RGBA, non-interlaced, no tRNS -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
-// the host's decoder (like non-ASCII text).  Chunk CRCs and the Adler-32 trailer are NOT verified on the device (a
-// damaged file that still inflates to exactly height x (1 + row bytes) is hashed, where the reference rejects it).
+// the host's decoder (like non-ASCII text).  The Adler-32 trailer is verified; chunk CRCs are NOT (a file damaged outside
+// its IDAT payload -- in an ancillary chunk, say -- is hashed, where the reference rejects it).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -371,6 +371,30 @@ __device__ void resolve_matches(InflateLds& L, const uint8_t* out, uint32_t rb_b
     }
 }
 
+// Adler-32 (RFC 1950) over the stream as it is produced: (a, b) after m more bytes d_0 .. d_{m-1} is
+// a + S1, b + m a + S2 with S1 = sum d_j, S2 = sum (m - j) d_j; the lanes take every 64th byte, m <= 4096 keeps S2 below 2^32.
+struct Adler {
+    uint32_t a = 1, b = 0;
+    template <class F>
+    __device__ __forceinline__ void add(uint32_t m, F&& byte_at, int lane) {
+        uint32_t s1 = 0, s2 = 0;
+        for (uint32_t j = lane; j < m; j += 64) {
+            const uint32_t d = byte_at(j);
+            s1 += d;
+            s2 += (m - j) * d;
+        }
+        uint64_t t1 = s1, t2 = s2;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            t1 += __shfl_xor(t1, o, 64);
+            t2 += __shfl_xor(t2, o, 64);
+        }
+        b = (uint32_t)((b + (uint64_t)m * a + t2) % 65521u);
+        a = (uint32_t)((a + t1) % 65521u);
+    }
+    __device__ __forceinline__ uint32_t value() const { return b << 16 | a; }
+};
+
 struct PngInfo {
     uint32_t zlen;      // bytes of the gathered zlib stream
     int32_t status;
@@ -476,6 +500,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
     uint32_t bp = 16, outpos = 0;
     bool last = false;
     int B = kMaxB;
+    Adler adler;
 #ifdef PNG_PROF
     unsigned long long _acc[16] = {0};
 #endif
@@ -504,6 +529,10 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 break;
             }
             for (uint32_t k = lane; k < len; k += 64) out[outpos + k] = z[byte + k];
+            for (uint32_t p0 = 0; p0 < len; p0 += 4096) {
+                const uint32_t m = len - p0 < 4096 ? len - p0 : 4096;
+                adler.add(m, [&](uint32_t j) { return (uint32_t)z[byte + p0 + j]; }, lane);
+            }
             __threadfence_block();
             outpos += len;
             {
@@ -722,6 +751,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             PROF_ADD(5);  // matches
             PROF_CNT(12, nm);
             flush_out(L, out, outpos, outpos + add, rb_base, lane);
+            adler.add(add, [&](uint32_t j) { return (uint32_t)L.rb[outpos + j - rb_base]; }, lane);
             __threadfence_block();                                           // later rounds read these bytes back
             outpos += add;
             {
@@ -753,6 +783,12 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
         }
     }
     if (!bad && outpos != raw_n) PNG_BAD(16);
+    if (!bad) {
+        // the Adler-32 of the output follows the deflate data at the next byte boundary, most significant byte first
+        const uint32_t e = (bp + 7) / 8;
+        if (e + 4 > zlen) PNG_BAD(17);
+        else if (((uint32_t)z[e] << 24 | (uint32_t)z[e + 1] << 16 | (uint32_t)z[e + 2] << 8 | z[e + 3]) != adler.value()) PNG_BAD(18);
+    }
 #ifdef PNG_PROF
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&g_png_prof[i], _acc[i]);

@@ -553,3 +553,37 @@ def test_sharded_submit_collect_two_in_flight(gpu_ctx, oracle, torch_cuda):
         assert np.array_equal(g_ids.cpu().numpy().view(np.uint64), o_ids)
         assert np.array_equal(g_keys.cpu().numpy().view(np.uint32), o_d)
         assert (g_cnt.cpu().numpy() == k).all()
+
+
+@pytest.mark.parametrize("order", ["ascending", "ascending_blocks", "descending", "shuffled", "one_inversion"])
+@pytest.mark.parametrize("nq", [7, 200])
+def test_hamming_strict_thresholds_only_when_ids_ascend(gpu_ctx, oracle, order, nq):
+    """An APPEND_ONLY shard tracks on the device whether its ids ascend with the row number; if they do, the stages after
+    the first filter with d < (k-th distance) instead of <= (a later row cannot win a tie).  Heavy ties make the
+    difference visible: codes drawn from 300 values, so whole plateaus of equal distance straddle every threshold.  Ids in
+    any other order must keep the non-strict filter -- the answer is the oracle's in every case."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(len(order) * 31 + nq)
+    n, k = 700_000, 10
+    palette = rng.integers(0, 2**64, 300, dtype=np.uint64)
+    codes = palette[rng.integers(0, 300, n)]
+    queries = palette[rng.integers(0, 300, nq)] ^ (np.uint64(1) << rng.integers(0, 64, nq).astype(np.uint64))
+    if order in ("ascending", "ascending_blocks"):
+        ids = np.cumsum(rng.integers(1, 5, n)).astype(np.uint64)
+    elif order == "descending":
+        ids = np.arange(n, 0, -1).astype(np.uint64) * 3
+    elif order == "shuffled":
+        ids = rng.permutation(n).astype(np.uint64) + 5
+    else:
+        ids = np.cumsum(rng.integers(1, 5, n)).astype(np.uint64)
+        ids[n - 1000], ids[n - 999] = ids[n - 999], ids[n - 1000]          # a single swap far into the corpus
+    ix = index.DeviceIndex(index.HAMMING64, 0, index.APPEND_ONLY, gpu_ctx)
+    if order == "ascending_blocks":                                         # several appends: the seam between blocks is checked too
+        for a, b in ((0, 1), (1, 300_001), (300_001, n)):
+            ix.upsert(0, ids[a:b], codes[a:b])
+    else:
+        ix.upsert(0, ids, codes)
+    g_ids, _, g_d, g_c = ix.search(0, queries, k)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+    assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids)
+    ix.close()

@@ -73,7 +73,11 @@ size_t hamming_workspace_bytes(const HammingPlan& p, uint32_t nq, uint32_t k);
 int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                           const uint64_t* queries, uint32_t nq, uint32_t k, uint8_t* ws,
                           const HammingPlan& p, uint64_t* out_ids, uint32_t* out_dist,
-                          float* out_scores, uint32_t* out_cnt, hipStream_t stream);
+                          float* out_scores, uint32_t* out_cnt, hipStream_t stream,
+                          const uint32_t* ids_ascending = nullptr);
+// ids_ascending: device word, non-zero while the shard's record ids ascend with the row number (kept by
+// launch_ids_order_update for append-only shards): later stages may then use strict thresholds (hamming_list_tau)
+int launch_ids_order_update(const uint64_t* ids, size_t n, bool first, uint32_t* state, hipStream_t stream);
 int launch_hamming_scores(const uint32_t* dist, size_t total, float* scores, hipStream_t stream);
 
 // topk.hip

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void hamming_scan_lanes(
 __global__ __launch_bounds__(64) void hamming_list_tau(const uint32_t* __restrict__ cand_cnt,
                                                        const uint32_t* __restrict__ cand_d, uint32_t cand_cap,
                                                        uint32_t k, const uint32_t* __restrict__ tau0,
-                                                       uint32_t* __restrict__ tau1) {
+                                                       uint32_t* __restrict__ tau1, const uint32_t* __restrict__ ids_ascending) {
     __shared__ uint32_t h[65];
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
@@ -670,7 +670,10 @@ __global__ __launch_bounds__(64) void hamming_list_tau(const uint32_t* __restric
         for (uint32_t b = 0; b < 65; b++) {
             cum += h[b];
             if (cum >= k) {
-                t = b;
+                // b is the distance of the k-th best (d, id) so far.  Where record ids ascend with the row number, every
+                // row still to come has a larger id than the current k-th, so a tie at distance b cannot displace it:
+                // only d < b can still enter.  That cuts the fat boundary bin -- most of a stage's suspects -- away.
+                t = (ids_ascending && *ids_ascending && b > 0) ? b - 1 : b;
                 break;
             }
         }
@@ -801,6 +804,27 @@ void slice_range(size_t n, uint32_t qgroups, uint32_t want_waves, size_t min_per
 }
 }  // namespace
 
+// state[0] = 1 while the record ids of a shard ascend with the row number; state[2..3] = the last id (u64).
+// Called for every appended block (`first`: the shard was empty); rows are only ever appended to such a shard.
+__global__ void ids_order_update_kernel(const uint64_t* __restrict__ ids, size_t n, bool first, uint32_t* __restrict__ state) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t* last = reinterpret_cast<uint64_t*>(state + 2);
+    bool ok;
+    if (i == 0) ok = first || ids[0] > *last;
+    else ok = ids[i] > ids[i - 1];
+    if (!ok) state[0] = 0;
+}
+__global__ void ids_order_last_kernel(const uint64_t* __restrict__ ids, size_t n, uint32_t* __restrict__ state) {
+    *reinterpret_cast<uint64_t*>(state + 2) = ids[n - 1];
+}
+int launch_ids_order_update(const uint64_t* ids, size_t n, bool first, uint32_t* state, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ids_order_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, n, first, state);
+    hipLaunchKernelGGL(ids_order_last_kernel, dim3(1), dim3(1), 0, stream, ids, n, state);
+    return 0;
+}
+
 HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     HammingPlan p;
     p.qgroups = (nq + kWave - 1) / kWave;
@@ -822,7 +846,11 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         size_t e = p.sample_n;
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
         // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs)
+#ifdef EXP_HAMMING_GROWTH
+        constexpr size_t growth = EXP_HAMMING_GROWTH;
+#else
         constexpr size_t growth = 4;
+#endif
         while (e < n && p.nstages < 12) {
             e = e * growth < n ? e * growth : n;
             p.stage_end[p.nstages++] = e;
@@ -882,7 +910,7 @@ size_t hamming_workspace_bytes(const HammingPlan& p, uint32_t nq, uint32_t k) {
 int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                           const uint64_t* queries, uint32_t nq, uint32_t k, uint8_t* ws,
                           const HammingPlan& p, uint64_t* out_ids, uint32_t* out_dist,
-                          float* out_scores, uint32_t* out_cnt, hipStream_t stream) {
+                          float* out_scores, uint32_t* out_cnt, hipStream_t stream, const uint32_t* ids_ascending) {
     if (nq == 0) return 0;
     if (nq > kHammingMaxBatch) return -1;   // callers chunk (index.hip)
     const HammingWs w = hamming_ws_layout(p, nq, k);
@@ -961,7 +989,8 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             }
             if (sidx + 1 < p.nstages) {
                 hipLaunchKernelGGL(hamming_list_tau, dim3(nq), dim3(64), 0, stream, (const uint32_t*)u32(w.cand_cnt),
-                                   (const uint32_t*)u32(w.cand_d), p.cand_cap, k, (const uint32_t*)tau_cur, tau_nxt);
+                                   (const uint32_t*)u32(w.cand_d), p.cand_cap, k, (const uint32_t*)tau_cur, tau_nxt,
+                                   ids_ascending);
                 uint32_t* t = tau_cur;
                 tau_cur = tau_nxt;
                 tau_nxt = t;

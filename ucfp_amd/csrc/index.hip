@@ -66,6 +66,7 @@ struct Shard {
     size_t n = 0, cap = 0;
     std::unordered_map<uint64_t, size_t> pos;  // id -> row (unless APPEND_ONLY)
     std::vector<uint64_t> host_ids;            // row -> id (unless APPEND_ONLY)
+    uint32_t* order = nullptr;                 // APPEND_ONLY Hamming shards: [0] = 1 while ids ascend with the row, [2..3] = last id
 };
 
 __global__ void scatter_rows_kernel(const uint64_t* __restrict__ src_ids, const uint8_t* __restrict__ src_rows,
@@ -85,6 +86,15 @@ __global__ void gather_norms_kernel(const float* __restrict__ src, const uint64_
                                     float* __restrict__ norms) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) norms[dst_row[i]] = src[i];
+}
+
+// APPEND_ONLY Hamming shards keep, on the device, whether their ids ascend with the row number (ucfp::launch_ids_order_update).
+int ensure_order_state(Shard& s, hipStream_t st) {
+    if (s.order) return 0;
+    if (hipMalloc((void**)&s.order, 16) != hipSuccess) return -1;
+    static const uint32_t init[4] = {1u, 0u, 0u, 0u};
+    if (hipMemcpyAsync(s.order, init, 16, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    return 0;
 }
 
 }  // namespace
@@ -175,7 +185,8 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
             if (cn != chunk) p = ucfp::hamming_plan(n, cn, k);
             ucfp::launch_hamming_search(s ? reinterpret_cast<const uint64_t*>(s->rows) : nullptr, s ? s->ids : nullptr,
                                         n, dq + c0, cn, k, ix->ws.p, p, d_out_ids + c0 * k, keys + c0 * k,
-                                        d_out_scores ? d_out_scores + c0 * k : nullptr, d_out_cnt + c0, st);
+                                        d_out_scores ? d_out_scores + c0 * k : nullptr, d_out_cnt + c0, st,
+                                        s ? s->order : nullptr);
         }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -367,6 +378,7 @@ void ucfp_index_destroy(ucfp_index* ix) {
         if (kv.second.ids) (void)hipFree(kv.second.ids);
         if (kv.second.rows) (void)hipFree(kv.second.rows);
         if (kv.second.norms) (void)hipFree(kv.second.norms);
+        if (kv.second.order) (void)hipFree(kv.second.order);
     }
     ix->ws.release();
     ix->stage.release();
@@ -440,6 +452,10 @@ int ucfp_index_upsert(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, cons
                            reinterpret_cast<const float*>(sp + o_norm), reinterpret_cast<const uint64_t*>(sp + o_dst),
                            m, s.norms);
     }
+    if (!mapped && ix->kind == UCFP_INDEX_HAMMING64 && m) {      // appended rows [s.n, new_n), in order
+        if (ensure_order_state(s, st)) return capi_fail(UCFP_E_INDEX, "out of device memory");
+        ucfp::launch_ids_order_update(s.ids + s.n, m, s.n == 0, s.order, st);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ix->data_ready, st));
     HIP_TRY(hipStreamSynchronize(st));  // staging vectors are stack-owned
@@ -471,6 +487,12 @@ int ucfp_index_append_dev(ucfp_index* ix, uint32_t tenant, const uint64_t* d_ids
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(s.ids + s.n, d_ids, n * 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.rows + s.n * ix->row_bytes, d_rows, n * ix->row_bytes, hipMemcpyDeviceToDevice, st));
+    if (ix->kind == UCFP_INDEX_HAMMING64) {
+        // rows are only ever appended here: keep track, on the device, of whether the ids ascend with the row number
+        // (they do for a bulk-loaded corpus); the staged Hamming search then tightens its thresholds (hamming_list_tau)
+        if (ensure_order_state(s, st)) return capi_fail(UCFP_E_INDEX, "out of device memory");
+        ucfp::launch_ids_order_update(s.ids + s.n, n, s.n == 0, s.order, st);
+    }
     if (ix->kind == UCFP_INDEX_COSINE_F32)
         ucfp::launch_cosine_norms(reinterpret_cast<const float*>(s.rows + s.n * ix->row_bytes), n, ix->dim,
                                   s.norms + s.n, st);

@@ -166,7 +166,10 @@ def test_upsert_overwrite_delete_tenants(gpu_ctx, oracle):
                                         # one to four queries over >= 4096 rows: the row-streaming kernel (1-4
                                         # 256-dim blocks per lane, ragged last block, ragged last row group)
                                         (6001, 768, 1, 10), (5003, 384, 2, 10), (4099, 1024, 4, 5), (7000, 100, 3, 10),
-                                        (4097, 256, 1, 1), (9000, 260, 4, 20)])
+                                        (4097, 256, 1, 1), (9000, 260, 4, 20),
+                                        # 5 .. 16 queries over wide rows: the 4x4x1 row-stream kernel
+                                        (20011, 768, 16, 10), (9001, 512, 5, 1), (12345, 1024, 9, 16), (8200, 640, 12, 17),
+                                        (4100, 768, 7, 3), (70001, 768, 16, 10)])
 def test_cosine_matches_oracle(gpu_ctx, oracle, n, dim, nq, k):
     from ucfp_amd import index
     rng = np.random.default_rng(n + dim)
@@ -586,4 +589,25 @@ def test_hamming_strict_thresholds_only_when_ids_ascend(gpu_ctx, oracle, order, 
     g_ids, _, g_d, g_c = ix.search(0, queries, k)
     o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
     assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids)
+    ix.close()
+
+
+def test_cosine_duplicate_rows_and_any_id_order(gpu_ctx, oracle):
+    """Ties are broken by record id: a corpus where every row exists in many copies (equal keys everywhere, ids in random
+    order) must return the k smallest ids of the best rows (8 queries over 768-d rows: the 4x4x1 row-stream kernel)."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(99)
+    base = rng.standard_normal((40, 768)).astype(np.float32)
+    n = 30_000
+    pick = rng.integers(0, 40, n)
+    rows = base[pick].copy()
+    ids = rng.permutation(n).astype(np.uint64) * np.uint64(7) + np.uint64(3)
+    queries = (base[:8] + 0.01 * rng.standard_normal((8, 768))).astype(np.float32)
+    ix = index.DeviceIndex(index.COSINE_F32, 768, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = ix.search(0, queries, 10)
+    for q in range(8):
+        best = np.sort(ids[pick == q])[:10]        # all copies of base[q] score the same, far above the rest
+        assert g_c[q] == 10 and np.array_equal(g_ids[q], best), q
+        assert np.all(g_sc[q] > 0.99)
     ix.close()

@@ -34,11 +34,18 @@ namespace ucfp {
 namespace {
 
 constexpr int kRoot = 10, kDRoot = 8;                  // bits indexed by the first-level tables
-constexpr uint32_t kIterOut = 4096;                    // output bytes one speculation round may add
-constexpr uint32_t kMatchCap = 1024;                   // matches listed per round
+// Two shapes of a speculation round.  Wide rounds (256-bit subsequences) resynchronise more often inside a subsequence
+// -- 3.3 instead of 4.3 parses per subsequence on the match-heavy config-1 files -- and halve the per-round overhead,
+// but their buffers take 30 KiB of LDS per wave instead of 17.5: right for a batch that cannot fill the chip anyway
+// (1000 files: +19 %), wrong for a large one (8000 files: -20 %).  launch_png_decode picks by batch size.
+template <int BITS>
+struct RoundCfg {
+    static constexpr int kMaxB = BITS;                                     // bits per subsequence
+    static constexpr uint32_t kIterOut = BITS == 256 ? 8192 : 4096;        // output bytes one round may add
+    static constexpr uint32_t kMatchCap = BITS == 256 ? 2048 : 1024;       // matches listed per round
+    static constexpr int kStageWords = BITS * 2 + 32;                      // 64 subsequences + overshoot + the fetch window
+};
 constexpr uint32_t kHist = 2048;                       // bytes of earlier rounds kept in LDS: a match one image row back (the common distance) never leaves the CU
-constexpr int kStageWords = 288;                       // compressed words staged per round: 64 x 128 bits + overshoot + refill
-constexpr int kMaxB = 128;                             // bits per subsequence
 
 // table entries: value (literal / length base / distance base) | extra bits << 16 | code length << 20 | kind << 24
 constexpr uint32_t kLit = 0, kLen = 1, kEob = 2, kSlow = 3;
@@ -47,18 +54,19 @@ constexpr uint32_t kInvalid = kSlow << 24;             // code length 0: resolve
 // The deflate window is the image itself: bytes of earlier rounds are read back from frame memory (this wave wrote
 // them; a workgroup-scope fence orders the stores before the loads), only the round in flight lives in LDS.  ~15 KiB
 // per wave instead of 48: ten waves per CU hide each other's LDS latency.
+template <class C>
 struct InflateLds {
     uint32_t lit[1 << kRoot];
     uint32_t dst[1 << kDRoot];
-    uint32_t stage[kStageWords];
-    uint32_t m_dst[kMatchCap];
-    uint32_t m_ld[kMatchCap];                          // len << 16 | (dist - 1)
+    uint32_t stage[C::kStageWords];
+    uint32_t m_dst[C::kMatchCap];
+    uint32_t m_ld[C::kMatchCap];                          // len << 16 | (dist - 1)
     uint16_t ll_sorted[288];
     uint16_t d_sorted[32];
     uint16_t ll_count[16];
     uint16_t d_count[16];
     uint8_t lens[320];
-    uint8_t rb[kHist + kIterOut + 8];                  // the last kHist bytes of earlier rounds + this round's output; rb[0] is stream position rb_base
+    uint8_t rb[kHist + C::kIterOut + 8];                  // the last kHist bytes of earlier rounds + this round's output; rb[0] is stream position rb_base
 };
 
 __device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t len) {
@@ -210,8 +218,8 @@ struct Parse {
 // its start position, and literal / length / distance handling are selects, not branches -- nested divergent regions
 // cost more in exec-mask bookkeeping and serial LDS waits than the work they skip.  One 64-bit window of the stream per
 // symbol (three words, one LDS round trip) serves both the literal/length code and the distance code behind it.
-template <bool EMIT>
-__device__ __forceinline__ Parse parse_sub(InflateLds& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint32_t rb_base,
+template <bool EMIT, class C>
+__device__ __forceinline__ Parse parse_sub(InflateLds<C>& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint32_t rb_base,
                                            uint32_t m_idx) {
     uint32_t pos = start, nb = 0, nm = 0, flags = 0;
     bool act = pos < limit;
@@ -248,7 +256,7 @@ __device__ __forceinline__ Parse parse_sub(InflateLds& L, uint32_t start, uint32
             if (go && is_len) {
                 if (dist > out_pos + nb) flags |= 2u;
                 const uint32_t mi = m_idx + nm;
-                if (mi < kMatchCap) {
+                if (mi < C::kMatchCap) {
                     L.m_dst[mi] = out_pos + nb;
                     L.m_ld[mi] = len << 16 | (dist - 1);
                 }
@@ -301,16 +309,18 @@ __device__ __forceinline__ uint32_t peek_u(const uint32_t* stage, uint32_t pos, 
 }
 
 // Stages kStageWords words of the stream starting at the word that holds bit `bp`; returns that word's bit offset.
-__device__ __forceinline__ uint32_t stage_load(InflateLds& L, const uint8_t* z, uint32_t zwords, uint32_t bp, int lane) {
+template <class C>
+__device__ __forceinline__ uint32_t stage_load(InflateLds<C>& L, const uint8_t* z, uint32_t zwords, uint32_t bp, int lane) {
     const uint32_t w0 = bp >> 5;
     const uint32_t* zw = reinterpret_cast<const uint32_t*>(z);
-    for (int i = lane; i < kStageWords; i += 64) L.stage[i] = (w0 + i < zwords) ? zw[w0 + i] : 0u;
+    for (int i = lane; i < C::kStageWords; i += 64) L.stage[i] = (w0 + i < zwords) ? zw[w0 + i] : 0u;
     wave_lds_sync();
     return w0 << 5;
 }
 
 // Round buffer -> frame memory for [from, to); rb[0] is position `base` (a multiple of 4), so whole words line up.
-__device__ __forceinline__ void flush_out(const InflateLds& L, uint8_t* out, uint32_t from, uint32_t to, uint32_t base, int lane) {
+template <class C>
+__device__ __forceinline__ void flush_out(const InflateLds<C>& L, uint8_t* out, uint32_t from, uint32_t to, uint32_t base, int lane) {
     uint32_t p = from;
     const uint32_t head = (4 - (p & 3)) & 3;
     if (lane < (int)head && p + lane < to) out[p + lane] = L.rb[p + lane - base];
@@ -324,12 +334,14 @@ __device__ __forceinline__ void flush_out(const InflateLds& L, uint8_t* out, uin
 }
 
 // A byte of the stream: from the round buffer (this round and the kHist bytes before it), or from frame memory.
-__device__ __forceinline__ uint8_t window_byte(const InflateLds& L, const uint8_t* out, uint32_t p, uint32_t rb_base) {
+template <class C>
+__device__ __forceinline__ uint8_t window_byte(const InflateLds<C>& L, const uint8_t* out, uint32_t p, uint32_t rb_base) {
     return p >= rb_base ? L.rb[p - rb_base] : out[p];
 }
 
 // Resolves the listed matches in stream order.  All literals of the round are already in the round buffer.
-__device__ void resolve_matches(InflateLds& L, const uint8_t* out, uint32_t rb_base, uint32_t total, int lane,
+template <class C>
+__device__ void resolve_matches(InflateLds<C>& L, const uint8_t* out, uint32_t rb_base, uint32_t total, int lane,
                                 unsigned long long* rounds = nullptr, unsigned long long* coop = nullptr) {
     for (uint32_t g0 = 0; g0 < total; g0 += 64) {
         const uint32_t mi = g0 + lane;
@@ -480,10 +492,11 @@ __device__ unsigned long long g_png_prof[16];
 #define PNG_BAD(code) (bad = true)
 #endif
 // One wave per image: zlib stream -> filtered scanlines (raw_n bytes expected).
+template <class C>
 __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets,
                                                         size_t n, PngInfo* __restrict__ info, uint8_t* __restrict__ raw,
                                                         size_t raw_stride, uint32_t raw_n) {
-    __shared__ InflateLds L;
+    __shared__ InflateLds<C> L;
     const size_t img = blockIdx.x;
     if (img >= n) return;
     const int lane = threadIdx.x;
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
     }
     uint32_t bp = 16, outpos = 0;
     bool last = false;
-    int B = kMaxB;
+    int B = C::kMaxB;
     Adler adler;
 #ifdef PNG_PROF
     unsigned long long _acc[16] = {0};
@@ -604,7 +617,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             uint32_t idx = 0, prev = 0;
             const uint32_t want = nlen + ndist;
             while (idx < want) {
-                if (rel + 14 > (uint32_t)(kStageWords - 2) * 32) {   // a header is at most ~4.5 kbit: cannot happen in a valid stream
+                if (rel + 14 > (uint32_t)(C::kStageWords - 2) * 32) {   // a header is at most ~4.5 kbit: cannot happen in a valid stream
                     PNG_BAD(6);
                     break;
                 }
@@ -697,7 +710,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 if (__ballot(miss)) {
                     PROF_CNT(10, 1);
                     if (miss) {
-                        P = parse_sub<false>(L, start, limit, 0, 0, 0);
+                        P = parse_sub<false, C>(L, start, limit, 0, 0, 0);
                         cache.put(P);
                     }
                 }
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             // how many of the confirmed lanes fit this round's buffer and match list
             const bool in = lane < nvalid;
             const uint32_t cb = wave_incl_scan(in ? P.nbytes() : 0, lane), cm = wave_incl_scan(in ? P.nmatch() : 0, lane);
-            const bool fits = in && cb <= kIterOut && cm <= kMatchCap && outpos + cb <= raw_n;
+            const bool fits = in && cb <= C::kIterOut && cm <= C::kMatchCap && outpos + cb <= raw_n;
             const int take = __popcll(__ballot(fits));                        // a prefix: the sums are monotonic
             if (take == 0) {
                 const uint32_t b0 = __shfl(P.nbytes(), 0, 64);
@@ -734,7 +747,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             const uint32_t rb_base = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
             bool far = false;
             PROF_ADD(3);  // scans / cut
-            if (lane < take) far = parse_sub<true>(L, P.start, limit, outpos + cb - P.nbytes(), rb_base, cm - P.nmatch()).err() && !P.err();
+            if (lane < take) far = parse_sub<true, C>(L, P.start, limit, outpos + cb - P.nbytes(), rb_base, cm - P.nmatch()).err() && !P.err();
             wave_lds_sync();
             PROF_ADD(4);  // emit
             PROF_CNT(11, take);
@@ -779,7 +792,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             bp = s0 + __shfl(P.exit, take - 1, 64);
             if (t_err || bp > total_bits) PNG_BAD(15);
             eob = t_eob;
-            if (take == 64 && add < kIterOut / 4 && B < kMaxB) B *= 2;
+            if (take == 64 && add < C::kIterOut / 4 && B < C::kMaxB) B *= 2;
         }
     }
     if (!bad && outpos != raw_n) PNG_BAD(16);
@@ -1020,8 +1033,15 @@ int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uin
     if (n == 0) return 0;
     PngInfo* info = reinterpret_cast<PngInfo*>(ws + l.info);
     hipLaunchKernelGGL(png_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, png, offsets, n, w, h, pixfmt, ws + l.zbuf, info);
-    hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info, ws + l.raw,
-                       l.raw_stride, (uint32_t)l.raw_n);
+    // wide rounds while the batch leaves most of the chip's wave slots empty anyway (RoundCfg)
+    // measured (files/s, narrow | wide): 600: 83 k | 98 k, 1000: 130 k | 157 k, 1400: 162 k | 118 k, 2000: 141 k | 160 k,
+    // 3000: 189 k | 164 k -- the chip holds about 1024 wide or 1536 narrow waves at a time
+    if (n <= 1024 || (n > 1536 && n <= 2048))
+        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<256>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
+                           ws + l.raw, l.raw_stride, (uint32_t)l.raw_n);
+    else
+        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<128>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
+                           ws + l.raw, l.raw_stride, (uint32_t)l.raw_n);
     const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
     const size_t lds = (size_t)w * bpp + 2 * 64 * (size_t)((3 + 1 + 64 * bpp + 15 + 15) / 16) * 16;
     auto go = [&](auto kern) {

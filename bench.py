@@ -180,6 +180,28 @@ def bench_config1_phash_png(dev, ctx, n_img=1000):
         go_png()
     torch.cuda.synchronize()
     t_png_h2d = (time.perf_counter() - t0) / 10
+    # ... and with the copy of batch i + 1 under the decode of batch i (two device blobs, a copy and a compute stream)
+    blobs = [d_blob, torch.empty_like(d_blob)]
+    s_copy, s_comp = torch.cuda.Stream(), torch.cuda.Stream()
+    done = [None, None]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20):
+        b = blobs[i & 1]
+        with torch.cuda.stream(s_copy):
+            if done[i & 1] is not None:
+                s_copy.wait_event(done[i & 1])
+            b.copy_(h_blob, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(s_copy)
+        s_comp.wait_event(ev)
+        image.fingerprint_pngs_dev(b.data_ptr(), d_off.data_ptr(), n_img, png_bytes, side, side, image.PIX_RGB8,
+                                   algo=image.PHASH, out_ptr=d_out2.data_ptr(), status_ptr=d_st.data_ptr(),
+                                   stream=s_comp.cuda_stream, ctx=ctx)
+        done[i & 1] = torch.cuda.Event()
+        done[i & 1].record(s_comp)
+    torch.cuda.synchronize()
+    t_png_pipe = (time.perf_counter() - t0) / 20
     return {
         "workload": f"{n_img} synthetic 256x256 RGB PNGs, ?algorithm=phash (168-B records)",
         "cpu": {"kind": "port", **host_cpu(), "threads": cores,
@@ -192,6 +214,7 @@ def bench_config1_phash_png(dev, ctx, n_img=1000):
                                        and np.array_equal(d_out.cpu().numpy(), ref)),
                 "png_front_end": {"images_per_s_encoded_bytes_resident": n_img / t_png,
                                   "images_per_s_incl_h2d_of_encoded_bytes": n_img / t_png_h2d,
+                                  "images_per_s_incl_h2d_next_batch_copied_under_decode": n_img / t_png_pipe,
                                   "png_bytes_per_image": png_bytes / n_img, "records_match_oracle": png_ok}},
         "gpu_hash_over_cpu_hash_all_cores": (n_img / t_gd) / (n_img / t_hn),
         "gpu_png_front_end_over_cpu_decode_plus_hash_1_thread": (n_img / t_png_h2d) / (n_img / (t_dec + t_h1)),

@@ -833,7 +833,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     // sample: the first 32k codes. A lane then accepts ~k*n/sample items over the robust range,
     // i.e. a wave leaves its fast path on ~64*k/sample = 2 % of the codes (k = 10).  (Sizing the sample so that a
     // whole number of 4x stages ends exactly at n -- one stage fewer at 10 M and 12.5 M -- measured the same.)
-    size_t s = 32768;
+    size_t s = 32768;     // (16 k / 48 k / 64 k measured the same at 10 M, 12.5 M and 100 M codes)
     if (s > n) s = n;
     p.sample_n = s;
     p.sample_parts = (uint32_t)((s + 1023) / 1024);  // short parts: the pre-pass is latency-bound per wave
@@ -846,11 +846,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         size_t e = p.sample_n;
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
         // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs)
-#ifdef EXP_HAMMING_GROWTH
-        constexpr size_t growth = EXP_HAMMING_GROWTH;
-#else
         constexpr size_t growth = 4;
-#endif
         while (e < n && p.nstages < 12) {
             e = e * growth < n ? e * growth : n;
             p.stage_end[p.nstages++] = e;

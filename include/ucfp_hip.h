@@ -148,6 +148,19 @@ int ucfp_image_png_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d
                                   const ucfp_image_preprocess* pre, const uint8_t* d_exact, uint8_t* d_out,
                                   int32_t* d_status, void* stream);
 
+/* Host micro-batcher for ENCODED uploads (SURVEY 8f N1 + N4): the per-request shape of handlers::ingest_image
+ * (src/server/handlers.rs:232-302) with the decode moved to the device.  One batcher per announced geometry and pixel
+ * format (ucfp_png_probe tells them from the first 29 bytes); concurrent submit() calls become ONE H2D copy of the
+ * encoded bytes + ucfp_image_png_hash_batch_dev (PNG decode, BLAKE3 of the file, hashing) + one D2H copy of the
+ * records.  *status as there: UCFP_IMAGE_NEEDS_HOST -> decode that upload on the host and use ucfp_image_batcher_submit. */
+typedef struct ucfp_png_batcher ucfp_png_batcher;
+int ucfp_png_batcher_create(ucfp_ctx* ctx, uint32_t algo, uint32_t width, uint32_t height, int pixfmt,
+                            const ucfp_image_preprocess* pre, size_t max_batch, size_t max_bytes, uint32_t max_delay_us,
+                            ucfp_png_batcher** out);
+void ucfp_png_batcher_destroy(ucfp_png_batcher* b);
+int ucfp_png_batcher_submit(ucfp_png_batcher* b, const uint8_t* png, size_t len, uint8_t* out, int32_t* status);
+int ucfp_png_batcher_stats(ucfp_png_batcher* b, uint64_t* batches, uint64_t* items);
+
 /* BLAKE3 (32-byte digests) of n byte strings that are already on the device: one blob + n + 1 byte offsets, like the
  * text calls; blob_bytes = d_offsets[n]; the blob must be readable up to the next multiple of 4 bytes.  This is the
  * records' `exact` field (image.rs:82: BLAKE3 of the upload) for uploads that were copied to the device encoded.

@@ -228,3 +228,34 @@ def test_damaged_files_never_hang_or_fault(gpu_ctx, oracle):
         except Exception:
             continue                        # damaged outside the IDAT payload: chunk CRCs are not verified on the device
         assert np.array_equal(fr[i], want), i
+
+
+def test_micro_batcher_for_encoded_uploads(gpu_ctx, oracle):
+    """SURVEY 8f N1 + N4: 32 request threads each submit one PNG upload at a time; every thread gets ITS record -- decode,
+    BLAKE3 of the file and hashes all from the device -- bit-exact, from far fewer launch sequences than uploads.  An
+    upload of another kind comes back NEEDS_HOST, a damaged one as a modality error, without disturbing its neighbours."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ucfp_amd import image
+    from ucfp_amd.blake3 import blake3_digest
+    rng = np.random.default_rng(12)
+    pngs, imgs = zip(*[config1_png(i, side=64, level=1 + i % 6) for i in range(200)])
+    pngs = list(pngs)
+    ex = np.stack([np.frombuffer(blake3_digest(p), np.uint8) for p in pngs])
+    ref, _ = oracle.image_hash_batch(np.stack(imgs), 7, pixfmt=1, exact=ex)
+    gray = _png(rng.integers(0, 256, (64, 64), dtype=np.uint8), "L")
+    pngs[17], pngs[90] = gray, pngs[90][: len(pngs[90]) // 2]
+    b = image.PngBatcher(64, 64, image.PIX_RGB8, max_batch=64, max_delay_us=2000, ctx=gpu_ctx)
+    try:
+        with ThreadPoolExecutor(32) as pool:
+            got = list(pool.map(b.submit, pngs))
+        for i, (rec, st) in enumerate(got):
+            if i == 17:
+                assert st == image.NEEDS_HOST and not any(rec)
+            elif i == 90:
+                assert st < 0 and not any(rec)
+            else:
+                assert st == 0 and rec == ref[i].tobytes(), i
+        batches, items = b.stats()
+        assert items == len(pngs) and batches < len(pngs) // 3, (batches, items)
+    finally:
+        b.close()

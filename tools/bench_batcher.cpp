@@ -48,8 +48,10 @@ static double run_threads(int threads, size_t total, F&& one) {
 int main(int argc, char** argv) {
     std::vector<int> tcs;
     uint32_t delay_us = 0;            // 0: flush as soon as the previous flush has returned (the batch follows the load)
+    const char* png_dir = nullptr;    // --png=DIR: 0.png .. 63.png (python tools/bench_png.py --dump DIR)
     for (int i = 1; i < argc; i++) {
         if (!strncmp(argv[i], "--delay=", 8)) delay_us = (uint32_t)atoi(argv[i] + 8);
+        else if (!strncmp(argv[i], "--png=", 6)) png_dir = argv[i] + 6;
         else tcs.push_back(atoi(argv[i]));
     }
     if (tcs.empty()) tcs = {32, 128, 512};
@@ -165,6 +167,54 @@ int main(int argc, char** argv) {
                    T, total / dt, (double)(i1 - i0) / (double)(b1 - b0 ? b1 - b0 : 1), dt / total * T * 1e6);
             fflush(stdout);
             ucfp_audio_batcher_destroy(b);
+        }
+    }
+    // ---- encoded uploads: 256 x 256 RGB PNG files (BASELINE config 1), decoded + BLAKE3-hashed + fingerprinted on the device ----
+    if (png_dir) {
+        std::vector<std::vector<uint8_t>> files;
+        for (int i = 0; i < 64; i++) {
+            char path[512];
+            snprintf(path, sizeof path, "%s/%d.png", png_dir, i);
+            FILE* f = fopen(path, "rb");
+            if (!f) break;
+            std::vector<uint8_t> b;
+            uint8_t buf[65536];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, f)) > 0) b.insert(b.end(), buf, buf + got);
+            fclose(f);
+            files.push_back(std::move(b));
+        }
+        if (files.empty()) {
+            fprintf(stderr, "no PNG files under %s (python tools/bench_png.py --dump DIR writes them)\n", png_dir);
+        } else {
+            uint32_t w = 0, h = 0;
+            int fmt = 0;
+            ucfp_png_probe(files[0].data(), files[0].size(), &w, &h, &fmt);
+            for (int T : tcs) {
+                ucfp_png_batcher* b = nullptr;
+                if (ucfp_png_batcher_create(ctx, 2 /* pHash */, w, h, fmt, nullptr, 1024, 256u << 20, delay_us, &b)) {
+                    fprintf(stderr, "png batcher: %s\n", ucfp_last_error());
+                    return 1;
+                }
+                auto one = [&](size_t i) {
+                    uint8_t out[UCFP_IMAGE_MULTI_BYTES];
+                    int32_t st = 0;
+                    const std::vector<uint8_t>& f = files[i % files.size()];
+                    int rc = ucfp_png_batcher_submit(b, f.data(), f.size(), out, &st);
+                    return rc ? rc : st;
+                };
+                run_threads(T, 1024, one);
+                uint64_t b0 = 0, i0 = 0, b1 = 0, i1 = 0;
+                ucfp_png_batcher_stats(b, &b0, &i0);
+                const size_t total = 40000;
+                const double dt = run_threads(T, total, one);
+                ucfp_png_batcher_stats(b, &b1, &i1);
+                printf("{\"batcher\": \"png\", \"file\": \"%ux%u PNG, %zu bytes\", \"threads\": %d, \"files_per_s\": %.0f, "
+                       "\"avg_batch\": %.1f, \"us_per_request\": %.1f}\n",
+                       w, h, files[0].size(), T, total / dt, (double)(i1 - i0) / (double)(b1 - b0 ? b1 - b0 : 1), dt / total * T * 1e6);
+                fflush(stdout);
+                ucfp_png_batcher_destroy(b);
+            }
         }
     }
     ucfp_ctx_destroy(ctx);

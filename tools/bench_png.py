@@ -30,6 +30,12 @@ def make(n, level, side=256):
 
 
 def main():
+    if "--dump" in sys.argv:              # write 64 config-1 files for tools/bench_batcher.cpp --png=DIR
+        d = sys.argv[sys.argv.index("--dump") + 1]
+        os.makedirs(d, exist_ok=True)
+        for i, p in enumerate(make(64, 1)[0]):
+            open(os.path.join(d, f"{i}.png"), "wb").write(p)
+        return
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1000
     level = int(sys.argv[sys.argv.index("--level") + 1]) if "--level" in sys.argv else 1
     ctx = _lib.current_context()

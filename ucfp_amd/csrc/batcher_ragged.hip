@@ -1,4 +1,4 @@
-// batcher_ragged.hip -- host micro-batchers for the variable-length modalities (text, then audio).
+// batcher_ragged.hip -- host micro-batchers for the variable-length modalities (text, audio, PNG uploads).
 //
 // The reference fingerprints one document / one clip per HTTP request on a tokio worker
 // (src/server/handlers.rs:304-460 text, :704-918 audio), up to 512 requests in flight (src/bin/ucfp.rs:267).
@@ -25,7 +25,7 @@ using ucfp::capi_fail;
 
 namespace {
 
-enum Kind { kTextMinhash, kTextSimhash, kAudioWang };
+enum Kind { kTextMinhash, kTextSimhash, kAudioWang, kPngHash };
 
 // Pinned / device staging of one set.  Input: [max_batch + 1 payload offsets | payload], one H2D copy.
 // Result (text): [max_batch status words | n records], one D2H copy.  Result (audio): [max_batch + 1 hash offsets],
@@ -38,6 +38,9 @@ struct Ragged {
     uint32_t shingle_k = 0;       // text / minhash
     uint32_t sample_rate = 0;     // audio
     ucfp_wang_config wang{};      // audio
+    uint32_t algo = 0, width = 0, height = 0;   // png
+    int pixfmt = 0;
+    ucfp_image_preprocess pre{8192, 32};
     size_t unit = 1;              // payload unit in bytes: 1 (UTF-8) or 4 (f32 sample)
     size_t rec = 0;               // fixed result bytes per item (text); 0 = ragged results (audio)
     size_t max_batch = 0, max_units = 0, out_cap = 0;   // out_cap: ragged results, 8-byte hashes per flush
@@ -70,6 +73,11 @@ int run_set(Ragged* b, int s, size_t n, size_t units) {
         case kTextSimhash:
             rc = ucfp_text_simhash_batch_dev(b->ctx, d_pay, d_off, n, b->mode, b->d_out + b->out_head,
                                              reinterpret_cast<int32_t*>(b->d_out), b->stream);
+            break;
+        case kPngHash:
+            // encoded uploads: decode, BLAKE3 (exact = NULL) and hash on the device
+            rc = ucfp_image_png_hash_batch_dev(b->ctx, b->algo, d_pay, d_off, n, units, b->width, b->height, b->pixfmt, &b->pre,
+                                               nullptr, b->d_out + b->out_head, reinterpret_cast<int32_t*>(b->d_out), b->stream);
             break;
         case kAudioWang:
             rc = ucfp_audio_wang_batch_dev(b->ctx, reinterpret_cast<const float*>(d_pay), d_off, units, n, b->sample_rate,
@@ -161,6 +169,9 @@ struct ucfp_text_batcher {
 struct ucfp_audio_batcher {
     Ragged r;
 };
+struct ucfp_png_batcher {
+    Ragged r;
+};
 
 extern "C" {
 
@@ -219,6 +230,67 @@ int ucfp_text_batcher_submit(ucfp_text_batcher* b, const uint8_t* utf8, size_t l
 }
 
 int ucfp_text_batcher_stats(ucfp_text_batcher* b, uint64_t* batches, uint64_t* items) {
+    if (!b) return capi_fail(UCFP_E_INVALID, "batcher is NULL");
+    b->r.core.stats(batches, items);
+    return UCFP_OK;
+}
+
+int ucfp_png_batcher_create(ucfp_ctx* ctx, uint32_t algo, uint32_t width, uint32_t height, int pixfmt,
+                            const ucfp_image_preprocess* pre, size_t max_batch, size_t max_bytes, uint32_t max_delay_us,
+                            ucfp_png_batcher** out) {
+    if (!ctx || !out) return capi_fail(UCFP_E_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    const size_t rec = ucfp_image_record_bytes(algo);
+    if (!rec) return capi_fail(UCFP_E_UNSUPPORTED, "image algo mask %u", algo);
+    if (pixfmt < UCFP_PIX_GRAY8 || pixfmt > UCFP_PIX_RGBA8) return capi_fail(UCFP_E_INVALID, "unknown pixfmt %d", pixfmt);
+    if (!width || !height || max_batch == 0 || max_batch > 65536 || max_bytes == 0 || max_bytes >= ((size_t)1 << 32))
+        return capi_fail(UCFP_E_INVALID, "batcher needs a geometry, 1 <= max_batch <= 65536 and 1 <= max_bytes < 2^32");
+    ucfp_png_batcher* b = new (std::nothrow) ucfp_png_batcher();
+    if (!b) return capi_fail(UCFP_E_INDEX, "out of host memory");
+    Ragged& r = b->r;
+    r.ctx = ctx;
+    r.device = ucfp::ctx_device(ctx);
+    r.kind = kPngHash;
+    r.algo = algo;
+    r.width = width;
+    r.height = height;
+    r.pixfmt = pixfmt;
+    if (pre) r.pre = *pre;
+    r.unit = 1;
+    r.rec = rec;
+    r.max_batch = max_batch;
+    r.max_units = max_bytes;
+    const int rc = start(&b->r, max_delay_us);
+    if (rc) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return UCFP_OK;
+}
+
+void ucfp_png_batcher_destroy(ucfp_png_batcher* b) {
+    if (!b) return;
+    teardown(&b->r);
+    delete b;
+}
+
+int ucfp_png_batcher_submit(ucfp_png_batcher* b, const uint8_t* png, size_t len, uint8_t* out, int32_t* status) {
+    if (!b || !out || !png || len == 0) return capi_fail(UCFP_E_INVALID, "batcher/png/out is NULL or empty");
+    Ragged& r = b->r;
+    ucfp::BatchCore::Ticket t;
+    const int rc = submit(&r, png, len, &t);
+    if (t.set < 0) return rc;
+    if (rc == UCFP_OK) {
+        memcpy(out, r.h_out[t.set] + r.out_head + t.slot * r.rec, r.rec);
+        if (status) *status = reinterpret_cast<const int32_t*>(r.h_out[t.set])[t.slot];
+    }
+    r.core.release(t);
+    if (rc != UCFP_OK) return capi_fail(rc, "batched PNG launch failed");
+    return UCFP_OK;
+}
+
+int ucfp_png_batcher_stats(ucfp_png_batcher* b, uint64_t* batches, uint64_t* items) {
     if (!b) return capi_fail(UCFP_E_INVALID, "batcher is NULL");
     b->r.core.stats(batches, items);
     return UCFP_OK;

@@ -186,6 +186,45 @@ def fingerprint_pngs(pngs: Sequence[bytes], width: int, height: int, pixfmt: int
     return d_out[:n].cpu().numpy(), d_st[:n].cpu().numpy()
 
 
+class PngBatcher:
+    """Host micro-batcher for encoded uploads (SURVEY 8f N1 + N4): request threads `submit` PNG bytes of one announced
+    geometry; the library copies them to the device together and decodes, BLAKE3-hashes and fingerprints them there."""
+
+    def __init__(self, width: int, height: int, pixfmt: int = PIX_RGB8, *, algo: int = MULTI, max_batch: int = 1024,
+                 max_bytes: int = 256 << 20, max_delay_us: int = 0, preprocess: Optional[PreprocessConfig] = None, ctx=None):
+        self._lib = _lib.load()
+        self.ctx = ctx or _lib.current_context()
+        self.rec = record_bytes(algo)
+        pre = (preprocess or PreprocessConfig())._c()
+        h = C.c_void_p()
+        _lib.check(self._lib.ucfp_png_batcher_create(self.ctx.handle, algo, width, height, pixfmt, C.byref(pre), max_batch,
+                                                     max_bytes, max_delay_us, C.byref(h)))
+        self.handle = h
+
+    def submit(self, png: bytes):
+        """-> (record bytes, status); status NEEDS_HOST: decode this upload on the host (`fingerprint_with`)."""
+        out = (C.c_uint8 * self.rec)()
+        st = C.c_int32(0)
+        _lib.check(self._lib.ucfp_png_batcher_submit(self.handle, png, len(png), out, C.byref(st)))
+        return bytes(out), int(st.value)
+
+    def stats(self):
+        b, i = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.ucfp_png_batcher_stats(self.handle, C.byref(b), C.byref(i)))
+        return int(b.value), int(i.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_png_batcher_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------------------------------
 # per-request adapters (encoded bytes in, Record out) -- the reference's call shape
 # ------------------------------------------------------------------------------------------

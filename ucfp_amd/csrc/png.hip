@@ -34,15 +34,15 @@ namespace ucfp {
 namespace {
 
 constexpr int kRoot = 10, kDRoot = 8;                  // bits indexed by the first-level tables
-// Two shapes of a speculation round.  Wide rounds (256-bit subsequences) resynchronise more often inside a subsequence
+// Three shapes of a speculation round.  Wide rounds (256-bit subsequences) resynchronise more often inside a subsequence
 // -- 3.3 instead of 4.3 parses per subsequence on the match-heavy config-1 files -- and halve the per-round overhead,
 // but their buffers take 30 KiB of LDS per wave instead of 17.5: right for a batch that cannot fill the chip anyway
 // (1000 files: +19 %), wrong for a large one (8000 files: -20 %).  launch_png_decode picks by batch size.
 template <int BITS>
 struct RoundCfg {
     static constexpr int kMaxB = BITS;                                     // bits per subsequence
-    static constexpr uint32_t kIterOut = BITS == 256 ? 8192 : 4096;        // output bytes one round may add
-    static constexpr uint32_t kMatchCap = BITS == 256 ? 2048 : 1024;       // matches listed per round
+    static constexpr uint32_t kIterOut = BITS * 32;                        // output bytes one round may add
+    static constexpr uint32_t kMatchCap = BITS * 8;                        // matches listed per round
     static constexpr int kStageWords = BITS * 2 + 32;                      // 64 subsequences + overshoot + the fetch window
 };
 constexpr uint32_t kHist = 2048;                       // bytes of earlier rounds kept in LDS: a match one image row back (the common distance) never leaves the CU
@@ -204,9 +204,9 @@ __device__ __noinline__ uint32_t slow_code32(uint32_t x, const uint16_t* count, 
 // A lane's parse of its subsequence: the symbols that START in [start, limit).
 struct Parse {
     uint32_t start, exit;     // exit: bit position of the first symbol this lane did NOT decode
-    uint32_t packed;          // bytes produced | matches << 16 | end-of-block << 30 | invalid code << 31
-    __device__ __forceinline__ uint32_t nbytes() const { return packed & 0xffffu; }
-    __device__ __forceinline__ uint32_t nmatch() const { return (packed >> 16) & 0x3fffu; }
+    uint32_t packed;          // bytes produced (17 bits) | matches << 17 (13 bits) | end-of-block << 30 | invalid code << 31
+    __device__ __forceinline__ uint32_t nbytes() const { return packed & 0x1ffffu; }
+    __device__ __forceinline__ uint32_t nmatch() const { return (packed >> 17) & 0x1fffu; }
     __device__ __forceinline__ bool eob() const { return (packed >> 30) & 1u; }
     __device__ __forceinline__ bool err() const { return packed >> 31; }
     __device__ __forceinline__ bool stopped() const { return packed >> 30; }
@@ -269,7 +269,7 @@ __device__ __forceinline__ Parse parse_sub(InflateLds<C>& L, uint32_t start, uin
         nm += (go && is_len) ? 1u : 0u;
         act = go && !eob && pos < limit;
     }
-    return Parse{start, pos, nb | nm << 16 | flags << 30};
+    return Parse{start, pos, nb | nm << 17 | flags << 30};     // a 512-bit subsequence holds < 256 matches, < 66 KiB of output
 }
 
 // The parses a lane has already made in this round, by start position: the candidates for a lane's start are few (wrong
@@ -1036,7 +1036,10 @@ int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uin
     // wide rounds while the batch leaves most of the chip's wave slots empty anyway (RoundCfg)
     // measured (files/s, narrow | wide): 600: 83 k | 98 k, 1000: 130 k | 157 k, 1400: 162 k | 118 k, 2000: 141 k | 160 k,
     // 3000: 189 k | 164 k -- the chip holds about 1024 wide or 1536 narrow waves at a time
-    if (n <= 1024 || (n > 1536 && n <= 2048))
+    if (n <= 512)           // two waves per CU hold such a batch: 512-bit rounds, 10 % less latency than 256-bit ones
+        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<512>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
+                           ws + l.raw, l.raw_stride, (uint32_t)l.raw_n);
+    else if (n <= 1024 || (n > 1536 && n <= 2048))
         hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<256>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
                            ws + l.raw, l.raw_stride, (uint32_t)l.raw_n);
     else

@@ -259,3 +259,20 @@ def test_micro_batcher_for_encoded_uploads(gpu_ctx, oracle):
         assert items == len(pngs) and batches < len(pngs) // 3, (batches, items)
     finally:
         b.close()
+
+
+@pytest.mark.parametrize("n", [520, 1100])
+def test_every_round_shape_of_the_inflate_kernel(gpu_ctx, oracle, n):
+    """The inflate kernel is launched in one of three round shapes by batch size (<= 512 files: 512-bit subsequences,
+    <= 1024: 256-bit, beyond: 128-bit); the other tests use small batches, these two reach the other shapes."""
+    from ucfp_amd import image
+    rng = np.random.default_rng(n)
+    base = [config1_png(i, side=64, level=(1, 6, 9)[i % 3]) for i in range(40)]
+    flat = _png(np.full((64, 64, 3), 200, np.uint8), "RGB", compress_level=9)
+    pngs = [base[i % 40][0] for i in range(n)]
+    pngs[5] = pngs[n - 3] = flat
+    fr, st = image.decode_pngs(pngs, 64, 64, image.PIX_RGB8, ctx=gpu_ctx)
+    assert not st.any()
+    for i in range(n):
+        want = np.full((64, 64, 3), 200, np.uint8) if i in (5, n - 3) else base[i % 40][1]
+        assert np.array_equal(fr[i], want), i

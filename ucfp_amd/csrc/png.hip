@@ -51,9 +51,9 @@ constexpr uint32_t kHist = 2048;                       // bytes of earlier round
 constexpr uint32_t kLit = 0, kLen = 1, kEob = 2, kSlow = 3;
 constexpr uint32_t kInvalid = kSlow << 24;             // code length 0: resolved (or rejected) by the canonical slow path
 
-// The deflate window is the image itself: bytes of earlier rounds are read back from frame memory (this wave wrote
-// them; a workgroup-scope fence orders the stores before the loads), only the round in flight lives in LDS.  ~15 KiB
-// per wave instead of 48: ten waves per CU hide each other's LDS latency.
+// The deflate window is the image itself: the round in flight and the last kHist bytes before it live in LDS, older
+// bytes are read back from frame memory (this wave wrote them; a workgroup-scope fence orders the stores before the
+// loads).  17.5 KiB per wave in the narrow shape instead of the 48 KiB a 32 KiB window in LDS would take.
 template <class C>
 struct InflateLds {
     uint32_t lit[1 << kRoot];

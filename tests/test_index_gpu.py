@@ -611,3 +611,26 @@ def test_cosine_duplicate_rows_and_any_id_order(gpu_ctx, oracle):
         assert g_c[q] == 10 and np.array_equal(g_ids[q], best), q
         assert np.all(g_sc[q] > 0.99)
     ix.close()
+
+
+@pytest.mark.parametrize("nq", [6, 90])
+def test_hamming_strict_thresholds_with_overflowing_lists(gpu_ctx, oracle, nq):
+    """Ascending ids (strict stage thresholds) AND a clustered corpus whose candidate lists overflow: the fallback tier then
+    filters the whole corpus with the SAMPLE's thresholds -- it must not see a strict stage threshold (found by the
+    randomised soak: it once did, and dropped the k-th best itself)."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(5 + nq)
+    n = 700_000
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    centres = codes[rng.integers(0, n, 8)]
+    near = centres[rng.integers(0, 8, n // 2)] ^ (np.uint64(1) << rng.integers(0, 63, n // 2).astype(np.uint64))
+    codes[: n // 2] = near                                   # half of the corpus within one bit of eight centres
+    ids = np.cumsum(rng.integers(1, 4, n)).astype(np.uint64)
+    queries = codes[rng.integers(0, n, nq)] ^ np.uint64(5)
+    ix = index.DeviceIndex(index.HAMMING64, 0, index.APPEND_ONLY, gpu_ctx)
+    ix.upsert(0, ids, codes)
+    for k in (1, 5, 10):
+        g_ids, _, g_d, g_c = ix.search(0, queries, k)
+        o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+        assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids), k
+    ix.close()

@@ -44,6 +44,10 @@ def main():
                 near = near ^ (torch.ones_like(near) << torch.randint(0, 63, (n // 2,), device=dev, generator=g))
                 codes[: n // 2] = near
             ids = torch.randperm(n, device=dev, generator=g).to(torch.int64)
+            if rng.random() < 0.5:     # ids ascending with the row: the stages after the first filter strictly (hamming_list_tau)
+                ids = torch.sort(ids * 3 + 1).values
+                if rng.random() < 0.3 and n > 10:     # ... except for one inversion far into the corpus
+                    ids[n - 5], ids[n - 4] = ids[n - 4].clone(), ids[n - 5].clone()
             q = codes[torch.randint(0, n, (nq,), device=dev, generator=g)] ^ 5
             ix = index.DeviceIndex(index.HAMMING64, flags=index.APPEND_ONLY, ctx=ctx)
             ix.append_dev(0, ids.data_ptr(), codes.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
@@ -63,8 +67,8 @@ def main():
             ix.close()
         else:
             n = int(rng.choice([900, 5000, 40_000, 270_000, 600_000]))
-            dim = int(rng.choice([32, 64, 100, 256, 384, 768]))
-            nq = int(rng.choice([1, 2, 4, 5, 40, 49, 130, 300]))
+            dim = int(rng.choice([32, 64, 100, 256, 384, 512, 768, 1024]))
+            nq = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 40, 49, 130, 300]))
             k = int(rng.choice([1, 10, 20]))
             if n * dim > 250_000_000:
                 n = 250_000_000 // dim

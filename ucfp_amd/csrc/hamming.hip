@@ -867,7 +867,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
 
 namespace {
 struct HammingWs {
-    size_t hist, tau0, part_ids, part_d, part_cnt, tau1, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, qimg, total;
+    size_t hist, tau0, part_ids, part_d, part_cnt, tau1, tau2, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, qimg, total;
 };
 HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -880,6 +880,7 @@ HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     w.part_d = off;    off = align(off + (size_t)ms * nq * k * 4);
     w.part_cnt = off;  off = align(off + (size_t)ms * nq * 4);
     w.tau1 = off;      off = align(off + (size_t)nq * 4);
+    w.tau2 = off;      off = align(off + (size_t)nq * 4);
     w.cand_cnt = off;  off = align(off + (size_t)nq * 4);
     w.overflow = off;  off = align(off + 4);
     w.cand_d = off;    off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 4 : 0));
@@ -957,8 +958,11 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         if (nq > (uint32_t)kFewQueries)
             hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 128 + 255) / 256), dim3(256), 0, stream, queries,
                                nq, qimg);
+        // stage thresholds alternate between tau1 and tau2: tau0 (the sample's, never strict) stays intact for the
+        // fallback tier, which filters the WHOLE corpus with d <= tau0 -- a strict stage threshold would drop the k-th itself
         uint32_t* tau_cur = u32(w.tau0);
         uint32_t* tau_nxt = u32(w.tau1);
+        uint32_t* tau_spare = u32(w.tau2);
         size_t begin = 0;
         for (uint32_t sidx = 0; sidx < p.nstages; sidx++) {
             const size_t end = p.stage_end[sidx];
@@ -987,7 +991,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                 hipLaunchKernelGGL(hamming_list_tau, dim3(nq), dim3(64), 0, stream, (const uint32_t*)u32(w.cand_cnt),
                                    (const uint32_t*)u32(w.cand_d), p.cand_cap, k, (const uint32_t*)tau_cur, tau_nxt,
                                    ids_ascending);
-                uint32_t* t = tau_cur;
+                uint32_t* t = tau_cur == u32(w.tau0) ? tau_spare : tau_cur;
                 tau_cur = tau_nxt;
                 tau_nxt = t;
             }

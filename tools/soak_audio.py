@@ -57,6 +57,23 @@ def main():
         g = audio.wang_hashes(x, 8000, cfg, ctx=ctx) if cfg else audio.wang_hashes(x, 8000, ctx=ctx)
         o = oracle.wang(x, ocfg, cap=max(64, g.shape[0] + 1000)) if ocfg else oracle.wang(x)
         assert g.shape == o.shape and np.array_equal(g, o), ("wang", n, rounds)
+        if rounds % 4 == 1:
+            # the ragged-batch entries: a mix of clip lengths (empty, under one frame, seconds, a minute) at a random source
+            # rate, Wang (resampler fused into the stream kernel) and Haitsma (batched 5 kHz resample + frame map)
+            sr = int(rng.choice([8000, 11025, 16000, 22050, 44100, 48000, 7999, 96000]))
+            lens = [int(v * sr) for v in rng.choice([0.0, 0.01, 0.1285, 0.3, 1.0, 2.5, 4.0, 9.7, 60.0], size=int(rng.integers(1, 24)))]
+            if sum(lens) > 90 * sr:
+                lens = lens[:3]
+            clips = [signal(rng, max(n_, 0), sr) if n_ else np.zeros(0, np.float32) for n_ in lens]
+            got = audio.wang_hashes_batch(clips, sr, cfg, ctx=ctx) if cfg else audio.wang_hashes_batch(clips, sr, ctx=ctx)
+            for c_, g_ in zip(clips, got):
+                r8 = c_ if sr == 8000 else oracle.resample_linear(c_, sr, 8000)
+                o_ = oracle.wang(r8, ocfg, cap=max(64, g_.shape[0] + 1000)) if ocfg else oracle.wang(r8)
+                assert g_.shape == o_.shape and np.array_equal(g_, o_), ("wang batch", sr, c_.size, rounds)
+            goth = audio.haitsma_frames_batch(clips, sr, ctx=ctx)
+            for c_, g_ in zip(clips, goth):
+                o_ = oracle.haitsma(c_, sr)
+                assert g_.shape == o_.shape and np.array_equal(g_, o_), ("haitsma batch", sr, c_.size, rounds)
         if rounds % 3 == 0:
             sr = int(rng.choice([5000, 8000, 16000, 44100]))
             y = signal(rng, max(4096, int(min(secs, 30.0) * sr)), sr)

@@ -136,3 +136,48 @@ def test_rebuild_equals_the_index_that_wrote_the_log(gpu_ctx, tmp_path):
     snap = store.Snapshot(path)
     assert any(r.record_id == 9999 for r in snap)
     snap.close()
+
+
+def test_random_operation_sequences_replay_like_a_dict(tmp_path):
+    """3000 random upserts / overwrites / deletes over a few tenants, the writer closed and reopened now and then: the
+    snapshot equals a plain dict that applied the same operations, in redb's range-scan order."""
+    from ucfp_amd import store
+    rng = np.random.default_rng(11)
+    path = str(tmp_path / "rand.sidecar")
+    model = {}
+    sc = store.Sidecar(path)
+    algos = ["imgfprint-multihash-v1", "imgfprint-phash-v1", "simhash-b64-tf", "minhash-h128"]
+    for step in range(3000):
+        tenant, rid = int(rng.integers(0, 4)), int(rng.integers(0, 300))
+        op = rng.random()
+        if op < 0.7:
+            algo = algos[int(rng.integers(0, 4))]
+            fp = rng.integers(0, 256, {"imgfprint-multihash-v1": 536, "imgfprint-phash-v1": 168, "simhash-b64-tf": 8,
+                                       "minhash-h128": 1032}[algo], dtype=np.uint8).tobytes()
+            emb = rng.standard_normal(int(rng.choice([4, 16]))).astype(np.float32).tolist() if rng.random() < 0.5 else None
+            r = Record(tenant_id=tenant, record_id=rid, modality=Modality.Image, format_version=1, algorithm=algo,
+                       config_hash=int(rng.integers(0, 1 << 62)), fingerprint=fp, embedding=emb)
+            sc.append([r])
+            model[(tenant, rid)] = r
+        else:
+            sc.delete(tenant, [rid])
+            model.pop((tenant, rid), None)
+        if step % 700 == 699:
+            sc.close()
+            sc = store.Sidecar(path)
+    sc.sync()
+    sc.close()
+    snap = store.Snapshot(path)
+    rows = list(snap)
+    assert [(r.tenant_id, r.record_id) for r in rows] == sorted(model)
+    for r in rows:
+        m = model[(r.tenant_id, r.record_id)]
+        assert r.fingerprint == m.fingerprint and r.algorithm == m.algorithm and r.config_hash == m.config_hash
+        assert (r.embedding is None) == (m.embedding is None)
+        if m.embedding is not None:
+            assert np.array_equal(np.float32(r.embedding), np.float32(m.embedding))
+    for algo, n in (("imgfprint-multihash-v1", 536), ("simhash-b64-tf", 8)):
+        t, ids, blobs = snap.gather_fingerprints(algo, n)
+        want = sorted(k for k, v in model.items() if v.algorithm == algo)
+        assert list(zip(t.tolist(), ids.tolist())) == want
+    snap.close()

@@ -131,7 +131,7 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
  *   UCFP_IMAGE_NEEDS_HOST  a valid PNG of another kind (palette, 16-bit, grey+alpha, interlaced, tRNS) or of another
  *                          geometry / format than announced: decode it with the host's decoder, submit the pixels
  *   UCFP_E_MODALITY        not a PNG / damaged stream (the reference answers 400)
- * The zlib stream's Adler-32 is verified on the device; chunk CRCs are not.
+ * Chunk CRCs and the zlib stream's Adler-32 are verified on the device.
  * png_bytes = d_offsets[n] (the host knows it; sizes the context's workspace: about png_bytes + n x (2 x frame bytes)). */
 #define UCFP_IMAGE_NEEDS_HOST 1
 /* Host-side: geometry and pixel format of a PNG from its IHDR.  UCFP_OK, UCFP_IMAGE_NEEDS_HOST or UCFP_E_MODALITY. */

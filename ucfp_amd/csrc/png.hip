@@ -20,8 +20,7 @@
 //                 outputs (a diagonal wavefront, 64 rows in flight).
 //
 // Scope: 8-bit greyscale / RGB / RGBA, non-interlaced, no tRNS -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
-// the host's decoder (like non-ASCII text).  The Adler-32 trailer is verified; chunk CRCs are NOT (a file damaged outside
-// its IDAT payload -- in an ancillary chunk, say -- is hashed, where the reference rejects it).
+// the host's decoder (like non-ASCII text).  Chunk CRCs and the Adler-32 trailer are verified, as the reference's decoder does.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -416,13 +415,82 @@ __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
     return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3];
 }
 
+// ---- chunk CRCs (PNG 5.5: CRC-32 of chunk type + data), verified like the reference's decoder does ----
+// A chunk is cut into 64 slices, one per lane (byte-wise table CRC from LDS); the slices' CRCs combine linearly:
+// crc(S0 | S1 | ...) = xor_j crc(S_j) * x^(8 * bytes after S_j) mod P (zlib's crc32_combine identity, reflected polynomial).
+constexpr uint32_t kCrcPoly = 0xedb88320u;
+__device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        p ^= ((a >> (31 - i)) & 1u) ? b : 0u;
+        b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+// x^(8 n) mod P; x2n[k] = x^(2^k) mod P
+__device__ __forceinline__ uint32_t crc_x8n(uint32_t n, const uint32_t* x2n) {
+    uint32_t p = 1u << 31;
+    for (uint32_t k = 3; __ballot(n != 0); k++, n >>= 1)
+        p = (n & 1u) ? crc_multmodp(x2n[k & 31], p) : p;
+    return p;
+}
+// tab: four 256-entry tables (slicing by 4: a word of input is four independent lookups instead of a chain of four)
+__device__ uint32_t chunk_crc(const uint8_t* base, uint32_t total, const uint32_t* tab, const uint32_t* x2n, int lane) {
+    const uint32_t per = (total + 63) / 64;
+    const uint32_t lo = lane * per < total ? lane * per : total, hi = lo + per < total ? lo + per : total;
+    uint32_t crc = 0xffffffffu;
+    uint32_t b = lo;
+    for (; b < hi && ((reinterpret_cast<uintptr_t>(base) + b) & 3u); b++) crc = tab[(crc ^ base[b]) & 255u] ^ (crc >> 8);
+    auto word = [&](uint32_t w) {
+        crc ^= w;
+        crc = tab[768 + (crc & 255u)] ^ tab[512 + ((crc >> 8) & 255u)] ^ tab[256 + ((crc >> 16) & 255u)] ^ tab[crc >> 24];
+    };
+    for (; b + 16 <= hi; b += 16) {                    // four words requested together
+        typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));     // word-aligned only
+        const u32x4a4 v = *reinterpret_cast<const u32x4a4*>(base + b);
+        word(v[0]), word(v[1]), word(v[2]), word(v[3]);
+    }
+    for (; b + 4 <= hi; b += 4) word(*reinterpret_cast<const uint32_t*>(base + b));
+    for (; b < hi; b++) crc = tab[(crc ^ base[b]) & 255u] ^ (crc >> 8);
+    const uint32_t c = hi > lo ? ~crc : 0u;
+    uint32_t t = crc_multmodp(crc_x8n(total - hi, x2n), c);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t ^= __shfl_xor(t, o, 64);
+    return t;
+}
+
 // One wave per file: validate, gather IDAT payloads to zbuf + align16(offsets[i]).
 __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict__ png, const uint64_t* __restrict__ offsets,
                                                      size_t n, uint32_t width, uint32_t height, int pixfmt,
                                                      uint8_t* __restrict__ zbuf, PngInfo* __restrict__ info) {
+    __shared__ uint32_t crc_tab[1024];
+    __shared__ uint32_t x2n[32];
     const size_t img = blockIdx.x;
     if (img >= n) return;
     const int lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) {
+        uint32_t c = i;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? kCrcPoly ^ (c >> 1) : c >> 1;
+        crc_tab[i] = c;
+    }
+    wave_lds_sync();
+    for (int t = 1; t < 4; t++) {                      // T_t[i] = T_{t-1}[i] advanced by one zero byte
+        for (uint32_t i = lane; i < 256; i += 64) {
+            const uint32_t v = crc_tab[(t - 1) * 256 + i];
+            crc_tab[t * 256 + i] = (v >> 8) ^ crc_tab[v & 255u];
+        }
+        wave_lds_sync();
+    }
+    {
+        uint32_t v = 1u << 30;            // x^1
+        for (int k = 0; k < 32; k++) {
+            if (lane == 0) x2n[k] = v;
+            v = crc_multmodp(v, v);
+        }
+    }
+    wave_lds_sync();
     const uint8_t* p = png + offsets[img];
     const size_t len = (size_t)(offsets[img + 1] - offsets[img]);
     uint8_t* z = zbuf + ((offsets[img] + 15) & ~(uint64_t)15);
@@ -438,6 +506,7 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
         if (w == 0 || h == 0 || comp != 0 || filt != 0 || lace > 1) status = UCFP_E_MODALITY;
         else if (depth != 8 || lace != 0 || fmt < 0 || fmt != pixfmt || w != width || h != height) status = UCFP_IMAGE_NEEDS_HOST;
     }
+    if (status != UCFP_E_MODALITY && chunk_crc(p + 12, 4 + 13, crc_tab, x2n, lane) != be32(p + 29)) status = UCFP_E_MODALITY;   // IHDR
     if (status == 0) {
         size_t pos = 8 + 25;
         bool seen_idat = false, idat_done = false, seen_end = false;
@@ -445,6 +514,10 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
             const uint32_t cl = be32(p + pos);
             const uint8_t t0 = p[pos + 4], t1 = p[pos + 5], t2 = p[pos + 6], t3 = p[pos + 7];
             if (cl > 0x7fffffffu || pos + 12 + (size_t)cl > len) {
+                status = UCFP_E_MODALITY;
+                break;
+            }
+            if (chunk_crc(p + pos + 4, 4 + cl, crc_tab, x2n, lane) != be32(p + pos + 8 + cl)) {
                 status = UCFP_E_MODALITY;
                 break;
             }

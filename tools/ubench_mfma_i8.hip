@@ -7,6 +7,7 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // MODE 0..3: 16x16x64 with MODE v_max3 per MFMA (results folded one iteration late)
 // MODE 10: 32x32x32, C = 0           MODE 11: 32x32x32, C = previous result (accumulate chain of 2)
@@ -15,6 +16,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(int* out, int iters) {
     i32x4 a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)blockIdx.x, 7}, c = {0, 0, 0, 0};
+    const bool sign_random = iters < 0;
     if (iters < 0) {   // negative iters: random 0/1 and +-1 bytes (the data the Hamming filter feeds): toggling -> power -> clock
         iters = -iters;
         uint32_t h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 12345u);
@@ -28,7 +30,54 @@ __global__ __launch_bounds__(1024) void k(int* out, int iters) {
     }
     int m0 = -1, m1 = -2, m2 = -3;
     int r = 0;
-    if (MODE < 10) {
+    if (MODE >= 20) {
+        // FP4 (e2m1) operands: nibble 0x2 = 1.0, 0xA = -1.0, 0 = 0; K = 64 in ONE instruction
+        if (sign_random) {
+            uint32_t h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 777u);
+            for (int j = 0; j < 4; j++) {
+                h = h * 1664525u + 1013904223u;
+                a[j] = (int)((h & 0x11111111u) << 1);
+                h = h * 1664525u + 1013904223u;
+                b[j] = (int)(0x22222222u | ((h & 0x11111111u) << 3));
+            }
+        } else {
+            for (int j = 0; j < 4; j++) a[j] = 0x22222222, b[j] = 0x22222222;
+        }
+        f32x16 d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) d[j][e] = (float)(j + e);
+        float f0 = -1.f, f1 = -2.f;
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (MODE == 20)
+                    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, 0 cbsz:4 blgp:4\n\tv_mfma_f32_32x32x64_f8f6f4 %3, %1, %2, 0 cbsz:4 blgp:4"
+                                 : "=&v"(d[j]) : "v"(a), "v"(b), "v"(d[(j + 2) & 3]));
+                if (MODE == 21 || MODE == 22) {
+                    // two tiles per asm block: the fold of the other buffers' results in the MFMA shadows
+                    const f32x16& p = d[(j + 2) & 3];
+                    asm volatile(
+                        "v_mfma_f32_32x32x64_f8f6f4 %0, %3, %4, 0 cbsz:4 blgp:4\n\t"
+                        "v_max3_f32 %1, %1, %5, %6\n\tv_max3_f32 %2, %2, %7, %8\n\tv_max3_f32 %1, %1, %9, %10\n\t"
+                        "v_max3_f32 %2, %2, %11, %12\n\t"
+                        "v_max3_f32 %1, %1, %13, %14\n\tv_max3_f32 %2, %2, %15, %16\n\tv_max3_f32 %1, %1, %17, %18\n\t"
+                        "v_max3_f32 %2, %2, %19, %20"
+                        : "=&v"(d[j]), "+v"(f0), "+v"(f1)
+                        : "v"(a), "v"(b), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]),
+                          "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]),
+                          "v"(p[15]));
+                    if (MODE == 22)   // an i8-rate equivalent: a second MFMA without fold work
+                        asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, 0 cbsz:4 blgp:4" : "=&v"(d[(j + 1) & 3]) : "v"(a), "v"(b));
+                }
+            }
+        }
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+#pragma unroll
+        for (int j = 0; j < 4; j++) r ^= __float_as_int(d[j][0]) ^ __float_as_int(d[j][15]);
+        r ^= __float_as_int(f0) ^ __float_as_int(f1);
+    } else if (MODE < 10) {
         i32x4 d[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) d[j] = i32x4{j, j, j, j};
@@ -116,8 +165,9 @@ void run(int waves_per_simd, int sign = 1) {
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    const double mfmas_per_simd = (double)iters * 8 * waves_per_simd;
-    const double pairs = (MODE < 10 ? 256.0 : 1024.0 / 2);   // code-query pairs one MFMA completes
+    const double per_iter = MODE == 21 ? 4 : 8;
+    const double mfmas_per_simd = (double)iters * per_iter * waves_per_simd;
+    const double pairs = (MODE >= 20 ? 1024.0 : MODE < 10 ? 256.0 : 1024.0 / 2);   // code-query pairs one MFMA completes
     printf("%s mode=%2d waves/SIMD=%d  %.3f ms  %.2f ns per MFMA per SIMD  -> %.1f T pairs/s on 1024 SIMDs\n", sign < 0 ? "random" : "const ", MODE,
            waves_per_simd, ms, ms * 1e6 / mfmas_per_simd, pairs / (ms * 1e6 / mfmas_per_simd) * 1024 / 1e3);
     (void)hipFree(d);
@@ -135,6 +185,11 @@ int main() {
         run<2>(w, -1);
         run<11>(w, -1);
         run<12>(w, -1);
+        run<20>(w);
+        run<21>(w);
+        run<20>(w, -1);
+        run<21>(w, -1);
+        run<22>(w, -1);
     }
     return 0;
 }

@@ -7,8 +7,8 @@
 //
 // Three scans share one structure (an upper bound tau[q] on the final k-th distance turns the search into a
 // filter; bounds come from a 32k-code sample, then from the candidates found so far, over ranges growing 4x):
-//   > 64 queries   hamming_scan_mfma   the pair distance as a +-1 x 0/1 byte contraction on the int8 matrix
-//                                      cores; suspect blocks are logged and re-evaluated exactly by hamming_rescan
+//   > 64 queries   hamming_scan_mfma   the pair distance as a +-1 x 0/1 contraction on the matrix cores (FP4
+//                                      operands, exact); suspect blocks are logged and re-evaluated exactly by hamming_rescan
 //   <= 64 queries  hamming_scan_lanes  lane = code, queries in SGPRs: a pure HBM stream
 //   robust tier    hamming_scan        lane = query, corpus code wave-uniform (s_load_dwordx16), per-pair work
 //                                      2 v_xor + 2 v_bcnt + 1 compare, lane-private LDS candidate lists pruned
@@ -257,109 +257,112 @@ __global__ __launch_bounds__(64) void hamming_scan(
 // FILTERED: every row with d <= tau[q] goes to q's candidate list in global memory, everything else
 // is dropped unseen.  With a batch of queries that scan is ALU-bound (HBM sees < 1 TB/s), and the
 // distance is an exact small-integer contraction: with x_i = 1/0 for the code bits and y_i = +1/-1
-// for the query bits,  sum_i x_i y_i = popc(q) - d(q, x).  Two v_mfma_i32_32x32x32_i8 (K = 2 x 32)
-// with  A = 32 codes as 0/1 bytes (rows),  B = 32 queries as +-1 bytes (columns)  give 1024 of
-// these sums in 64 cycles (the popcount path: ~290), and a pair is a candidate iff
-// sum >= popc(q) - tau[q].  Integers throughout -- nothing is approximated.
+// for the query bits,  sum_i x_i y_i = popc(q) - d(q, x).  0, +1 and -1 are exact in FP4 (e2m1: nibbles 0x0, 0x2,
+// 0xA) and the products accumulate in f32, so ONE v_mfma_f32_32x32x64_f8f6f4 (cbsz = blgp = 4: both operands FP4,
+// K = 64 = the whole code) with  A = 32 codes (rows),  B = 32 queries (columns)  gives 1024 of these sums in 32
+// cycles -- twice the int8 rate (two v_mfma_i32_32x32x32_i8, 64 cycles: rounds 1-2 of this file) and ~9x the
+// popcount path (~290) -- and a pair is a candidate iff sum >= popc(q) - tau[q].  Small integers in f32: nothing is
+// approximated (tools/probe_mfma_fp4.hip checks the operand and result layout against popcounts).
+//   K map   lane (nn, hh) holds the 32 bits [32 hh, 32 hh + 32) of row / column nn as 4 dwords of 8 nibbles; bit
+//           4 i + j of that word sits in nibble i of dword j.  A and B use the SAME map, which is all a dot product
+//           needs, and it makes the expansion four shifted ANDs with 0x22222222 per code tile.
 //   layout  the 16 results a lane holds all belong to ONE query (column = lane & 31), so they are
-//           folded with v_max3 (two results per instruction) before the single compare against the
-//           lane's threshold: no C operand, 8 v_max3 per MFMA pair, and the 32x32 shape keeps the
-//           vector issue port (8 cycles per MFMA + 4 per v_max3) below the matrix pipe's 64 cycles
-//   LDS     the +-1 image of the whole query pass (<= 2048 queries, 2 KiB per 32-query tile,
+//           folded with v_max3_f32 (two results per instruction) before the single compare against the
+//           lane's threshold: no C operand, 8 fold instructions per MFMA.  The vector issue port (8 cycles per
+//           MFMA + 4 per v_max3) is now what bounds the loop: 40 cycles per 1024 pairs against the matrix pipe's 32
+//           (tools/ubench_mfma_i8.hip modes 20-22: 52.7 T pairs/s on random operands against 33.2 for the int8 form)
+//   LDS     the +-1 image of the whole batch (<= 4096 queries, 1 KiB per 32-query tile,
 //           lane-contiguous for ds_read_b128) and the thresholds, built once per workgroup
-//   wave    expands 4 code tiles (128 codes) into registers (lane half and K half pick the bits: the
-//           same k-permutation on both operands), then walks all query tiles: 8 MFMAs, 32 v_max3,
-//           1 compare, software-pipelined by one tile
+//   wave    expands 4 code tiles (128 codes) into registers, then walks all query tiles: 4 MFMAs, 32 v_max3,
+//           1 compare per tile, software-pipelined by one tile
 //   hits    rare by construction of tau.  The scan only RECORDS a suspect block (query tile, code
 //           tile, ballot of the lanes over threshold) in the wave's own slice of a global log -- one
 //           store, no atomics, nothing to wait for.  hamming_rescan then re-evaluates the flagged
-//           (query, 16-code half) combinations with plain popcounts (exact, independent of the MFMA
-//           result layout) and appends the true candidates to the per-query lists.
+//           (query, 16-code half) combinations with plain popcounts (exact; it checks the result layout it
+//           assumes and raises the fallback flag on any disagreement) and appends the true candidates to the
+//           per-query lists.
 // The scan runs in stages over geometrically growing ranges: tau0 (k-th distance inside a 32k-code
 // sample) filters [0, 4 x 32k); the k-th smallest distance of the candidates so far filters the next
 // 4x larger range, and so on, so every stage admits only ~4k..20k candidates per query.  The final
 // top-k is selected from the lists.  If a log or a list overflows (adversarial order) a flag routes
 // the batch through the robust tier, device-side -- results never depend on the heuristic.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-constexpr int kQP = 2048;    // queries per pass (their +-1 image is resident in LDS)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kQP = 4096;    // queries per pass (their +-1 image is resident in LDS): one pass per search call
 constexpr int kTB = 4;       // 32-code tiles per wave step
 constexpr int kMW = 8;       // waves per workgroup (2 per SIMD; the loop is software-pipelined inside a wave)
 constexpr int kStep = kTB * 32;
+static_assert(kQP >= (int)kHammingMaxBatch, "one pass covers a whole search call");
 
-__device__ __forceinline__ uint32_t spread4(uint32_t nib) {   // bit i of nib -> byte i (0 / 1)
-    return __umul24(nib, 0x204081u) & 0x01010101u;
-}
-__device__ __forceinline__ i32x4 expand01(uint32_t bits16) {
+// FP4 operand words of a 32-bit half: dword j nibble i <- bit 4 i + j.  Codes: 1 -> 0x2 (+1.0), 0 -> 0x0 (0.0).
+__device__ __forceinline__ i32x4 expand_code_fp4(uint32_t w) {
     i32x4 v;
-    v[0] = (int)spread4(bits16 & 15u);
-    v[1] = (int)spread4((bits16 >> 4) & 15u);
-    v[2] = (int)spread4((bits16 >> 8) & 15u);
-    v[3] = (int)spread4(bits16 >> 12);
+    v[0] = (int)((w << 1) & 0x22222222u);
+    v[1] = (int)(w & 0x22222222u);
+    v[2] = (int)((w >> 1) & 0x22222222u);
+    v[3] = (int)((w >> 2) & 0x22222222u);
     return v;
 }
-__device__ __forceinline__ i32x4 expand_pm1(uint32_t bits16) {   // 1 -> +1, 0 -> -1
-    const i32x4 t = expand01(bits16);
+// Queries: 1 -> 0x2 (+1.0), 0 -> 0xA (-1.0).
+__device__ __forceinline__ i32x4 expand_query_fp4(uint32_t w) {
+    const uint32_t n = ~w;
     i32x4 v;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t u = ((uint32_t)t[j] << 8) - (uint32_t)t[j];   // 0xFF where set
-        v[j] = (int)(~u | 0x01010101u);
-    }
+    v[0] = (int)(0x22222222u | ((n << 3) & 0x88888888u));
+    v[1] = (int)(0x22222222u | ((n << 2) & 0x88888888u));
+    v[2] = (int)(0x22222222u | ((n << 1) & 0x88888888u));
+    v[3] = (int)(0x22222222u | (n & 0x88888888u));
     return v;
 }
 
 size_t hamming_mfma_lds_bytes(uint32_t nq) {
     const uint32_t tiles = ((nq < (uint32_t)kQP ? nq : (uint32_t)kQP) + 31) / 32;
-    return (size_t)(tiles + 2) * (2048 + 128);   // +2: the drain tile and its operand prefetch
+    return (size_t)(tiles + 2) * (1024 + 128);   // +2: the drain tile and its operand prefetch
 }
 uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) * kMW; }
 
-// One code tile of the software-pipelined step, as text: MFMA (K half 0), four v_max3 folding the previous
-// tile's results, MFMA (K half 1, accumulating), four more.  %0 result, %1 running max, %2/%3 the code
-// tile's two K halves (A), %4/%5 the query tile's (B), %6..%21 the 16 previous results of this lane.
-#define UCFP_FOLD                                     \
-    "v_mfma_i32_32x32x32_i8 %0, %2, %4, 0\n\t"        \
-    "v_max3_i32 %1, %6, %7, %8\n\t"                   \
-    "v_max3_i32 %1, %1, %9, %10\n\t"                  \
-    "v_max3_i32 %1, %1, %11, %12\n\t"                 \
-    "v_max3_i32 %1, %1, %13, %14\n\t"                 \
-    "v_mfma_i32_32x32x32_i8 %0, %3, %5, %0\n\t"       \
-    "v_max3_i32 %1, %1, %15, %16\n\t"                 \
-    "v_max3_i32 %1, %1, %17, %18\n\t"                 \
-    "v_max3_i32 %1, %1, %19, %20\n\t"                 \
-    "v_max_i32 %1, %1, %21"
+// One code tile of the software-pipelined step, as text: the MFMA, then eight instructions folding the previous
+// tile's results.  %0 result, %1 running max, %2 the code tile (A), %3 the query tile (B), %4..%19 the 16
+// previous results of this lane.
+#define UCFP_FOLD                                                 \
+    "v_mfma_f32_32x32x64_f8f6f4 %0, %2, %3, 0 cbsz:4 blgp:4\n\t"  \
+    "v_max3_f32 %1, %4, %5, %6\n\t"                               \
+    "v_max3_f32 %1, %1, %7, %8\n\t"                               \
+    "v_max3_f32 %1, %1, %9, %10\n\t"                              \
+    "v_max3_f32 %1, %1, %11, %12\n\t"                             \
+    "v_max3_f32 %1, %1, %13, %14\n\t"                             \
+    "v_max3_f32 %1, %1, %15, %16\n\t"                             \
+    "v_max3_f32 %1, %1, %17, %18\n\t"                             \
+    "v_max_f32 %1, %1, %19"
 // the last tile of a step also folds the four running maxima and compares with the lane's threshold:
-// %2 scratch, %3 = lane mask of (max >= thr) in an SGPR pair, inputs shifted by two, %24..%26 the other
-// three maxima, %27 the threshold
-#define UCFP_FOLD_LAST                                \
-    "v_mfma_i32_32x32x32_i8 %0, %4, %6, 0\n\t"        \
-    "v_max3_i32 %1, %8, %9, %10\n\t"                  \
-    "v_max3_i32 %1, %1, %11, %12\n\t"                 \
-    "v_max3_i32 %1, %1, %13, %14\n\t"                 \
-    "v_max3_i32 %1, %1, %15, %16\n\t"                 \
-    "v_mfma_i32_32x32x32_i8 %0, %5, %7, %0\n\t"       \
-    "v_max3_i32 %1, %1, %17, %18\n\t"                 \
-    "v_max3_i32 %1, %1, %19, %20\n\t"                 \
-    "v_max3_i32 %1, %1, %21, %22\n\t"                 \
-    "v_max_i32 %1, %1, %23\n\t"                       \
-    "v_max3_i32 %2, %1, %24, %25\n\t"                 \
-    "v_max_i32 %2, %2, %26\n\t"                       \
-    "v_cmp_ge_i32 %3, %2, %27\n\t"                  \
+// %2 scratch, %3 = lane mask of (max >= thr) in an SGPR pair, inputs shifted by two, %22..%24 the other
+// three maxima, %25 the threshold
+#define UCFP_FOLD_LAST                                            \
+    "v_mfma_f32_32x32x64_f8f6f4 %0, %4, %5, 0 cbsz:4 blgp:4\n\t"  \
+    "v_max3_f32 %1, %6, %7, %8\n\t"                               \
+    "v_max3_f32 %1, %1, %9, %10\n\t"                              \
+    "v_max3_f32 %1, %1, %11, %12\n\t"                             \
+    "v_max3_f32 %1, %1, %13, %14\n\t"                             \
+    "v_max3_f32 %1, %1, %15, %16\n\t"                             \
+    "v_max3_f32 %1, %1, %17, %18\n\t"                             \
+    "v_max3_f32 %1, %1, %19, %20\n\t"                             \
+    "v_max_f32 %1, %1, %21\n\t"                                   \
+    "v_max3_f32 %2, %1, %22, %23\n\t"                             \
+    "v_max_f32 %2, %2, %24\n\t"                                   \
+    "v_cmp_ge_f32 %3, %2, %25\n\t"                                \
     "s_nop 1"
-#define UCFP_FOLD_IN(b)                                                                                           \
-    "v"(A[b][0]), "v"(A[b][1]), "v"(b0), "v"(b1), "v"(Dp[b][0]), "v"(Dp[b][1]), "v"(Dp[b][2]), "v"(Dp[b][3]),     \
-        "v"(Dp[b][4]), "v"(Dp[b][5]), "v"(Dp[b][6]), "v"(Dp[b][7]), "v"(Dp[b][8]), "v"(Dp[b][9]), "v"(Dp[b][10]), \
-        "v"(Dp[b][11]), "v"(Dp[b][12]), "v"(Dp[b][13]), "v"(Dp[b][14]), "v"(Dp[b][15])
+#define UCFP_FOLD_IN(b)                                                                                          \
+    "v"(A[b]), "v"(bq), "v"(Dp[b][0]), "v"(Dp[b][1]), "v"(Dp[b][2]), "v"(Dp[b][3]), "v"(Dp[b][4]), "v"(Dp[b][5]), \
+        "v"(Dp[b][6]), "v"(Dp[b][7]), "v"(Dp[b][8]), "v"(Dp[b][9]), "v"(Dp[b][10]), "v"(Dp[b][11]),              \
+        "v"(Dp[b][12]), "v"(Dp[b][13]), "v"(Dp[b][14]), "v"(Dp[b][15])
 
-// +-1 image of the query batch in the scan's LDS layout, built once per search: [tile][K half][lane] 16 B
+// +-1 image of the query batch in the scan's LDS layout, built once per search: [tile][lane] 16 B
 __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __restrict__ queries, uint32_t nq,
                                                            i32x4* __restrict__ img) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= ((nq + 31) / 32) * 128) return;
-    const uint32_t t = s >> 7, h = (s >> 6) & 1, l = s & 63, q = t * 32 + (l & 31);
+    if (s >= ((nq + 31) / 32) * 64) return;
+    const uint32_t t = s >> 6, l = s & 63, q = t * 32 + (l & 31);
     i32x4 v = {0, 0, 0, 0};   // dead columns are all-zero: their sums are 0
-    if (q < nq) v = expand_pm1((uint32_t)(queries[q] >> (32 * h + 16 * (l >> 5))) & 0xffffu);
+    if (q < nq) v = expand_query_fp4((uint32_t)(queries[q] >> (32 * (l >> 5))));
     img[s] = v;
 }
 
@@ -372,25 +375,26 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint32_t q0 = blockIdx.y * kQP;
     const uint32_t nqp = nq - q0 < (uint32_t)kQP ? nq - q0 : (uint32_t)kQP;
     const uint32_t ntiles = (nqp + 31) / 32;
-    // [tile][K half][lane] 16 B: the B operand of query tile t, K half h, is one ds_read_b128 per lane
+    // [tile][lane] 16 B: the B operand of query tile t is one ds_read_b128 per lane
     i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
-    int* THR = reinterpret_cast<int*>(mf_lds + (size_t)(ntiles + 2) * 2048);   // [tile][32]
+    float* THR = reinterpret_cast<float*>(mf_lds + (size_t)(ntiles + 2) * 1024);   // [tile][32]
+    const float kNever = __int_as_float(0x7f800000);                               // +inf: no finite sum reaches it
     // copy of the prebuilt image + 2 zero pad tiles; 8 loads in flight per thread (a plain loop would pay the
     // global latency 17 times in a row)
-    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 128; s0 += kMW * 64 * 8) {
+    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += kMW * 64 * 8) {
         i32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t s = s0 + u * kMW * 64;
-            v[u] = s < ntiles * 128 ? qimg[(size_t)(q0 / 32) * 128 + s] : i32x4{0, 0, 0, 0};
+            v[u] = s < ntiles * 64 ? qimg[(size_t)(q0 / 32) * 64 + s] : i32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t s = s0 + u * kMW * 64;
-            if (s < (ntiles + 2) * 128) QB[s] = v[u];
+            if (s < (ntiles + 2) * 64) QB[s] = v[u];
         }
     }
-    {   // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) are all-zero, their sums stay below INT_MAX
+    {   // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) never hit
         constexpr int kT = (kQP / 32 + 2) * 32 / (kMW * 64) + 1;   // slots per thread
         uint64_t qv[kT];
         uint32_t tv[kT];
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         for (int u = 0; u < kT; u++) {
             const uint32_t s = threadIdx.x + u * kMW * 64, q = q0 + s;
             if (s < (ntiles + 2) * 32)
-                THR[s] = (s < ntiles * 32 && q < nq) ? (int)__popcll(qv[u]) - (int)tv[u] : 0x7fffffff;
+                THR[s] = (s < ntiles * 32 && q < nq) ? (float)((int)__popcll(qv[u]) - (int)tv[u]) : kNever;
         }
     }
     __syncthreads();
@@ -418,55 +422,48 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     uint4* __restrict__ mylog = log + slice * log_cap;
     uint32_t ln = 0;   // records written, wave-uniform
 
-    // lane (nn, hh) needs bits [32h + 16hh, +16) of code nn for both K halves h: two 2-byte loads
-    const uint16_t* __restrict__ chunks = reinterpret_cast<const uint16_t*>(codes);
+    // lane (nn, hh) needs bits [32 hh, +32) of code nn: one 4-byte load, a wave reads 256 contiguous bytes per tile
+    const uint32_t* __restrict__ halves = reinterpret_cast<const uint32_t*>(codes);
     auto load_codes = [&](uint32_t (&x)[kTB], size_t st) {
 #pragma unroll
         for (int b = 0; b < kTB; b++) {
             const size_t row = begin + st * kStep + 32 * b + nn;
             const bool ok = st < nsuper && row < end;
-            const uint32_t lo = ok ? (uint32_t)__builtin_nontemporal_load(chunks + row * 4 + hh) : 0u;
-            const uint32_t hi = ok ? (uint32_t)__builtin_nontemporal_load(chunks + row * 4 + 2 + hh) : 0u;
-            x[b] = lo | (hi << 16);
+            x[b] = ok ? __builtin_nontemporal_load(halves + row * 2 + hh) : 0u;
         }
     };
     // result buffers of the software pipeline.  Their content at the start of a code step is irrelevant:
-    // the first fold of every step runs against the threshold INT_MAX ("tile -1").
-    i32x16 D0[kTB], D1[kTB];
+    // the first fold of every step runs against the threshold +inf ("tile -1").
+    f32x16 D0[kTB], D1[kTB];
 #pragma unroll
     for (int b = 0; b < kTB; b++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) D0[b][e] = D1[b][e] = 0;
+        for (int e = 0; e < 16; e++) D0[b][e] = D1[b][e] = 0.f;
     uint32_t x[kTB];
     load_codes(x, gwave);
     for (size_t st = gwave; st < nsuper; st += nwaves) {
-        i32x4 A[kTB][2];
+        i32x4 A[kTB];
 #pragma unroll
-        for (int b = 0; b < kTB; b++) {
-            A[b][0] = expand01(x[b] & 0xffffu);
-            A[b][1] = expand01(x[b] >> 16);
-        }
+        for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(x[b]);
         load_codes(x, st + nwaves);   // next step's codes travel while this one computes
         const uint32_t off = (uint32_t)(st * kStep);   // row - begin of code tile 0 (the span is < 2^32)
-        // Software pipeline over the query tiles: the MFMAs of tile t are interleaved with the v_max3
-        // folding tile t-1's results -- an MFMA keeps the vector issue port for 8 of its 32 cycles, four
-        // v_max3 use 16 more, so one wave alone keeps the matrix pipe busy.  Issue order is pinned by
-        // volatile asm (the scheduler otherwise serialises MFMA bursts and fold bursts).  Hazards are
-        // covered by construction, not by compiler nops: a result is first read one whole step (8
-        // MFMAs, 256 cycles) after its MFMA issued; the accumulate pair is the same opcode on the same
-        // registers (hardware-forwarded); B operands come from LDS (waitcnt on the asm operands), A was
+        // Software pipeline over the query tiles: the MFMA of tile t is followed by the v_max3 folding tile t-1's
+        // results -- an MFMA keeps the vector issue port for 8 of its 32 cycles and eight v_max3 use 32 more, so
+        // with two waves per SIMD the issue port is saturated and the matrix pipe 80 % busy.  Issue order is
+        // pinned by volatile asm (the scheduler otherwise serialises MFMA bursts and fold bursts).  Hazards are
+        // covered by construction, not by compiler nops: a result is first read one whole step (4
+        // MFMAs, >= 128 cycles) after its MFMA issued; B operands come from LDS (waitcnt on the asm operands), A was
         // written by VALU hundreds of cycles earlier.
-        auto step = [&](uint32_t t, i32x16 (&Dn)[kTB], const i32x16 (&Dp)[kTB], const i32x4& b0, const i32x4& b1,
-                        int thr, i32x4& n0, i32x4& n1, int& nthr) {
+        auto step = [&](uint32_t t, f32x16 (&Dn)[kTB], const f32x16 (&Dp)[kTB], const i32x4& bq, float thr, i32x4& nq_,
+                        float& nthr) {
             static_assert(kTB == 4, "four fold blocks");
-            int m0, m1, m2, m3, mm;
+            float m0, m1, m2, m3, mm;
             uint64_t hit;
             // The "memory" clobbers keep the operand prefetch of the next tile (plain LDS loads: the compiler
             // places their address arithmetic and waitcnt) where it is written, in the shadow of the first
-            // MFMAs; the verdict on tile t-1 (threshold `thr`) is taken inside the last MFMA's shadow.
+            // MFMA; the verdict on tile t-1 (threshold `thr`) is taken inside the last MFMA's shadow.
             asm volatile(UCFP_FOLD : "=&v"(Dn[0]), "=&v"(m0) : UCFP_FOLD_IN(0) : "memory");
-            n0 = QB[(t + 1) * 128 + lane];   // the pad tiles end the array
-            n1 = QB[(t + 1) * 128 + 64 + lane];
+            nq_ = QB[(t + 1) * 64 + lane];   // the pad tiles end the array
             nthr = THR[(t + 1) * 32 + nn];
             asm volatile(UCFP_FOLD : "=&v"(Dn[1]), "=&v"(m1) : UCFP_FOLD_IN(1) : "memory");
             asm volatile(UCFP_FOLD : "=&v"(Dn[2]), "=&v"(m2) : UCFP_FOLD_IN(2) : "memory");
@@ -475,7 +472,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
                          : UCFP_FOLD_IN(3), "v"(m0), "v"(m1), "v"(m2), "v"(thr)
                          : "memory");
             if (__builtin_expect(hit != 0, 0)) {
-                const int m[kTB] = {m0, m1, m2, m3};
+                const float m[kTB] = {m0, m1, m2, m3};
 #pragma unroll
                 for (int b = 0; b < kTB; b++) {
                     const uint64_t mask = __ballot(m[b] >= thr);
@@ -491,21 +488,21 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
                 }
             }
         };
-        i32x4 p0 = QB[lane], p1 = QB[64 + lane], r0, r1;
+        i32x4 p = QB[lane], r;
         // tiles 0 .. ntiles: the last one is a pad tile that only drains the pipeline.  Two steps per
         // trip so that result and operand registers ping-pong without moves.  The fold inside step t
         // tests tile t-1, so its threshold lags: tp = thr(t-1), tc = thr(t), tn = thr(t+1).
-        int tp = 0x7fffffff, tc = THR[nn], tn;
+        float tp = kNever, tc = THR[nn], tn;
         uint32_t t = 0;
         for (; t + 2 <= ntiles + 1; t += 2) {
-            step(t, D0, D1, p0, p1, tp, r0, r1, tn);
+            step(t, D0, D1, p, tp, r, tn);
             tp = tc;
             tc = tn;
-            step(t + 1, D1, D0, r0, r1, tp, p0, p1, tn);
+            step(t + 1, D1, D0, r, tp, p, tn);
             tp = tc;
             tc = tn;
         }
-        if (t < ntiles + 1) step(t, D0, D1, p0, p1, tp, r0, r1, tn);
+        if (t < ntiles + 1) step(t, D0, D1, p, tp, r, tn);
         // the drain tile's MFMAs may still be writing D0/D1: 18 wait states before anything rewrites them
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     }
@@ -857,7 +854,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         if (cc < 2048) cc = 2048;
         if (cc > 65536) cc = 65536;
         p.cand_cap = (uint32_t)cc;
-        p.log_cap = 2048;
+        p.log_cap = 4096;   // per scan wave: 2048 slices x 4096 records x 16 B
         slice_range(n, p.qgroups, 256 * 16, 4096, p.fb_slices, p.fb_per_slice);
         return p;
     }
@@ -887,7 +884,7 @@ HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     w.cand_id = off;   off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 8 : 0));
     w.log_cnt = off;   off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * 4 : 0));
     w.log = off;       off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * p.log_cap * 16 : 0));
-    w.qimg = off;      off = align(off + (p.fast ? (size_t)((nq + 31) / 32) * 128 * 16 : 0));
+    w.qimg = off;      off = align(off + (p.fast ? (size_t)((nq + 31) / 32) * 64 * 16 : 0));
     w.total = off;
     return w;
 }
@@ -956,7 +953,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         i32x4* qimg = reinterpret_cast<i32x4*>(ws + w.qimg);
         if (nq > (uint32_t)kFewQueries)
-            hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 128 + 255) / 256), dim3(256), 0, stream, queries,
+            hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 64 + 255) / 256), dim3(256), 0, stream, queries,
                                nq, qimg);
         // stage thresholds alternate between tau1 and tau2: tau0 (the sample's, never strict) stays intact for the
         // fallback tier, which filters the WHOLE corpus with d <= tau0 -- a strict stage threshold would drop the k-th itself

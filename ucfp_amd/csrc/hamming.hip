@@ -366,11 +366,15 @@ __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __res
     img[s] = v;
 }
 
-// log record: x = query tile (global: q / 32), y = row - begin of the 32-code tile, (z, w) = lane ballot
+// log record: x = query tile (global: q / 32), y = row - begin of the 32-code tile, (z, w) = lane ballot.
+// Launched with kMW waves per workgroup, or kMW / 2 (one per SIMD) for a stage too short to give every wave of the
+// full grid two steps: the waves of a SIMD share its issue port, so halving them halves the quantum a stage is rounded
+// up to at the price of ~13 % of the steady-state rate.
 __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint64_t* __restrict__ codes, size_t begin, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
     const i32x4* __restrict__ qimg, const uint32_t* __restrict__ tau, uint4* __restrict__ log,
     uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ overflow) {
+    const uint32_t nthreads = blockDim.x, mw = nthreads >> 6;   // waves in this workgroup
     extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
     const uint32_t q0 = blockIdx.y * kQP;
     const uint32_t nqp = nq - q0 < (uint32_t)kQP ? nq - q0 : (uint32_t)kQP;
@@ -381,33 +385,33 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const float kNever = __int_as_float(0x7f800000);                               // +inf: no finite sum reaches it
     // copy of the prebuilt image + 2 zero pad tiles; 8 loads in flight per thread (a plain loop would pay the
     // global latency 17 times in a row)
-    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += kMW * 64 * 8) {
+    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += nthreads * 8) {
         i32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const uint32_t s = s0 + u * kMW * 64;
+            const uint32_t s = s0 + u * nthreads;
             v[u] = s < ntiles * 64 ? qimg[(size_t)(q0 / 32) * 64 + s] : i32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const uint32_t s = s0 + u * kMW * 64;
+            const uint32_t s = s0 + u * nthreads;
             if (s < (ntiles + 2) * 64) QB[s] = v[u];
         }
     }
-    {   // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) never hit
-        constexpr int kT = (kQP / 32 + 2) * 32 / (kMW * 64) + 1;   // slots per thread
-        uint64_t qv[kT];
-        uint32_t tv[kT];
+    // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) never hit
+    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 32; s0 += nthreads * 4) {
+        uint64_t qv[4];
+        uint32_t tv[4];
 #pragma unroll
-        for (int u = 0; u < kT; u++) {
-            const uint32_t s = threadIdx.x + u * kMW * 64, q = q0 + s;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t s = s0 + u * nthreads, q = q0 + s;
             const bool live = s < ntiles * 32 && q < nq;
             qv[u] = live ? queries[q] : 0ull;
             tv[u] = live ? tau[q] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < kT; u++) {
-            const uint32_t s = threadIdx.x + u * kMW * 64, q = q0 + s;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t s = s0 + u * nthreads, q = q0 + s;
             if (s < (ntiles + 2) * 32)
                 THR[s] = (s < ntiles * 32 && q < nq) ? (float)((int)__popcll(qv[u]) - (int)tv[u]) : kNever;
         }
@@ -416,9 +420,9 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
 
     const int lane = threadIdx.x & 63;
     const int nn = lane & 31, hh = lane >> 5;
-    const size_t gwave = (size_t)blockIdx.x * kMW + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * kMW;
+    const size_t gwave = (size_t)blockIdx.x * mw + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * mw;
     const size_t nsuper = (end - begin + kStep - 1) / kStep;
-    const size_t slice = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kMW + (threadIdx.x >> 6);
+    const size_t slice = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * mw + (threadIdx.x >> 6);
     uint4* __restrict__ mylog = log + slice * log_cap;
     uint32_t ln = 0;   // records written, wave-uniform
 
@@ -964,8 +968,11 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         for (uint32_t sidx = 0; sidx < p.nstages; sidx++) {
             const size_t end = p.stage_end[sidx];
             const size_t supers = (end - begin + kStep - 1) / kStep;
-            unsigned wgs = 256;   // one workgroup of kMW waves per CU (the query image fills its LDS)
-            if ((size_t)wgs * kMW > supers) wgs = (unsigned)((supers + kMW - 1) / kMW);
+            // one workgroup per CU (the query image fills its LDS): kMW waves, or half of them for a stage that would
+            // not give every wave of the full grid three steps (see the kernel's header)
+            const unsigned mw = supers < (size_t)256 * kMW * 3 ? kMW / 2 : kMW;
+            unsigned wgs = 256;
+            if ((size_t)wgs * mw > supers) wgs = (unsigned)((supers + mw - 1) / mw);
             if (nq <= (uint32_t)kFewQueries) {
                 const size_t per_block = 256 * 8;
                 size_t blocks = (end - begin + per_block - 1) / per_block;
@@ -975,11 +982,11 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                                    u64(w.cand_id), p.cand_cap, u32(w.overflow));
             } else {
             // every wave of the scan writes its slice's record count, and the slices of a launch are 0 .. wgs * passes *
-            // kMW - 1: the rescan covers exactly those (no memset of the counters)
-            hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(kMW * 64), lds, stream, codes, begin, end,
+            // mw - 1: the rescan covers exactly those (no memset of the counters)
+            hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(mw * 64), lds, stream, codes, begin, end,
                                queries, nq, (const i32x4*)qimg, (const uint32_t*)tau_cur,
                                reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow));
-            hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * (unsigned)kMW), dim3(256), 0, stream, codes, ids, begin, end, queries,
+            hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw), dim3(256), 0, stream, codes, ids, begin, end, queries,
                                (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
                                u64(w.cand_id), p.cand_cap, u32(w.overflow));

@@ -290,7 +290,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kQP = 4096;    // queries per pass (their +-1 image is resident in LDS): one pass per search call
 constexpr int kTB = 4;       // 32-code tiles per wave step
-constexpr int kMW = 8;       // waves per workgroup (2 per SIMD; the loop is software-pipelined inside a wave)
+constexpr int kMW = 16;      // waves per workgroup (4 per SIMD; the loop is software-pipelined inside a wave)
 constexpr int kStep = kTB * 32;
 static_assert(kQP >= (int)kHammingMaxBatch, "one pass covers a whole search call");
 
@@ -320,11 +320,11 @@ size_t hamming_mfma_lds_bytes(uint32_t nq) {
 }
 uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) * kMW; }
 
-// One code tile of the software-pipelined step, as text: the MFMA, then eight instructions folding the previous
-// tile's results.  %0 result, %1 running max, %2 the code tile (A), %3 the query tile (B), %4..%19 the 16
-// previous results of this lane.
+// One code tile of the software-pipelined step, as text: eight instructions folding the tile's PREVIOUS results
+// (query tile t-1), then the MFMA of query tile t into the same registers -- the results live in place, 16 registers
+// per code tile.  %0 the results (read-write), %1 running max, %2 the code tile (A), %3 the query tile (B), %4..%19
+// the 16 results as scalars (the same registers as %0).
 #define UCFP_FOLD                                                 \
-    "v_mfma_f32_32x32x64_f8f6f4 %0, %2, %3, 0 cbsz:4 blgp:4\n\t"  \
     "v_max3_f32 %1, %4, %5, %6\n\t"                               \
     "v_max3_f32 %1, %1, %7, %8\n\t"                               \
     "v_max3_f32 %1, %1, %9, %10\n\t"                              \
@@ -332,12 +332,12 @@ uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) 
     "v_max3_f32 %1, %1, %13, %14\n\t"                             \
     "v_max3_f32 %1, %1, %15, %16\n\t"                             \
     "v_max3_f32 %1, %1, %17, %18\n\t"                             \
-    "v_max_f32 %1, %1, %19"
+    "v_max_f32 %1, %1, %19\n\t"                                   \
+    "v_mfma_f32_32x32x64_f8f6f4 %0, %2, %3, 0 cbsz:4 blgp:4"
 // the last tile of a step also folds the four running maxima and compares with the lane's threshold:
 // %2 scratch, %3 = lane mask of (max >= thr) in an SGPR pair, inputs shifted by two, %22..%24 the other
 // three maxima, %25 the threshold
 #define UCFP_FOLD_LAST                                            \
-    "v_mfma_f32_32x32x64_f8f6f4 %0, %4, %5, 0 cbsz:4 blgp:4\n\t"  \
     "v_max3_f32 %1, %6, %7, %8\n\t"                               \
     "v_max3_f32 %1, %1, %9, %10\n\t"                              \
     "v_max3_f32 %1, %1, %11, %12\n\t"                             \
@@ -349,11 +349,12 @@ uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) 
     "v_max3_f32 %2, %1, %22, %23\n\t"                             \
     "v_max_f32 %2, %2, %24\n\t"                                   \
     "v_cmp_ge_f32 %3, %2, %25\n\t"                                \
-    "s_nop 1"
-#define UCFP_FOLD_IN(b)                                                                                          \
-    "v"(A[b]), "v"(bq), "v"(Dp[b][0]), "v"(Dp[b][1]), "v"(Dp[b][2]), "v"(Dp[b][3]), "v"(Dp[b][4]), "v"(Dp[b][5]), \
-        "v"(Dp[b][6]), "v"(Dp[b][7]), "v"(Dp[b][8]), "v"(Dp[b][9]), "v"(Dp[b][10]), "v"(Dp[b][11]),              \
-        "v"(Dp[b][12]), "v"(Dp[b][13]), "v"(Dp[b][14]), "v"(Dp[b][15])
+    "v_mfma_f32_32x32x64_f8f6f4 %0, %4, %5, 0 cbsz:4 blgp:4\n\t"  \
+    "s_nop 0"
+#define UCFP_FOLD_IN(b)                                                                                      \
+    "v"(A[b]), "v"(bq), "v"(D[b][0]), "v"(D[b][1]), "v"(D[b][2]), "v"(D[b][3]), "v"(D[b][4]), "v"(D[b][5]),  \
+        "v"(D[b][6]), "v"(D[b][7]), "v"(D[b][8]), "v"(D[b][9]), "v"(D[b][10]), "v"(D[b][11]), "v"(D[b][12]), \
+        "v"(D[b][13]), "v"(D[b][14]), "v"(D[b][15])
 
 // +-1 image of the query batch in the scan's LDS layout, built once per search: [tile][lane] 16 B
 __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __restrict__ queries, uint32_t nq,
@@ -366,10 +367,10 @@ __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __res
     img[s] = v;
 }
 
-// log record: x = query tile (global: q / 32), y = row - begin of the 32-code tile, (z, w) = lane ballot.
-// Launched with kMW waves per workgroup, or kMW / 2 (one per SIMD) for a stage too short to give every wave of the
-// full grid two steps: the waves of a SIMD share its issue port, so halving them halves the quantum a stage is rounded
-// up to at the price of ~13 % of the steady-state rate.
+// log record (48 bytes, one per suspect step of a wave): query tile (global: q / 32), row - begin of the step's first
+// code, then the lane ballots of its four 32-code tiles.
+// Launched with 4, 8 or kMW waves per workgroup (launch_hamming_search picks per stage: fewer waves round a short
+// stage up to a smaller quantum, more waves cover each other's stalls in a long one).
 __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint64_t* __restrict__ codes, size_t begin, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
     const i32x4* __restrict__ qimg, const uint32_t* __restrict__ tau, uint4* __restrict__ log,
@@ -420,10 +421,11 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
 
     const int lane = threadIdx.x & 63;
     const int nn = lane & 31, hh = lane >> 5;
-    const size_t gwave = (size_t)blockIdx.x * mw + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * mw;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, in an SGPR
+    const size_t gwave = (size_t)blockIdx.x * mw + wv, nwaves = (size_t)gridDim.x * mw;
     const size_t nsuper = (end - begin + kStep - 1) / kStep;
-    const size_t slice = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * mw + (threadIdx.x >> 6);
-    uint4* __restrict__ mylog = log + slice * log_cap;
+    const size_t slice = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * mw + wv;
+    uint4* __restrict__ mylog = log + slice * log_cap * 3;   // 48-byte records
     uint32_t ln = 0;   // records written, wave-uniform
 
     // lane (nn, hh) needs bits [32 hh, +32) of code nn: one 4-byte load, a wave reads 256 contiguous bytes per tile
@@ -436,13 +438,13 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
             x[b] = ok ? __builtin_nontemporal_load(halves + row * 2 + hh) : 0u;
         }
     };
-    // result buffers of the software pipeline.  Their content at the start of a code step is irrelevant:
+    // results of the software pipeline, in place.  Their content at the start of a code step is irrelevant:
     // the first fold of every step runs against the threshold +inf ("tile -1").
-    f32x16 D0[kTB], D1[kTB];
+    f32x16 D[kTB];
 #pragma unroll
     for (int b = 0; b < kTB; b++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) D0[b][e] = D1[b][e] = 0.f;
+        for (int e = 0; e < 16; e++) D[b][e] = 0.f;
     uint32_t x[kTB];
     load_codes(x, gwave);
     for (size_t st = gwave; st < nsuper; st += nwaves) {
@@ -451,126 +453,135 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(x[b]);
         load_codes(x, st + nwaves);   // next step's codes travel while this one computes
         const uint32_t off = (uint32_t)(st * kStep);   // row - begin of code tile 0 (the span is < 2^32)
-        // Software pipeline over the query tiles: the MFMA of tile t is followed by the v_max3 folding tile t-1's
-        // results -- an MFMA keeps the vector issue port for 8 of its 32 cycles and eight v_max3 use 32 more, so
-        // with two waves per SIMD the issue port is saturated and the matrix pipe 80 % busy.  Issue order is
-        // pinned by volatile asm (the scheduler otherwise serialises MFMA bursts and fold bursts).  Hazards are
-        // covered by construction, not by compiler nops: a result is first read one whole step (4
-        // MFMAs, >= 128 cycles) after its MFMA issued; B operands come from LDS (waitcnt on the asm operands), A was
-        // written by VALU hundreds of cycles earlier.
-        auto step = [&](uint32_t t, f32x16 (&Dn)[kTB], const f32x16 (&Dp)[kTB], const i32x4& bq, float thr, i32x4& nq_,
-                        float& nthr) {
+        // Software pipeline over the query tiles: per code tile, the v_max3 folding query tile t-1's results, then the
+        // MFMA of query tile t into the same registers -- an MFMA keeps the vector issue port for 8 of its 32 cycles
+        // and eight v_max3 use 32 more, so the issue port is what saturates (the matrix pipe is 80 % busy) and the
+        // waves of a SIMD only have to cover each other's stalls.  Issue order is pinned by volatile asm (the
+        // scheduler otherwise serialises MFMA bursts and fold bursts).  Hazards are covered by construction, not by
+        // compiler nops: a result is first read one whole step (3 MFMAs and 4 folds, >= 150 cycles) after its MFMA
+        // issued, and the MFMA that overwrites it issues after the fold that read it; B operands come from LDS
+        // (waitcnt on the asm operands), A was written by VALU hundreds of cycles earlier.
+        auto step = [&](uint32_t t, const i32x4& bq, float thr, i32x4& nq_, float& nthr) {
             static_assert(kTB == 4, "four fold blocks");
             float m0, m1, m2, m3, mm;
             uint64_t hit;
             // The "memory" clobbers keep the operand prefetch of the next tile (plain LDS loads: the compiler
-            // places their address arithmetic and waitcnt) where it is written, in the shadow of the first
-            // MFMA; the verdict on tile t-1 (threshold `thr`) is taken inside the last MFMA's shadow.
-            asm volatile(UCFP_FOLD : "=&v"(Dn[0]), "=&v"(m0) : UCFP_FOLD_IN(0) : "memory");
+            // places their address arithmetic and waitcnt) where it is written, early in the step.
+            asm volatile(UCFP_FOLD : "+v"(D[0]), "=&v"(m0) : UCFP_FOLD_IN(0) : "memory");
             nq_ = QB[(t + 1) * 64 + lane];   // the pad tiles end the array
             nthr = THR[(t + 1) * 32 + nn];
-            asm volatile(UCFP_FOLD : "=&v"(Dn[1]), "=&v"(m1) : UCFP_FOLD_IN(1) : "memory");
-            asm volatile(UCFP_FOLD : "=&v"(Dn[2]), "=&v"(m2) : UCFP_FOLD_IN(2) : "memory");
+            asm volatile(UCFP_FOLD : "+v"(D[1]), "=&v"(m1) : UCFP_FOLD_IN(1) : "memory");
+            asm volatile(UCFP_FOLD : "+v"(D[2]), "=&v"(m2) : UCFP_FOLD_IN(2) : "memory");
             asm volatile(UCFP_FOLD_LAST
-                         : "=&v"(Dn[3]), "=&v"(m3), "=&v"(mm), "=s"(hit)
+                         : "+v"(D[3]), "=&v"(m3), "=&v"(mm), "=s"(hit)
                          : UCFP_FOLD_IN(3), "v"(m0), "v"(m1), "v"(m2), "v"(thr)
                          : "memory");
             if (__builtin_expect(hit != 0, 0)) {
-                const float m[kTB] = {m0, m1, m2, m3};
-#pragma unroll
-                for (int b = 0; b < kTB; b++) {
-                    const uint64_t mask = __ballot(m[b] >= thr);
-                    if (mask) {
-                        if (ln < log_cap) {
-                            if (lane == 0)
-                                mylog[ln] = make_uint4(q0 / 32 + (t - 1), off + 32 * b, (uint32_t)mask, (uint32_t)(mask >> 32));
-                        } else if (lane == 0) {
-                            *overflow = 1;
-                        }
-                        ln++;
-                    }
+                // straight-line: the four per-tile ballots and ONE 48-byte record written by lanes 0..2 (in the first
+                // stages nearly every step comes through here, and a branch per code tile was most of their time)
+                const uint64_t k0 = __ballot(m0 >= thr), k1 = __ballot(m1 >= thr), k2 = __ballot(m2 >= thr),
+                               k3 = __ballot(m3 >= thr);
+                const uint4 ra = make_uint4(q0 / 32 + (t - 1), off, (uint32_t)k0, (uint32_t)(k0 >> 32));
+                const uint4 rb = make_uint4((uint32_t)k1, (uint32_t)(k1 >> 32), (uint32_t)k2, (uint32_t)(k2 >> 32));
+                const uint4 rc = make_uint4((uint32_t)k3, (uint32_t)(k3 >> 32), 0u, 0u);
+                uint4 v;
+                v.x = lane == 0 ? ra.x : lane == 1 ? rb.x : rc.x;
+                v.y = lane == 0 ? ra.y : lane == 1 ? rb.y : rc.y;
+                v.z = lane == 0 ? ra.z : lane == 1 ? rb.z : rc.z;
+                v.w = lane == 0 ? ra.w : lane == 1 ? rb.w : rc.w;
+                if (ln < log_cap) {
+                    if (lane < 3) mylog[(size_t)ln * 3 + lane] = v;
+                } else if (lane == 0) {
+                    *overflow = 1;
                 }
+                ln++;
             }
         };
         i32x4 p = QB[lane], r;
         // tiles 0 .. ntiles: the last one is a pad tile that only drains the pipeline.  Two steps per
-        // trip so that result and operand registers ping-pong without moves.  The fold inside step t
+        // trip so that the operand registers ping-pong without moves.  The fold inside step t
         // tests tile t-1, so its threshold lags: tp = thr(t-1), tc = thr(t), tn = thr(t+1).
         float tp = kNever, tc = THR[nn], tn;
         uint32_t t = 0;
         for (; t + 2 <= ntiles + 1; t += 2) {
-            step(t, D0, D1, p, tp, r, tn);
+            step(t, p, tp, r, tn);
             tp = tc;
             tc = tn;
-            step(t + 1, D1, D0, r, tp, p, tn);
+            step(t + 1, r, tp, p, tn);
             tp = tc;
             tc = tn;
         }
-        if (t < ntiles + 1) step(t, D0, D1, p, tp, r, tn);
-        // the drain tile's MFMAs may still be writing D0/D1: 18 wait states before anything rewrites them
+        if (t < ntiles + 1) step(t, p, tp, r, tn);
+        // the drain tile's MFMAs may still be writing D: 18 wait states before anything else touches it
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     }
     if (lane == 0) log_cnt[slice] = ln < log_cap ? ln : log_cap;
 }
 
-// One block per log slice, one LANE per record: exact distances for the flagged (query, 16 results) lanes of
-// the record; true candidates are appended to the per-query lists.
+// gridDim.y blocks per log slice, one lane per (record, code tile): exact distances for the flagged (query, 16 results) lanes;
+// true candidates are appended to the per-query lists.
 __global__ __launch_bounds__(256) void hamming_rescan(
     const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t begin, size_t end,
     const uint64_t* __restrict__ queries, const uint32_t* __restrict__ tau, const uint4* __restrict__ log,
     const uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ cand_cnt,
     uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id, uint32_t cand_cap, uint32_t* __restrict__ overflow) {
     const uint32_t cnt = log_cnt[blockIdx.x];
-    for (uint32_t rix = threadIdx.x; rix < cnt; rix += 256) {
-        const uint4 r = log[(size_t)blockIdx.x * log_cap + rix];
-        uint64_t mask = (uint64_t)r.z | ((uint64_t)r.w << 32);
-        while (mask) {
-            const int l = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const uint32_t q = r.x * 32 + (l & 31);   // a flagged lane always has a live query
-            const uint64_t qv = queries[q];
-            const uint32_t tq = tau[q];
-            // the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
-            const size_t row0 = begin + r.y + 4 * (l >> 5);
-            uint64_t cv[16];
-            if (row0 + 28 <= end) {   // four groups of four consecutive codes: 16-byte loads (row0 is a multiple of 4)
-                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    // one thread per (record, code tile): the record's header and that tile's lane ballot
+    for (uint32_t idx = blockIdx.y * 256 + threadIdx.x; idx < cnt * kTB; idx += gridDim.y * 256) {
+        const uint32_t rix = idx / kTB, b = idx % kTB;
+        const uint32_t* rec = reinterpret_cast<const uint32_t*>(log + ((size_t)blockIdx.x * log_cap + rix) * 3);
+        const uint2 ra = *reinterpret_cast<const uint2*>(rec);
+        const uint2 mk = *reinterpret_cast<const uint2*>(rec + 2 + 2 * b);
+        {
+            uint64_t mask = (uint64_t)mk.x | ((uint64_t)mk.y << 32);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t q = ra.x * 32 + (l & 31);   // a flagged lane always has a live query
+                const uint64_t qv = queries[q];
+                const uint32_t tq = tau[q];
+                // the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
+                const size_t row0 = begin + ra.y + 32 * b + 4 * (l >> 5);
+                uint64_t cv[16];
+                if (row0 + 28 <= end) {   // four groups of four consecutive codes: 16-byte loads (row0 is a multiple of 4)
+                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const u64x2 a = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g);
-                    const u64x2 b = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g + 2);
-                    cv[4 * g] = a[0];
-                    cv[4 * g + 1] = a[1];
-                    cv[4 * g + 2] = b[0];
-                    cv[4 * g + 3] = b[1];
+                    for (int g = 0; g < 4; g++) {
+                        const u64x2 c0 = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g);
+                        const u64x2 c1 = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g + 2);
+                        cv[4 * g] = c0[0];
+                        cv[4 * g + 1] = c0[1];
+                        cv[4 * g + 2] = c1[0];
+                        cv[4 * g + 3] = c1[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+                        cv[j] = codes[row < end ? row : begin];
+                    }
                 }
-            } else {
+                bool found = false;
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     const size_t row = row0 + (j & 3) + 8 * (j >> 2);
-                    cv[j] = codes[row < end ? row : begin];
-                }
-            }
-            bool found = false;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const size_t row = row0 + (j & 3) + 8 * (j >> 2);
-                const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
-                if (d <= tq && row < end) {
-                    found = true;
-                    const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
-                    if (pos < cand_cap) {
-                        cand_d[(size_t)q * cand_cap + pos] = d;
-                        cand_id[(size_t)q * cand_cap + pos] = ids[row];
-                    } else {
-                        *overflow = 1;
+                    const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
+                    if (d <= tq && row < end) {
+                        found = true;
+                        const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
+                        if (pos < cand_cap) {
+                            cand_d[(size_t)q * cand_cap + pos] = d;
+                            cand_id[(size_t)q * cand_cap + pos] = ids[row];
+                        } else {
+                            *overflow = 1;
+                        }
                     }
                 }
+                // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
+                // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
+                // this kernel disagree about the result layout -> distrust the filter, take the robust tier
+                if (!found && (int)__popcll(qv) - (int)tq > 0) *overflow = 1;
             }
-            // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
-            // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
-            // this kernel disagree about the result layout -> distrust the filter, take the robust tier
-            if (!found && (int)__popcll(qv) - (int)tq > 0) *overflow = 1;
         }
     }
 }
@@ -858,7 +869,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         if (cc < 2048) cc = 2048;
         if (cc > 65536) cc = 65536;
         p.cand_cap = (uint32_t)cc;
-        p.log_cap = 4096;   // per scan wave: 2048 slices x 4096 records x 16 B
+        p.log_cap = 1024;   // suspect steps per scan wave: 4096 slices x 1024 records x 48 B
         slice_range(n, p.qgroups, 256 * 16, 4096, p.fb_slices, p.fb_per_slice);
         return p;
     }
@@ -887,7 +898,7 @@ HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     w.cand_d = off;    off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 4 : 0));
     w.cand_id = off;   off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 8 : 0));
     w.log_cnt = off;   off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * 4 : 0));
-    w.log = off;       off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * p.log_cap * 16 : 0));
+    w.log = off;       off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * p.log_cap * 48 : 0));
     w.qimg = off;      off = align(off + (p.fast ? (size_t)((nq + 31) / 32) * 64 * 16 : 0));
     w.total = off;
     return w;
@@ -968,11 +979,23 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         for (uint32_t sidx = 0; sidx < p.nstages; sidx++) {
             const size_t end = p.stage_end[sidx];
             const size_t supers = (end - begin + kStep - 1) / kStep;
-            // one workgroup per CU (the query image fills its LDS): kMW waves, or half of them for a stage that would
-            // not give every wave of the full grid three steps (see the kernel's header)
-            const unsigned mw = supers < (size_t)256 * kMW * 3 ? kMW / 2 : kMW;
+            // one workgroup per CU (the query image fills its LDS) of 4, 8 or 16 waves: the waves of a SIMD share its
+            // issue port, so a stage costs ~ rounds x (time of one step with that many waves per SIMD); the relative
+            // step times 1 : 1.77 : 3.38 are tools/ubench_mfma_i8.hip's (46.6 / 52.7 / 55.2 T pairs/s at 1 / 2 / 4 waves)
+            unsigned mw = kMW;
+            {
+                double best = 1e30;
+                const unsigned opt[3] = {4, 8, (unsigned)kMW};
+                const double rel[3] = {1.0, 1.77, 3.38};
+                for (int o = 0; o < 3; o++) {
+                    const double c = (double)((supers + 256 * opt[o] - 1) / (256 * opt[o])) * rel[o];
+                    if (c < best - 1e-9) best = c, mw = opt[o];
+                }
+            }
             unsigned wgs = 256;
             if ((size_t)wgs * mw > supers) wgs = (unsigned)((supers + mw - 1) / mw);
+            // suspects are dense in the short first stages (every step logs a record): more rescan blocks per slice there
+            const unsigned rescan_parts = supers <= 4096 ? 4 : 1;
             if (nq <= (uint32_t)kFewQueries) {
                 const size_t per_block = 256 * 8;
                 size_t blocks = (end - begin + per_block - 1) / per_block;
@@ -986,7 +1009,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(mw * 64), lds, stream, codes, begin, end,
                                queries, nq, (const i32x4*)qimg, (const uint32_t*)tau_cur,
                                reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow));
-            hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw), dim3(256), 0, stream, codes, ids, begin, end, queries,
+            hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw, rescan_parts), dim3(256), 0, stream, codes, ids, begin, end, queries,
                                (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
                                u64(w.cand_id), p.cand_cap, u32(w.overflow));

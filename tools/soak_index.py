@@ -32,8 +32,8 @@ def main():
     while time.time() - t0 < a.seconds:
         rounds += 1
         if rounds % 2:
-            n = int(rng.choice([300, 5000, 70_000, 300_000, 1_200_000]))
-            nq = int(rng.choice([1, 3, 17, 64, 65, 200, 700]))
+            n = int(rng.choice([300, 5000, 70_000, 300_000, 1_200_000, 3_000_000]))
+            nq = int(rng.choice([1, 3, 17, 64, 65, 200, 700, 2049, 4096]))
             k = int(rng.choice([1, 5, 10, 16, 17, 50]))
             g = torch.Generator(device=dev)
             g.manual_seed(int(rng.integers(1 << 30)))

@@ -1,4 +1,5 @@
-// ubench_hamming_core.hip -- the inner loop of hamming_scan_mfma in isolation (LDS-resident query tiles,
+// ubench_hamming_core.hip -- the INT8 inner loop hamming_scan_mfma had in rounds 1-2 (it now uses FP4 operands: see
+// ubench_mfma_i8.hip modes 20-22), in isolation (LDS-resident query tiles,
 // 4 code tiles in registers, software-pipelined MFMA + v_max3 fold, never-taken hit branch), with knobs
 // to find what separates it from the bare MFMA + v_max3 stream of ubench_mfma_i8.hip.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_hamming_core.hip -o tools/ubench_hamming_core.bin

@@ -1,4 +1,4 @@
-// ubench_mfma_i8.hip -- issue model behind the Hamming matrix-core filter: ns per MFMA
+// ubench_mfma_i8.hip -- issue model behind the Hamming matrix-core filter, int8 and FP4 forms: ns per MFMA
 // per SIMD for v_mfma_i32_16x16x64_i8 and v_mfma_i32_32x32x32_i8 with v_max3_i32 fillers in the gaps.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_mfma_i8.hip -o tools/ubench_mfma_i8.bin && tools/ubench_mfma_i8.bin
 #include <hip/hip_runtime.h>

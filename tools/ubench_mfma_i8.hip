@@ -49,12 +49,32 @@ __global__ __launch_bounds__(1024) void k(int* out, int iters) {
 #pragma unroll
             for (int e = 0; e < 16; e++) d[j][e] = (float)(j + e);
         float f0 = -1.f, f1 = -2.f;
+        f32x16 cc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) cc[e] = 8388608.f + 4194304.f + 1088.f;
+        const int sa = 127 + 16, sb = 127;
         for (int it = 0; it < iters; it++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (MODE == 20)
                     asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, 0 cbsz:4 blgp:4\n\tv_mfma_f32_32x32x64_f8f6f4 %3, %1, %2, 0 cbsz:4 blgp:4"
                                  : "=&v"(d[j]) : "v"(a), "v"(b), "v"(d[(j + 2) & 3]));
+                if (MODE == 23) {
+                    // two code tiles packed into one result (C = bias, second MFMA block-scaled by 2^16) and folded four
+                    // values per instruction with v_pk_maximum3_f16: 8 fold instructions per TWO MFMAs
+                    const f32x16& p = d[(j + 2) & 3];
+                    asm volatile(
+                        "v_mfma_f32_32x32x64_f8f6f4 %0, %3, %4, %21 cbsz:4 blgp:4\n\t"
+                        "v_pk_maximum3_f16 %1, %1, %5, %6\n\tv_pk_maximum3_f16 %2, %2, %7, %8\n\tv_pk_maximum3_f16 %1, %1, %9, %10\n\t"
+                        "v_pk_maximum3_f16 %2, %2, %11, %12\n\t"
+                        "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %3, %4, %0, %22, %23 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\t"
+                        "v_pk_maximum3_f16 %1, %1, %13, %14\n\tv_pk_maximum3_f16 %2, %2, %15, %16\n\tv_pk_maximum3_f16 %1, %1, %17, %18\n\t"
+                        "v_pk_maximum3_f16 %2, %2, %19, %20"
+                        : "=&v"(d[j]), "+v"(f0), "+v"(f1)
+                        : "v"(a), "v"(b), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]),
+                          "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]),
+                          "v"(p[15]), "v"(cc), "v"(sa), "v"(sb));
+                }
                 if (MODE == 21 || MODE == 22) {
                     // two tiles per asm block: the fold of the other buffers' results in the MFMA shadows
                     const f32x16& p = d[(j + 2) & 3];
@@ -190,6 +210,8 @@ int main() {
         run<20>(w, -1);
         run<21>(w, -1);
         run<22>(w, -1);
+        run<23>(w);
+        run<23>(w, -1);
     }
     return 0;
 }

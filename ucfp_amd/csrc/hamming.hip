@@ -320,41 +320,62 @@ size_t hamming_mfma_lds_bytes(uint32_t nq) {
 }
 uint32_t hamming_log_slices(uint32_t nq) { return 256u * ((nq + kQP - 1) / kQP) * kMW; }
 
-// One code tile of the software-pipelined step, as text: eight instructions folding the tile's PREVIOUS results
-// (query tile t-1), then the MFMA of query tile t into the same registers -- the results live in place, 16 registers
-// per code tile.  %0 the results (read-write), %1 running max, %2 the code tile (A), %3 the query tile (B), %4..%19
-// the 16 results as scalars (the same registers as %0).
-#define UCFP_FOLD                                                 \
-    "v_max3_f32 %1, %4, %5, %6\n\t"                               \
-    "v_max3_f32 %1, %1, %7, %8\n\t"                               \
-    "v_max3_f32 %1, %1, %9, %10\n\t"                              \
-    "v_max3_f32 %1, %1, %11, %12\n\t"                             \
-    "v_max3_f32 %1, %1, %13, %14\n\t"                             \
-    "v_max3_f32 %1, %1, %15, %16\n\t"                             \
-    "v_max3_f32 %1, %1, %17, %18\n\t"                             \
-    "v_max_f32 %1, %1, %19\n\t"                                   \
-    "v_mfma_f32_32x32x64_f8f6f4 %0, %2, %3, 0 cbsz:4 blgp:4"
-// the last tile of a step also folds the four running maxima and compares with the lane's threshold:
-// %2 scratch, %3 = lane mask of (max >= thr) in an SGPR pair, inputs shifted by two, %22..%24 the other
-// three maxima, %25 the threshold
-#define UCFP_FOLD_LAST                                            \
-    "v_max3_f32 %1, %6, %7, %8\n\t"                               \
-    "v_max3_f32 %1, %1, %9, %10\n\t"                              \
-    "v_max3_f32 %1, %1, %11, %12\n\t"                             \
-    "v_max3_f32 %1, %1, %13, %14\n\t"                             \
-    "v_max3_f32 %1, %1, %15, %16\n\t"                             \
-    "v_max3_f32 %1, %1, %17, %18\n\t"                             \
-    "v_max3_f32 %1, %1, %19, %20\n\t"                             \
-    "v_max_f32 %1, %1, %21\n\t"                                   \
-    "v_max3_f32 %2, %1, %22, %23\n\t"                             \
-    "v_max_f32 %2, %2, %24\n\t"                                   \
-    "v_cmp_ge_f32 %3, %2, %25\n\t"                                \
-    "v_mfma_f32_32x32x64_f8f6f4 %0, %4, %5, 0 cbsz:4 blgp:4\n\t"  \
+// Two code tiles share one accumulator: the matrix core itself packs their sums into one f32,
+//   D = A_a x B + C              C = 2^23 + 2^22 + 1088 in every element
+//   D = (2^16 A_b) x B + D       v_mfma_scale_...: block scale 2^16 on A (E8M0 143), 1 on B (127)
+// = 2^23 + 65536 (64 + s_b) + (1088 + s_a), an integer below 2^24, so its bit pattern is
+// 0x4B00'0000 | (64 + s_b) << 16 | (1088 + s_a): two ordered 16-bit fields, both valid monotone f16 patterns, which
+// v_pk_maximum3_f16 folds FOUR sums at a time -- 8 fold instructions per two MFMAs, which puts the loop back under the
+// matrix pipe (tools/probe_mfma_fp4_pack.hip checks the packing bit for bit; tools/ubench_mfma_i8.hip mode 23 the rate:
+// 63-64 T pairs/s on random operands against 54 for one v_max3_f32 fold per MFMA).  s_b = +64 would carry out of its
+// field; it needs popc(q) = 64, and such a query is filtered as q with bit 0 cleared and tau + 1 (see filter_query).
+// As text, in place: eight instructions folding the pair's PREVIOUS results (query tile t-1), then the two MFMAs of
+// query tile t into the same registers.  %0 the results (read-write), %1 running max (packed), %2 / %21 the two code
+// tiles (A), %3 the query tile (B), %4..%19 the 16 results as scalars (the same registers as %0), %20 the bias
+// tuple C, %22 / %23 the block scales.
+#define UCFP_FOLD_PAIR                                                                                   \
+    "v_pk_maximum3_f16 %1, %4, %5, %6\n\t"                                                               \
+    "v_pk_maximum3_f16 %1, %1, %7, %8\n\t"                                                               \
+    "v_pk_maximum3_f16 %1, %1, %9, %10\n\t"                                                              \
+    "v_pk_maximum3_f16 %1, %1, %11, %12\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %13, %14\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %15, %16\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %17, %18\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %19, %19\n\t"                                                             \
+    "v_mfma_f32_32x32x64_f8f6f4 %0, %2, %3, %20 cbsz:4 blgp:4\n\t"                                       \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %21, %3, %0, %22, %23 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+// the second pair of a step also takes the verdict: %2 scratch, %3 = lane mask of "some field >= its threshold" in an
+// SGPR pair, inputs shifted by two, %26 the first pair's maximum, %27 the threshold word (each field = threshold - 1:
+// a saturating subtraction leaves a non-zero field iff max >= threshold)
+#define UCFP_FOLD_PAIR_LAST                                                                              \
+    "v_pk_maximum3_f16 %1, %6, %7, %8\n\t"                                                               \
+    "v_pk_maximum3_f16 %1, %1, %9, %10\n\t"                                                              \
+    "v_pk_maximum3_f16 %1, %1, %11, %12\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %13, %14\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %15, %16\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %17, %18\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %19, %20\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %21, %21\n\t"                                                             \
+    "v_mfma_f32_32x32x64_f8f6f4 %0, %4, %5, %22 cbsz:4 blgp:4\n\t"                                       \
+    "v_pk_maximum3_f16 %2, %1, %26, %26\n\t"                                                             \
+    "v_pk_sub_u16 %2, %2, %27 clamp\n\t"                                                                 \
+    "v_cmp_ne_u32 %3, 0, %2\n\t"                                                                         \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %23, %5, %0, %24, %25 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\t"     \
     "s_nop 0"
-#define UCFP_FOLD_IN(b)                                                                                      \
-    "v"(A[b]), "v"(bq), "v"(D[b][0]), "v"(D[b][1]), "v"(D[b][2]), "v"(D[b][3]), "v"(D[b][4]), "v"(D[b][5]),  \
-        "v"(D[b][6]), "v"(D[b][7]), "v"(D[b][8]), "v"(D[b][9]), "v"(D[b][10]), "v"(D[b][11]), "v"(D[b][12]), \
-        "v"(D[b][13]), "v"(D[b][14]), "v"(D[b][15])
+#define UCFP_FOLD_PAIR_IN(p)                                                                                      \
+    "v"(A[2 * p]), "v"(bq), "v"(D[p][0]), "v"(D[p][1]), "v"(D[p][2]), "v"(D[p][3]), "v"(D[p][4]), "v"(D[p][5]),   \
+        "v"(D[p][6]), "v"(D[p][7]), "v"(D[p][8]), "v"(D[p][9]), "v"(D[p][10]), "v"(D[p][11]), "v"(D[p][12]),      \
+        "v"(D[p][13]), "v"(D[p][14]), "v"(D[p][15]), "v"(cc), "v"(A[2 * p + 1]), "v"(sa), "v"(sb)
+
+constexpr uint32_t kFieldHi = 0x4B00u + 64u, kFieldLo = 1088u;   // a sum s sits in its field as kField + s
+
+// The query the FILTER sees and the slack its threshold gets: popc(q) = 64 would let a sum reach +64 and carry out of
+// the packed field, so that one query is filtered with bit 0 cleared and tau + 1 -- d(q', x) <= d(q, x) + 1, so nothing
+// is lost, and hamming_rescan evaluates the suspects against the true query.
+__device__ __forceinline__ uint64_t filter_query(uint64_t q, uint32_t& slack) {
+    slack = q == ~0ull ? 1u : 0u;
+    return q == ~0ull ? q & ~1ull : q;
+}
 
 // +-1 image of the query batch in the scan's LDS layout, built once per search: [tile][lane] 16 B
 __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __restrict__ queries, uint32_t nq,
@@ -363,7 +384,8 @@ __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __res
     if (s >= ((nq + 31) / 32) * 64) return;
     const uint32_t t = s >> 6, l = s & 63, q = t * 32 + (l & 31);
     i32x4 v = {0, 0, 0, 0};   // dead columns are all-zero: their sums are 0
-    if (q < nq) v = expand_query_fp4((uint32_t)(queries[q] >> (32 * (l >> 5))));
+    uint32_t slack;
+    if (q < nq) v = expand_query_fp4((uint32_t)(filter_query(queries[q], slack) >> (32 * (l >> 5))));
     img[s] = v;
 }
 
@@ -382,8 +404,8 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint32_t ntiles = (nqp + 31) / 32;
     // [tile][lane] 16 B: the B operand of query tile t is one ds_read_b128 per lane
     i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
-    float* THR = reinterpret_cast<float*>(mf_lds + (size_t)(ntiles + 2) * 1024);   // [tile][32]
-    const float kNever = __int_as_float(0x7f800000);                               // +inf: no finite sum reaches it
+    uint32_t* THR = reinterpret_cast<uint32_t*>(mf_lds + (size_t)(ntiles + 2) * 1024);   // [tile][32]: packed, threshold - 1 per field
+    constexpr uint32_t kNever = 0xffffffffu;                                               // no field exceeds it
     // copy of the prebuilt image + 2 zero pad tiles; 8 loads in flight per thread (a plain loop would pay the
     // global latency 17 times in a row)
     for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += nthreads * 8) {
@@ -408,13 +430,19 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
             const uint32_t s = s0 + u * nthreads, q = q0 + s;
             const bool live = s < ntiles * 32 && q < nq;
             qv[u] = live ? queries[q] : 0ull;
-            tv[u] = live ? tau[q] : 0u;
+            tv[u] = live ? (tau[q] < 64u ? tau[q] : 64u) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t s = s0 + u * nthreads, q = q0 + s;
-            if (s < (ntiles + 2) * 32)
-                THR[s] = (s < ntiles * 32 && q < nq) ? (float)((int)__popcll(qv[u]) - (int)tv[u]) : kNever;
+            if (s < (ntiles + 2) * 32) {
+                uint32_t slack;
+                const uint64_t fq = filter_query(qv[u], slack);
+                const int thr = (int)__popcll(fq) - (int)(tv[u] + slack);   // a pair is a suspect iff its sum >= thr (>= -65)
+                THR[s] = (s < ntiles * 32 && q < nq)
+                             ? ((uint32_t)((int)kFieldHi + thr - 1) << 16) | (uint32_t)((int)kFieldLo + thr - 1)
+                             : kNever;
+            }
         }
     }
     __syncthreads();
@@ -438,13 +466,19 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
             x[b] = ok ? __builtin_nontemporal_load(halves + row * 2 + hh) : 0u;
         }
     };
-    // results of the software pipeline, in place.  Their content at the start of a code step is irrelevant:
-    // the first fold of every step runs against the threshold +inf ("tile -1").
-    f32x16 D[kTB];
+    // results of the software pipeline, in place: one accumulator per PAIR of code tiles.  Their content at the start
+    // of a code step is irrelevant: the first fold of every step runs against the threshold "never" ("tile -1").
+    static_assert(kTB == 4, "two pairs of code tiles per step");
+    f32x16 D[kTB / 2];
 #pragma unroll
-    for (int b = 0; b < kTB; b++)
+    for (int p = 0; p < kTB / 2; p++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) D[b][e] = 0.f;
+        for (int e = 0; e < 16; e++) D[p][e] = 0.f;
+    f32x16 cc;   // the bias tuple C
+#pragma unroll
+    for (int e = 0; e < 16; e++) cc[e] = 8388608.f + 4194304.f + (float)kFieldLo;
+    asm volatile("" : "+v"(cc));   // sixteen registers, not one rematerialised constant
+    const int sa = 127 + 16, sb = 127;   // E8M0 block scales: 2^16 on the pair's second code tile, 1 on the queries
     uint32_t x[kTB];
     load_codes(x, gwave);
     for (size_t st = gwave; st < nsuper; st += nwaves) {
@@ -453,34 +487,34 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(x[b]);
         load_codes(x, st + nwaves);   // next step's codes travel while this one computes
         const uint32_t off = (uint32_t)(st * kStep);   // row - begin of code tile 0 (the span is < 2^32)
-        // Software pipeline over the query tiles: per code tile, the v_max3 folding query tile t-1's results, then the
-        // MFMA of query tile t into the same registers -- an MFMA keeps the vector issue port for 8 of its 32 cycles
-        // and eight v_max3 use 32 more, so the issue port is what saturates (the matrix pipe is 80 % busy) and the
-        // waves of a SIMD only have to cover each other's stalls.  Issue order is pinned by volatile asm (the
-        // scheduler otherwise serialises MFMA bursts and fold bursts).  Hazards are covered by construction, not by
-        // compiler nops: a result is first read one whole step (3 MFMAs and 4 folds, >= 150 cycles) after its MFMA
-        // issued, and the MFMA that overwrites it issues after the fold that read it; B operands come from LDS
-        // (waitcnt on the asm operands), A was written by VALU hundreds of cycles earlier.
-        auto step = [&](uint32_t t, const i32x4& bq, float thr, i32x4& nq_, float& nthr) {
-            static_assert(kTB == 4, "four fold blocks");
-            float m0, m1, m2, m3, mm;
+        // Software pipeline over the query tiles: per pair of code tiles, the v_pk_maximum3 folding query tile t-1's
+        // results, then the two MFMAs of query tile t into the same registers.  4 MFMAs (128 matrix-pipe cycles)
+        // carry 19 vector instructions (76 issue cycles) + their own 32: the matrix pipe is the bound again, and the
+        // waves of a SIMD cover each other's stalls.  Issue order is pinned by volatile asm (the scheduler otherwise
+        // serialises MFMA bursts and fold bursts).  Hazards are covered by construction, not by compiler nops: a result
+        // is first read one whole step (2 MFMAs and a fold, >= 96 cycles) after its last MFMA issued, the accumulating
+        // MFMA follows its producer back to back (forwarded), and the MFMA that overwrites a result issues after the
+        // fold that read it; B operands come from LDS (waitcnt on the asm operands), A was written by VALU hundreds of
+        // cycles earlier.
+        auto step = [&](uint32_t t, const i32x4& bq, uint32_t thr, i32x4& nq_, uint32_t& nthr) {
+            uint32_t m01, m23, vs;
             uint64_t hit;
             // The "memory" clobbers keep the operand prefetch of the next tile (plain LDS loads: the compiler
             // places their address arithmetic and waitcnt) where it is written, early in the step.
-            asm volatile(UCFP_FOLD : "+v"(D[0]), "=&v"(m0) : UCFP_FOLD_IN(0) : "memory");
+            asm volatile(UCFP_FOLD_PAIR : "+v"(D[0]), "=&v"(m01) : UCFP_FOLD_PAIR_IN(0) : "memory");
             nq_ = QB[(t + 1) * 64 + lane];   // the pad tiles end the array
             nthr = THR[(t + 1) * 32 + nn];
-            asm volatile(UCFP_FOLD : "+v"(D[1]), "=&v"(m1) : UCFP_FOLD_IN(1) : "memory");
-            asm volatile(UCFP_FOLD : "+v"(D[2]), "=&v"(m2) : UCFP_FOLD_IN(2) : "memory");
-            asm volatile(UCFP_FOLD_LAST
-                         : "+v"(D[3]), "=&v"(m3), "=&v"(mm), "=s"(hit)
-                         : UCFP_FOLD_IN(3), "v"(m0), "v"(m1), "v"(m2), "v"(thr)
+            asm volatile(UCFP_FOLD_PAIR_LAST
+                         : "+v"(D[1]), "=&v"(m23), "=&v"(vs), "=s"(hit)
+                         : UCFP_FOLD_PAIR_IN(1), "v"(m01), "v"(thr)
                          : "memory");
             if (__builtin_expect(hit != 0, 0)) {
-                // straight-line: the four per-tile ballots and ONE 48-byte record written by lanes 0..2 (in the first
-                // stages nearly every step comes through here, and a branch per code tile was most of their time)
-                const uint64_t k0 = __ballot(m0 >= thr), k1 = __ballot(m1 >= thr), k2 = __ballot(m2 >= thr),
-                               k3 = __ballot(m3 >= thr);
+                // straight-line: the four per-tile ballots (m01 = fields of tiles 1 | 0, m23 = tiles 3 | 2; a threshold
+                // field holds threshold - 1) and ONE 48-byte record written by lanes 0..2 (in the first stages nearly
+                // every step comes through here, and a branch per code tile was most of their time)
+                const uint32_t tl = thr & 0xffffu, th = thr >> 16;
+                const uint64_t k0 = __ballot((m01 & 0xffffu) > tl), k1 = __ballot((m01 >> 16) > th),
+                               k2 = __ballot((m23 & 0xffffu) > tl), k3 = __ballot((m23 >> 16) > th);
                 const uint4 ra = make_uint4(q0 / 32 + (t - 1), off, (uint32_t)k0, (uint32_t)(k0 >> 32));
                 const uint4 rb = make_uint4((uint32_t)k1, (uint32_t)(k1 >> 32), (uint32_t)k2, (uint32_t)(k2 >> 32));
                 const uint4 rc = make_uint4((uint32_t)k3, (uint32_t)(k3 >> 32), 0u, 0u);
@@ -501,7 +535,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         // tiles 0 .. ntiles: the last one is a pad tile that only drains the pipeline.  Two steps per
         // trip so that the operand registers ping-pong without moves.  The fold inside step t
         // tests tile t-1, so its threshold lags: tp = thr(t-1), tc = thr(t), tn = thr(t+1).
-        float tp = kNever, tc = THR[nn], tn;
+        uint32_t tp = kNever, tc = THR[nn], tn;
         uint32_t t = 0;
         for (; t + 2 <= ntiles + 1; t += 2) {
             step(t, p, tp, r, tn);
@@ -580,7 +614,9 @@ __global__ __launch_bounds__(256) void hamming_rescan(
                 // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
                 // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
                 // this kernel disagree about the result layout -> distrust the filter, take the robust tier
-                if (!found && (int)__popcll(qv) - (int)tq > 0) *overflow = 1;
+                // (the all-ones query is filtered one bit off and one distance wider -- filter_query -- so its lanes may be
+                // flagged in vain)
+                if (!found && (int)__popcll(qv) - (int)tq > 0 && qv != ~0ull) *overflow = 1;
             }
         }
     }
@@ -980,13 +1016,14 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             const size_t end = p.stage_end[sidx];
             const size_t supers = (end - begin + kStep - 1) / kStep;
             // one workgroup per CU (the query image fills its LDS) of 4, 8 or 16 waves: the waves of a SIMD share its
-            // issue port, so a stage costs ~ rounds x (time of one step with that many waves per SIMD); the relative
-            // step times 1 : 1.77 : 3.38 are tools/ubench_mfma_i8.hip's (46.6 / 52.7 / 55.2 T pairs/s at 1 / 2 / 4 waves)
+            // matrix pipe, so a stage costs ~ rounds x (time of one step with that many waves per SIMD); the relative
+            // step times 1 : 2 : 3.9 are tools/ubench_mfma_i8.hip's (mode 23: 62.7 / 62.8 / 64.0 T pairs/s at 1 / 2 / 4
+            // waves); more waves also cover the stalls the bare stream does not have
             unsigned mw = kMW;
             {
                 double best = 1e30;
                 const unsigned opt[3] = {4, 8, (unsigned)kMW};
-                const double rel[3] = {1.0, 1.77, 3.38};
+                const double rel[3] = {1.0, 2.0, 3.9};
                 for (int o = 0; o < 3; o++) {
                     const double c = (double)((supers + 256 * opt[o] - 1) / (256 * opt[o])) * rel[o];
                     if (c < best - 1e-9) best = c, mw = opt[o];

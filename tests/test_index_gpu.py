@@ -91,8 +91,8 @@ def test_hamming_adversarial_order(gpu_ctx, oracle, nq):
                                     (400_003, 65, 128), (262_144, 64, 10), (262_145, 97, 1)])
 def test_hamming_two_tier_matches_oracle(gpu_ctx, oracle, n, nq, k):
     """n >= 2^18 takes the staged filter path: the matrix-core scan (hamming_scan_mfma + hamming_rescan)
-    for more than 64 queries, the lane-per-code scan (hamming_scan_lanes) below; ragged tails, two
-    query passes (nq > 2048), k up to 128."""
+    for more than 64 queries, the lane-per-code scan (hamming_scan_lanes) below; ragged tails, more than
+    2048 queries in the LDS image, k up to 128."""
     from ucfp_amd import index
     rng = np.random.default_rng(n + k)
     ids, codes, queries = _planted_corpus(rng, n, nq, planted_per_q=12)
@@ -100,6 +100,49 @@ def test_hamming_two_tier_matches_oracle(gpu_ctx, oracle, n, nq, k):
     ix.upsert(0, ids, codes)
     g_ids, _, g_d, g_c = ix.search(0, queries, k)
     o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+    assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids)
+    ix.close()
+
+
+def test_hamming_matrix_filter_extreme_words(gpu_ctx, oracle):
+    """The matrix-core filter packs two sums per result register in fields that hold -64 .. +63: the all-ones query
+    (whose sum against an all-ones code is +64) is filtered one bit off and one distance wider (hamming.hip
+    filter_query), and all-zero / all-one queries and codes, in both tiles of a pair and next to ordinary near
+    neighbours, must come out exact."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(6464)
+    n, nq, k = 400_000, 160, 10
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    q = rng.integers(0, 2**64, nq, dtype=np.uint64)
+    ones, zeros = np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64(0)
+    q[0], q[1], q[33], q[70] = ones, zeros, ones, zeros
+    q[2] = ones ^ np.uint64(1)                      # popc 63: the ordinary path right next to the special one
+    for pos in (5, 37, 64 + 9, 100_003, 250_000 + 40, n - 1):            # both halves of a pair, several steps and stages
+        codes[pos] = ones
+        codes[pos + 1 if pos + 1 < n else pos - 1] = zeros
+    for j in range(nq):                                                  # ordinary planted neighbours in the same tiles
+        for d in (1, 3, 6):
+            pos = int(rng.integers(0, n))
+            if codes[pos] in (ones, zeros):
+                continue
+            flip = np.uint64(0)
+            for b in rng.choice(64, d, replace=False):
+                flip |= np.uint64(1) << np.uint64(b)
+            codes[pos] = q[j] ^ flip
+    ids = rng.permutation(n).astype(np.uint64)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    ix.upsert(0, ids, codes)
+    g_ids, _, g_d, g_c = ix.search(0, q, k)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, q, k)
+    assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids)
+    assert g_d[0, 0] == 0 and g_d[1, 0] == 0      # the all-ones / all-zeros queries found their exact matches
+    ix.close()
+    # ... and through the append-only (strict thresholds) path with ids ascending
+    ix = index.DeviceIndex(index.HAMMING64, flags=index.APPEND_ONLY, ctx=gpu_ctx)
+    ids2 = np.arange(n, dtype=np.uint64) * 2 + 7
+    ix.upsert(0, ids2, codes)
+    g_ids, _, g_d, g_c = ix.search(0, q, k)
+    o_ids, o_d, o_c = oracle.hamming_topk(ids2, codes, q, k)
     assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids)
     ix.close()
 

@@ -48,7 +48,14 @@ def main():
                 ids = torch.sort(ids * 3 + 1).values
                 if rng.random() < 0.3 and n > 10:     # ... except for one inversion far into the corpus
                     ids[n - 5], ids[n - 4] = ids[n - 4].clone(), ids[n - 5].clone()
+            if rng.random() < 0.3:     # extreme words: the packed fields of the matrix filter hold sums -64 .. +63
+                pos = torch.randint(0, n, (6,), device=dev, generator=g)
+                codes[pos[:3]] = -1
+                codes[pos[3:]] = 0
             q = codes[torch.randint(0, n, (nq,), device=dev, generator=g)] ^ 5
+            if rng.random() < 0.3:
+                q[0] = -1
+                q[nq // 2] = 0
             ix = index.DeviceIndex(index.HAMMING64, flags=index.APPEND_ONLY, ctx=ctx)
             ix.append_dev(0, ids.data_ptr(), codes.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
             o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)

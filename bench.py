@@ -381,10 +381,11 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
     # The filter is a +-1 x 0/1 contraction with FP4 (e2m1) operands on v_mfma_f32_32x32x64_f8f6f4: 64 MACs =
     # 128 ops per code-query pair, exact in f32.  Dense FP4 peak = 4 x the bf16 rate = 10 PFLOP/s
     # (MI355X_MICROARCH.md, matrix cores); the int8 form of rounds 1-2 (5 POP/s peak) is kept as the second
-    # yardstick.  The loop is bound by the vector issue port, not the matrix pipe: one MFMA (8 issue cycles) + eight
-    # v_max3 (32) per 1024 pairs = 40 cycles against the pipe's 32, i.e. <= 0.8 of the FP4 peak at 2.4 GHz;
-    # tools/ubench_mfma_i8.hip modes 20-22 measure 52.7 T pairs/s (6.7 PFLOP/s) for that bare stream on random
-    # operands (the chip clocks down under toggling data), 72 T without the fold.
+    # yardstick.  Two code tiles share an accumulator (the second MFMA block-scaled by 2^16) and v_pk_maximum3_f16
+    # folds four sums per instruction, so the matrix pipe bounds the loop: tools/ubench_mfma_i8.hip mode 23 measures
+    # 63-64 T pairs/s (8.1 PFLOP/s) for that bare stream on random operands (the chip holds ~1.95 GHz under toggling
+    # data, not 2.4), 72 T without any fold.  PMC on the 100 M search's largest dispatch
+    # (profiles/r02/hamming_scan_pmc.txt): matrix pipes busy 80 % of the kernel's cycles at 1.86 GHz.
     fp4_peak = 10.0e15
     i8_peak = 5.0e15
     ops_per_pair = 128.0
@@ -403,7 +404,7 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
                              "incl. staging, rescan and selection)",
                      "frac": pairs_per_s * ops_per_pair / world / fp4_peak,
                      "frac_of_int8_peak": pairs_per_s * ops_per_pair / world / i8_peak,
-                     "issue_bound_frac": 0.8,
+                     "matrix_pipe_busy_pmc": 0.80, "clock_GHz_pmc": 1.86,
                      "T_pairs_per_s_per_gpu": pairs_per_s / world / 1e12,
                      "hbm_GBs_per_gpu": ((nq + 4095) // 4096) * n_local * 8 / (dt / args.ann_steps) / 1e9},
         "planted_neighbours_found": f"{planted_found}/{(nq + 1) // 2}",

@@ -266,17 +266,17 @@ __global__ __launch_bounds__(64) void hamming_scan(
 //   K map   lane (nn, hh) holds the 32 bits [32 hh, 32 hh + 32) of row / column nn as 4 dwords of 8 nibbles; bit
 //           4 i + j of that word sits in nibble i of dword j.  A and B use the SAME map, which is all a dot product
 //           needs, and it makes the expansion four shifted ANDs with 0x22222222 per code tile.
-//   layout  the 16 results a lane holds all belong to ONE query (column = lane & 31), so they are
-//           folded with v_max3_f32 (two results per instruction) before the single compare against the
-//           lane's threshold: no C operand, 8 fold instructions per MFMA.  The vector issue port (8 cycles per
-//           MFMA + 4 per v_max3) is now what bounds the loop: 40 cycles per 1024 pairs against the matrix pipe's 32
-//           (tools/ubench_mfma_i8.hip modes 20-22: 52.7 T pairs/s on random operands against 33.2 for the int8 form)
+//   layout  the 16 results a lane holds all belong to ONE query (column = lane & 31), so they are folded to one
+//           maximum before the single compare against the lane's threshold.  Folding with v_max3_f32 (two results per
+//           instruction, 8 per MFMA) put the vector issue port -- 8 cycles per MFMA + 32 -- over the matrix pipe's 32,
+//           so two code tiles share an accumulator and the matrix core packs their sums into one f32 (UCFP_FOLD_PAIR
+//           below): v_pk_maximum3_f16 then folds four sums per instruction and the matrix pipe is the bound again
 //   LDS     the +-1 image of the whole batch (<= 4096 queries, 1 KiB per 32-query tile,
-//           lane-contiguous for ds_read_b128) and the thresholds, built once per workgroup
-//   wave    expands 4 code tiles (128 codes) into registers, then walks all query tiles: 4 MFMAs, 32 v_max3,
-//           1 compare per tile, software-pipelined by one tile
-//   hits    rare by construction of tau.  The scan only RECORDS a suspect block (query tile, code
-//           tile, ballot of the lanes over threshold) in the wave's own slice of a global log -- one
+//           lane-contiguous for ds_read_b128) and the packed thresholds, built once per workgroup
+//   wave    expands 4 code tiles = 2 pairs (128 codes) into registers, then walks all query tiles: 4 MFMAs,
+//           17 v_pk_maximum3, a saturating subtract and a compare per tile, software-pipelined by one tile, in place
+//   hits    rare by construction of tau.  The scan only RECORDS a suspect step (query tile, first code, the four
+//           code tiles' ballots of the lanes over threshold) in the wave's own slice of a global log -- one
 //           store, no atomics, nothing to wait for.  hamming_rescan then re-evaluates the flagged
 //           (query, 16-code half) combinations with plain popcounts (exact; it checks the result layout it
 //           assumes and raises the fallback flag on any disagreement) and appends the true candidates to the

@@ -86,6 +86,12 @@ struct SelectPlan {
     size_t per_slice = 0;
 };
 SelectPlan select_plan(size_t n, uint32_t nq);
+// few queries (<= 16): chunk minima -> threshold -> gather (topk.hip); `mins` = select_pruned_ws_bytes(n, nq) bytes
+bool select_pruned_ok(size_t n, uint32_t nq, uint32_t k);
+size_t select_pruned_ws_bytes(size_t n, uint32_t nq);
+int launch_select_pruned_u32(const uint32_t* keys, const uint64_t* ids, size_t n, uint32_t nq, uint32_t k, uint32_t* mins,
+                             uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream,
+                             const uint32_t* run_flag);
 int launch_select_topk_u32(const uint32_t* keys, const uint64_t* ids, size_t n, const SelectPlan& p,
                            uint32_t nq, uint32_t k, uint64_t* part_ids, uint32_t* part_key,
                            uint32_t* part_cnt, hipStream_t stream, const uint32_t* run_flag = nullptr);

@@ -250,6 +250,8 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     off = align256(off + fq * cap * 4);
     const size_t o_flag = off;
     off = align256(off + 256);
+    const size_t o_mins = off;
+    off = align256(off + ucfp::select_pruned_ws_bytes(n, 16));
     int rc = ix->ws.ensure(off);
     if (rc) return rc;
     uint8_t* w = ix->ws.p;
@@ -266,6 +268,11 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     // select + merge of `m` rows of keys for `cnt` queries, within the partial space reserved for the chunk
     auto select_merge = [&](size_t m, uint32_t cnt, uint64_t* o_ids, uint32_t* o_keys, uint32_t* o_cnt,
                             const uint32_t* run_flag) {
+        if (ucfp::select_pruned_ok(m, cnt, k)) {   // a handful of queries: two launches instead of select + merge tree
+            ucfp::launch_select_pruned_u32(keymat, s->ids, m, cnt, k, reinterpret_cast<uint32_t*>(w + o_mins), o_ids, o_keys,
+                                           o_cnt, st, run_flag);
+            return;
+        }
         ucfp::SelectPlan pl = ucfp::select_plan(m, cnt);
         if (pl.slices > sp.slices) {
             pl.per_slice = (((m + sp.slices - 1) / sp.slices) + 63) & ~(size_t)63;

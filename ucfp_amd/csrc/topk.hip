@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/ucfp_hip.h"
 #include "common.h"
 
 namespace ucfp {
@@ -275,6 +276,219 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
         }
         if (out_cnt) out_cnt[(size_t)blockIdx.y * nq + q] = emitted;
     }
+}
+
+// ---- few queries over a dense key matrix: chunk minima, a threshold, a gather ---------------------------------------------
+// With one to sixteen queries the slice lists + merge tree above are a chain of launches whose latencies (60-110 us) show
+// next to a 0.5 ms corpus pass.  Here: (1) one wave per chunk of `chunk` keys writes the chunk's minimum; (2) one workgroup
+// per query finds tau = the k-th smallest chunk minimum by an 8-bit radix select in LDS -- at least k keys are <= tau, so
+// the k best keys all are -- and gathers the keys <= tau from the chunks whose minimum is <= tau (about k of them), ranks
+// the handful of candidates by (key, id) and writes the answer.  Exact for any input: when candidates pile up (ties) the
+// list is pruned to its best k and the threshold tightened, the way select_topk_u32 does it.
+constexpr uint32_t kPruneMaxChunks = 4096;   // chunk minima per query held in LDS
+constexpr uint32_t kPruneBatch = 4;          // pieces of 1024 keys gathered between two checks of the list
+constexpr uint32_t kPruneKeep = 1024;        // the list is pruned to its best k once it holds more than this
+constexpr uint32_t kPruneCap = kPruneKeep + kPruneBatch * 1024;   // candidate slots: a trip always fits
+
+__global__ __launch_bounds__(64) void chunk_min_u32(const uint32_t* __restrict__ keys, size_t n, size_t chunk, uint32_t nchunks,
+                                                    uint32_t* __restrict__ mins, const uint32_t* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
+    const uint32_t q = blockIdx.y, c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t* __restrict__ kq = keys + (size_t)q * n;
+    const size_t s0 = (size_t)c * chunk, s1 = s0 + chunk < n ? s0 + chunk : n;
+    uint32_t m = 0xffffffffu;
+    // the key matrix of a query starts at a multiple of 4 keys only if n is one: 16-byte loads when it is
+    if ((n & 3) == 0) {
+        for (size_t i = s0 + (size_t)lane * 4; i < s1; i += 64 * 4) {
+            if (i + 4 <= s1) {
+                const uint4 v = *reinterpret_cast<const uint4*>(kq + i);
+                m = min(min(m, min(v.x, v.y)), min(v.z, v.w));
+            } else {
+                for (size_t j = i; j < s1; j++) m = min(m, kq[j]);
+            }
+        }
+    } else {
+        for (size_t i = s0 + lane; i < s1; i += 64) m = min(m, kq[i]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, kWave));
+    if (lane == 0) mins[(size_t)q * nchunks + c] = m;
+}
+
+__global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ ids,
+                                                         size_t n, size_t chunk, uint32_t nchunks,
+                                                         const uint32_t* __restrict__ mins, uint32_t nq, uint32_t k,
+                                                         uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_key,
+                                                         uint32_t* __restrict__ out_cnt, const uint32_t* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
+    __shared__ uint32_t s_min[kPruneMaxChunks];      // chunk minima, then the list of qualifying chunks
+    __shared__ uint32_t s_key[kPruneCap];
+    __shared__ uint64_t s_id[kPruneCap];
+    __shared__ uint32_t s_tkey[UCFP_INDEX_MAX_K];
+    __shared__ uint64_t s_tid[UCFP_INDEX_MAX_K];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_sel[2];                    // radix select: chosen bin, rank left inside it
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_n;                         // candidates in the list
+    __shared__ uint32_t s_nqual;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* __restrict__ kq = keys + (size_t)q * n;
+
+    for (uint32_t c = tid; c < nchunks; c += 256) s_min[c] = mins[(size_t)q * nchunks + c];
+    if (tid == 0) s_n = 0, s_nqual = 0;
+    __syncthreads();
+    // ---- tau = the kk-th smallest chunk minimum, most significant byte first
+    uint32_t tau = 0xffffffffu;
+    if (nchunks > k) {
+        uint32_t prefix = 0, mask = 0, want = k;     // rank (1-based) still to find among the minima matching `prefix`
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            s_hist[tid] = 0;
+            __syncthreads();
+            for (uint32_t c = tid; c < nchunks; c += 256) {
+                const uint32_t v = s_min[c];
+                if ((v & mask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            {   // the bin holding rank `want`: inclusive scan of the 256 counts, one per thread
+                const uint32_t cntb = s_hist[tid];
+                uint32_t incl = cntb;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, kWave);
+                    if ((int)(tid & 63) >= off) incl += o;
+                }
+                if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+                __syncthreads();
+                uint32_t before = 0;
+                for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wtot[w];
+                incl += before;
+                if (incl - cntb < want && want <= incl) {      // exactly one thread: the minima matching `prefix` number >= want
+                    s_sel[0] = tid;
+                    s_sel[1] = want - (incl - cntb);
+                }
+            }
+            __syncthreads();
+            prefix |= s_sel[0] << shift;
+            mask |= 255u << shift;
+            want = s_sel[1];
+        }
+        tau = prefix;
+    }
+    // ---- the chunks that can hold a key <= tau, compacted in place behind a barrier (order does not matter)
+    uint32_t mine[kPruneMaxChunks / 256];
+#pragma unroll
+    for (uint32_t u = 0; u < kPruneMaxChunks / 256; u++) {
+        const uint32_t c = tid + u * 256;
+        mine[u] = c < nchunks ? s_min[c] : 0xffffffffu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kPruneMaxChunks / 256; u++) {
+        const uint32_t c = tid + u * 256;
+        if (c < nchunks && mine[u] <= tau && mine[u] != 0xffffffffu) s_min[atomicAdd(&s_nqual, 1u)] = c;
+    }
+    __syncthreads();
+    const uint32_t nqual = s_nqual;
+
+    // keep the best min(n, k) candidates, sorted by (key, id), at the front of the list; returns their number
+    auto prune = [&]() -> uint32_t {
+        const uint32_t cn = s_n < kPruneCap ? s_n : kPruneCap;
+        // rank of every candidate = the number of candidates before it (ranks are unique: ids are)
+        for (uint32_t e = tid; e < cn; e += 256) {
+            const uint32_t dk = s_key[e];
+            const uint64_t di = s_id[e];
+            uint32_t rank = 0;
+            for (uint32_t o = 0; o < cn; o++) rank += key_less(s_key[o], s_id[o], dk, di) ? 1u : 0u;
+            if (rank < k) {
+                s_tkey[rank] = dk;
+                s_tid[rank] = di;
+            }
+        }
+        __syncthreads();
+        const uint32_t kept = cn < k ? cn : k;
+        if (tid < kept) {
+            s_key[tid] = s_tkey[tid];
+            s_id[tid] = s_tid[tid];
+        }
+        if (tid == 0) s_n = kept;
+        __syncthreads();
+        return kept;
+    };
+
+    // ---- gather: kPruneBatch x 1024 keys per trip, every thread one group of 4 keys per chunk piece
+    const uint32_t pieces_per_chunk = (uint32_t)((chunk + 1023) / 1024);
+    const uint32_t npieces = nqual * pieces_per_chunk;
+    for (uint32_t p0 = 0; p0 < npieces; p0 += kPruneBatch) {
+        uint32_t kv[kPruneBatch][4];
+        size_t at[kPruneBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kPruneBatch; u++) {
+            const uint32_t pc = p0 + u;
+            at[u] = n;
+#pragma unroll
+            for (int j = 0; j < 4; j++) kv[u][j] = 0xffffffffu;
+            if (pc < npieces) {
+                const uint32_t c = s_min[pc / pieces_per_chunk], piece = pc % pieces_per_chunk;
+                const size_t c1 = (size_t)c * chunk + chunk < n ? (size_t)c * chunk + chunk : n;
+                const size_t i = (size_t)c * chunk + (size_t)piece * 1024 + (size_t)tid * 4;
+                at[u] = i;
+                if ((n & 3) == 0 && i + 4 <= c1) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(kq + i);
+                    kv[u][0] = v.x, kv[u][1] = v.y, kv[u][2] = v.z, kv[u][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (i + j < c1) kv[u][j] = kq[i + j];
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPruneBatch; u++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (kv[u][j] != 0xffffffffu && kv[u][j] <= tau) {
+                    const uint32_t pos = atomicAdd(&s_n, 1u);
+                    if (pos < kPruneCap) {
+                        s_key[pos] = kv[u][j];
+                        s_id[pos] = ids[at[u] + j];
+                    }
+                }
+        __syncthreads();
+        // a trip adds at most kPruneBatch x 1024 candidates: prune while another one might not fit
+        if (s_n > kPruneKeep) {                          // block-uniform
+            // (an overfull list cannot happen: the check runs after every trip and a trip fits behind the last prune)
+            const uint32_t kept = prune();
+            if (kept >= k && s_key[k - 1] < tau) tau = s_key[k - 1];
+            __syncthreads();
+        }
+    }
+    const uint32_t kept = prune();
+    for (uint32_t r = tid; r < k; r += 256) {
+        out_ids[(size_t)q * k + r] = r < kept ? s_id[r] : ~0ull;
+        out_key[(size_t)q * k + r] = r < kept ? s_key[r] : 0xffffffffu;
+    }
+    if (tid == 0 && out_cnt) out_cnt[q] = kept;
+}
+
+size_t select_pruned_chunk(size_t n) {
+    size_t chunk = 1024;
+    while ((n + chunk - 1) / chunk > kPruneMaxChunks) chunk *= 2;
+    return chunk;
+}
+size_t select_pruned_ws_bytes(size_t, uint32_t nq) { return (size_t)kPruneMaxChunks * nq * 4 + 256; }
+bool select_pruned_ok(size_t n, uint32_t nq, uint32_t k) { return nq >= 1 && nq <= 16 && k >= 1 && k <= UCFP_INDEX_MAX_K && n >= 1; }
+
+int launch_select_pruned_u32(const uint32_t* keys, const uint64_t* ids, size_t n, uint32_t nq, uint32_t k, uint32_t* mins,
+                             uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream,
+                             const uint32_t* run_flag) {
+    if (nq == 0) return 0;
+    const size_t chunk = select_pruned_chunk(n);
+    const uint32_t nchunks = (uint32_t)((n + chunk - 1) / chunk);
+    hipLaunchKernelGGL(chunk_min_u32, dim3(nchunks, nq), dim3(64), 0, stream, keys, n, chunk, nchunks, mins, run_flag);
+    hipLaunchKernelGGL(select_pruned_u32, dim3(nq), dim3(256), 0, stream, keys, ids, n, chunk, nchunks,
+                       (const uint32_t*)mins, nq, k, out_ids, out_key, out_cnt, run_flag);
+    return 0;
 }
 
 SelectPlan select_plan(size_t n, uint32_t nq) {

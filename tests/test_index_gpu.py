@@ -656,6 +656,43 @@ def test_cosine_duplicate_rows_and_any_id_order(gpu_ctx, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("nq,dim", [(1, 384), (3, 768), (7, 768), (16, 512)])
+def test_cosine_few_queries_massive_ties(gpu_ctx, nq, dim):
+    """One to sixteen queries select through chunk minima + a threshold + a gather (topk.hip select_pruned_u32): a corpus
+    that is mostly copies of a few rows makes every chunk qualify and the candidate list overflow again and again, and
+    the answer must still be the k smallest ids among the best-scoring copies -- plus the plain case around it (distinct
+    rows, k larger than the number of chunks, zero rows)."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(1000 + nq)
+    n, k = 150_000, 25
+    base = rng.standard_normal((20, dim)).astype(np.float32)
+    pick = rng.integers(0, 20, n)
+    rows = base[pick].copy()
+    loose = rng.integers(0, n, 2000)
+    rows[loose] = rng.standard_normal((2000, dim)).astype(np.float32)     # some distinct rows in between
+    pick[loose] = -1
+    rows[rng.integers(0, n, 7)] = 0.0
+    ids = rng.permutation(n).astype(np.uint64) * np.uint64(3) + np.uint64(11)
+    queries = (base[:nq] if nq <= 20 else base[np.arange(nq) % 20]).copy()
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    nrm = np.linalg.norm(rows, axis=1)
+    for q in range(nq):
+        live = (pick == q) & (nrm > 0)
+        best = np.sort(ids[live])[:k]            # every copy of base[q] scores 1.0, above everything else
+        assert g_c[q] == k and np.array_equal(g_ids[q], best), q
+        assert np.all(np.abs(g_sc[q] - 1.0) <= 1e-5)
+    ix.close()
+    # a corpus smaller than one chunk, k above its size
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids[:17], rows[:17])
+    g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    live17 = int((nrm[:17] > 0).sum())
+    assert np.all(g_c == live17) and np.all(g_ids[:, live17:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    ix.close()
+
+
 @pytest.mark.parametrize("nq", [6, 90])
 def test_hamming_strict_thresholds_with_overflowing_lists(gpu_ctx, oracle, nq):
     """Ascending ids (strict stage thresholds) AND a clustered corpus whose candidate lists overflow: the fallback tier then

@@ -370,10 +370,13 @@ __global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __re
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     float a0 = acc0[g][i], a1 = acc1[g][i];
-                    a0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x124, 0xf, 0xf, false));   // row_ror:4
-                    a1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0x124, 0xf, 0xf, false));
+                    // row_ror:8 FIRST, then row_ror:4: the pairs {b, b + 2} and then {pair, other pair} are the same two
+                    // operands in every lane, so all lanes end with the same bits (the other order associates
+                    // differently per lane, and copies of a row in the two halves of a tile then differ by an ulp)
                     a0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x128, 0xf, 0xf, false));   // row_ror:8
                     a1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0x128, 0xf, 0xf, false));
+                    a0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x124, 0xf, 0xf, false));   // row_ror:4
+                    a1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0x124, 0xf, 0xf, false));
                     a0 += __shfl_xor(a0, 16, 64);
                     a1 += __shfl_xor(a1, 16, 64);
                     a0 += __shfl_xor(a0, 32, 64);

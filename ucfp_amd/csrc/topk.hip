@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restr
     };
 
     // ---- gather: kPruneBatch x 1024 keys per trip, every thread one group of 4 keys per chunk piece
+    uint64_t tau_id = ~0ull;   // with key == tau: ids below this one still count (no id is ~0)
     const uint32_t pieces_per_chunk = (uint32_t)((chunk + 1023) / 1024);
     const uint32_t npieces = nqual * pieces_per_chunk;
     for (uint32_t p0 = 0; p0 < npieces; p0 += kPruneBatch) {
@@ -448,10 +449,14 @@ __global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restr
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (kv[u][j] != 0xffffffffu && kv[u][j] <= tau) {
+                    const uint64_t id = ids[at[u] + j];
+                    // once the list has been pruned, a key equal to the k-th best only matters with a smaller id (a corpus
+                    // of copies would otherwise refill the list on every trip)
+                    if (kv[u][j] == tau && id >= tau_id) continue;
                     const uint32_t pos = atomicAdd(&s_n, 1u);
                     if (pos < kPruneCap) {
                         s_key[pos] = kv[u][j];
-                        s_id[pos] = ids[at[u] + j];
+                        s_id[pos] = id;
                     }
                 }
         __syncthreads();
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restr
         if (s_n > kPruneKeep) {                          // block-uniform
             // (an overfull list cannot happen: the check runs after every trip and a trip fits behind the last prune)
             const uint32_t kept = prune();
-            if (kept >= k && s_key[k - 1] < tau) tau = s_key[k - 1];
+            if (kept >= k) tau = s_key[k - 1], tau_id = s_id[k - 1];   // the k-th best itself is in the list already
             __syncthreads();
         }
     }

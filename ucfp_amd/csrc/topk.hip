@@ -286,6 +286,7 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
 // the handful of candidates by (key, id) and writes the answer.  Exact for any input: when candidates pile up (ties) the
 // list is pruned to its best k and the threshold tightened, the way select_topk_u32 does it.
 constexpr uint32_t kPruneMaxChunks = 4096;   // chunk minima per query held in LDS
+constexpr uint32_t kPruneMaxQueries = 16;    // one workgroup per query: beyond this the slice lists fill the chip as well (32 / 48 / 64 queries measured level)
 constexpr uint32_t kPruneBatch = 4;          // pieces of 1024 keys gathered between two checks of the list
 constexpr uint32_t kPruneKeep = 1024;        // the list is pruned to its best k once it holds more than this
 constexpr uint32_t kPruneCap = kPruneKeep + kPruneBatch * 1024;   // candidate slots: a trip always fits
@@ -482,7 +483,7 @@ size_t select_pruned_chunk(size_t n) {
     return chunk;
 }
 size_t select_pruned_ws_bytes(size_t, uint32_t nq) { return (size_t)kPruneMaxChunks * nq * 4 + 256; }
-bool select_pruned_ok(size_t n, uint32_t nq, uint32_t k) { return nq >= 1 && nq <= 16 && k >= 1 && k <= UCFP_INDEX_MAX_K && n >= 1; }
+bool select_pruned_ok(size_t n, uint32_t nq, uint32_t k) { return nq >= 1 && nq <= kPruneMaxQueries && k >= 1 && k <= UCFP_INDEX_MAX_K && n >= 1; }
 
 int launch_select_pruned_u32(const uint32_t* keys, const uint64_t* ids, size_t n, uint32_t nq, uint32_t k, uint32_t* mins,
                              uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream,

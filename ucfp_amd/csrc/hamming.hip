@@ -7,9 +7,9 @@
 //
 // Three scans share one structure (an upper bound tau[q] on the final k-th distance turns the search into a
 // filter; bounds come from a 32k-code sample, then from the candidates found so far, over ranges growing 4x):
-//   > 64 queries   hamming_scan_mfma   the pair distance as a +-1 x 0/1 contraction on the matrix cores (FP4
+//   many queries   hamming_scan_mfma   the pair distance as a +-1 x 0/1 contraction on the matrix cores (FP4
 //                                      operands, exact); suspect blocks are logged and re-evaluated exactly by hamming_rescan
-//   <= 64 queries  hamming_scan_lanes  lane = code, queries in SGPRs: a pure HBM stream
+//   few queries    hamming_scan_lanes  lane = code, queries in SGPRs: a pure HBM stream
 //   robust tier    hamming_scan        lane = query, corpus code wave-uniform (s_load_dwordx16), per-pair work
 //                                      2 v_xor + 2 v_bcnt + 1 compare, lane-private LDS candidate lists pruned
 //                                      wave-synchronously: small corpora, and -- gated device-side by a flag --
@@ -627,7 +627,14 @@ __global__ __launch_bounds__(256) void hamming_rescan(
 // the scan is a pure HBM stream: each lane holds 8 codes (4 x 16-byte loads in flight), the queries
 // and their thresholds are wave-uniform (SGPRs), a pair costs 2 v_xor + 2 v_bcnt + 1 compare, and the
 // rare candidate is appended to its query's list directly.  Same staging and lists as the MFMA filter.
-constexpr int kFewQueries = 64;
+constexpr int kFewQueries = 64;   // most queries the lane-per-code scan takes (its histogram's LDS); see few_queries()
+// Which filter a batch takes.  The lane-per-code scan costs ~ n x nq popcount work on top of ~0.1 ms of staging launches, the
+// matrix filter ~0.15 ms (10 M codes) .. 0.37 ms (100 M) nearly flat up to 100 queries (its longer chain of launches:
+// query image, rescans): measured crossovers 40 queries at 10 M codes, 20 at 100 M (tools/bench_hamming.py).
+static bool few_queries(size_t n, uint32_t nq) {
+    const uint32_t most = n >= (size_t)50'000'000 ? 20u : n >= (size_t)5'000'000 ? 40u : (uint32_t)kFewQueries;
+    return nq <= most;
+}
 
 __global__ __launch_bounds__(256) void hamming_sample_hist_lanes(const uint64_t* __restrict__ codes, size_t sample_n,
                                                                  const uint64_t* __restrict__ queries, uint32_t nq,
@@ -893,7 +900,8 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     if (p.fast) {
         size_t e = p.sample_n;
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
-        // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs)
+        // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs; the same
+        // for batches of 9 .. 256 queries, where 16x measured 5-20 % slower)
         constexpr size_t growth = 4;
         while (e < n && p.nstages < 12) {
             e = e * growth < n ? e * growth : n;
@@ -974,7 +982,8 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         return 0;
     }
     // tau0 from the sample
-    if (nq <= (uint32_t)kFewQueries) {
+    const bool few = few_queries(n, nq);
+    if (few) {
         (void)hipMemsetAsync(u32(w.hist), 0, (size_t)nq * 65 * 4, stream);
         hipLaunchKernelGGL(hamming_sample_hist_lanes, dim3((unsigned)((p.sample_n + 1023) / 1024)), dim3(256), 0, stream,
                            codes, p.sample_n, queries, nq, u32(w.hist));
@@ -1003,7 +1012,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_scan_mfma),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         i32x4* qimg = reinterpret_cast<i32x4*>(ws + w.qimg);
-        if (nq > (uint32_t)kFewQueries)
+        if (!few)
             hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 64 + 255) / 256), dim3(256), 0, stream, queries,
                                nq, qimg);
         // stage thresholds alternate between tau1 and tau2: tau0 (the sample's, never strict) stays intact for the
@@ -1033,7 +1042,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             if ((size_t)wgs * mw > supers) wgs = (unsigned)((supers + mw - 1) / mw);
             // suspects are dense in the short first stages (every step logs a record): more rescan blocks per slice there
             const unsigned rescan_parts = supers <= 4096 ? 4 : 1;
-            if (nq <= (uint32_t)kFewQueries) {
+            if (few) {
                 const size_t per_block = 256 * 8;
                 size_t blocks = (end - begin + per_block - 1) / per_block;
                 if (blocks > 256 * 8) blocks = 256 * 8;

@@ -88,7 +88,9 @@ def test_hamming_adversarial_order(gpu_ctx, oracle, nq):
 
 @pytest.mark.parametrize("n,nq,k", [(1_200_000, 70, 10), (2_500_000, 9, 10), (1_100_000, 3, 64),
                                     (300_000, 130, 10), (777_777, 300, 37), (600_000, 2100, 5),
-                                    (400_003, 65, 128), (262_144, 64, 10), (262_145, 97, 1)])
+                                    (400_003, 65, 128), (262_144, 64, 10), (262_145, 97, 1),
+                                    # a full LDS image (128 query tiles) and the chunking above it
+                                    (300_000, 4096, 4), (270_000, 4097, 3)])
 def test_hamming_two_tier_matches_oracle(gpu_ctx, oracle, n, nq, k):
     """n >= 2^18 takes the staged filter path: the matrix-core scan (hamming_scan_mfma + hamming_rescan)
     for more than 64 queries, the lane-per-code scan (hamming_scan_lanes) below; ragged tails, more than

@@ -109,8 +109,12 @@ struct ucfp_index {
     std::mutex mu;
     std::map<uint32_t, Shard> shards;
     hipStream_t stream = nullptr;  // host-pointer entry points run here
-    DevBuf ws;                     // search workspace (partials, keys, ...)
-    hipEvent_t ws_done = nullptr;  // orders successive searches' use of `ws` across streams
+    // search workspaces (partials, keys, ...): Hamming searches alternate between two, so that two batches enqueued on
+    // different streams run side by side (the sharded search does that); a cosine search -- its key matrix can be
+    // gigabytes -- always takes slot 0.  ws_done[i] orders successive uses of slot i across streams.
+    DevBuf ws_slot[2];
+    hipEvent_t ws_done[2] = {nullptr, nullptr};
+    unsigned ws_next = 0, ws_cur = 0;
     // Mutations and searches may run on different streams: a mutation first waits for every search enqueued so far
     // (ws_done: none may still be reading rows that are overwritten, swapped or re-allocated) and leaves `data_ready`
     // behind; a search waits for `data_ready` (rows appended on another stream have landed).
@@ -176,15 +180,15 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
             keys_off = align256(need);
             need = keys_off + nq * k * 4;
         }
-        int rc = ix->ws.ensure(need);
+        int rc = ix->ws_slot[ix->ws_cur].ensure(need);
         if (rc) return rc;
-        if (!keys) keys = reinterpret_cast<uint32_t*>(ix->ws.p + keys_off);
+        if (!keys) keys = reinterpret_cast<uint32_t*>(ix->ws_slot[ix->ws_cur].p + keys_off);
         const uint64_t* dq = reinterpret_cast<const uint64_t*>(d_queries);
         for (size_t c0 = 0; c0 < nq; c0 += chunk) {
             const uint32_t cn = (uint32_t)(nq - c0 < chunk ? nq - c0 : chunk);
             if (cn != chunk) p = ucfp::hamming_plan(n, cn, k);
             ucfp::launch_hamming_search(s ? reinterpret_cast<const uint64_t*>(s->rows) : nullptr, s ? s->ids : nullptr,
-                                        n, dq + c0, cn, k, ix->ws.p, p, d_out_ids + c0 * k, keys + c0 * k,
+                                        n, dq + c0, cn, k, ix->ws_slot[ix->ws_cur].p, p, d_out_ids + c0 * k, keys + c0 * k,
                                         d_out_scores ? d_out_scores + c0 * k : nullptr, d_out_cnt + c0, st,
                                         s ? s->order : nullptr);
         }
@@ -198,10 +202,10 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
         if (d_out_keys) HIP_TRY(hipMemsetAsync(d_out_keys, 0xff, nq * k * 4, st));
         HIP_TRY(hipMemsetAsync(d_out_cnt, 0, nq * 4, st));
         if (d_out_scores) {
-            int rc = ix->ws.ensure(nq * k * 4 + 256);
+            int rc = ix->ws_slot[ix->ws_cur].ensure(nq * k * 4 + 256);
             if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(ix->ws.p, 0xff, nq * k * 4, st));
-            ucfp::launch_cosine_scores_from_keys(reinterpret_cast<uint32_t*>(ix->ws.p), nq * k, d_out_scores, st);
+            HIP_TRY(hipMemsetAsync(ix->ws_slot[ix->ws_cur].p, 0xff, nq * k * 4, st));
+            ucfp::launch_cosine_scores_from_keys(reinterpret_cast<uint32_t*>(ix->ws_slot[ix->ws_cur].p), nq * k, d_out_scores, st);
         }
         return 0;
     }
@@ -252,9 +256,9 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     off = align256(off + 256);
     const size_t o_mins = off;
     off = align256(off + ucfp::select_pruned_ws_bytes(n, 16));
-    int rc = ix->ws.ensure(off);
+    int rc = ix->ws_slot[ix->ws_cur].ensure(off);
     if (rc) return rc;
-    uint8_t* w = ix->ws.p;
+    uint8_t* w = ix->ws_slot[ix->ws_cur].p;
     float* qn = reinterpret_cast<float*>(w + o_qn);
     uint32_t* keymat = reinterpret_cast<uint32_t*>(w + o_keys);
     uint32_t* okeys = d_out_keys ? d_out_keys : reinterpret_cast<uint32_t*>(w + o_ok);
@@ -367,7 +371,7 @@ int ucfp_index_create(ucfp_ctx* ctx, int kind, uint32_t dim, uint32_t flags, ucf
     ix->row_bytes = kind == UCFP_INDEX_HAMMING64 ? 8 : (size_t)dim * 4;
     hipError_t e = hipSetDevice(ix->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ws_done, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ix->ws_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->data_ready, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete ix;
@@ -387,10 +391,11 @@ void ucfp_index_destroy(ucfp_index* ix) {
         if (kv.second.norms) (void)hipFree(kv.second.norms);
         if (kv.second.order) (void)hipFree(kv.second.order);
     }
-    ix->ws.release();
+    for (auto& w : ix->ws_slot) w.release();
     ix->stage.release();
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
-    if (ix->ws_done) (void)hipEventDestroy(ix->ws_done);
+    for (hipEvent_t ev : ix->ws_done)
+        if (ev) (void)hipEventDestroy(ev);
     if (ix->data_ready) (void)hipEventDestroy(ix->data_ready);
     delete ix;
 }
@@ -403,7 +408,7 @@ int ucfp_index_upsert(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, cons
     HIP_TRY(hipSetDevice(ix->device));
     Shard& s = ix->shards[tenant];
     hipStream_t st = ix->stream;
-    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    for (hipEvent_t ev : ix->ws_done) HIP_TRY(hipStreamWaitEvent(st, ev, 0));
     HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));
     const bool mapped = !(ix->flags & UCFP_INDEX_APPEND_ONLY);
     // resolve target rows on the host; within a batch the LAST occurrence of an id wins
@@ -488,7 +493,7 @@ int ucfp_index_append_dev(ucfp_index* ix, uint32_t tenant, const uint64_t* d_ids
     HIP_TRY(hipSetDevice(ix->device));
     Shard& s = ix->shards[tenant];
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    for (hipEvent_t ev : ix->ws_done) HIP_TRY(hipStreamWaitEvent(st, ev, 0));
     HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));   // an earlier mutation on another stream (growth copies the rows)
     int rc = shard_reserve(ix, s, s.n + n, st);
     if (rc) return rc;
@@ -521,7 +526,7 @@ int ucfp_index_delete(ucfp_index* ix, uint32_t tenant, const uint64_t* ids, size
     Shard& s = sit->second;
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = ix->stream;
-    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    for (hipEvent_t ev : ix->ws_done) HIP_TRY(hipStreamWaitEvent(st, ev, 0));
     HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));
     size_t removed = 0;
     for (size_t i = 0; i < n; i++) {
@@ -664,11 +669,12 @@ int ucfp_index_search_dev(ucfp_index* ix, uint32_t tenant, const void* d_queries
     }
     auto it = ix->shards.find(tenant);
     const Shard* s = it == ix->shards.end() ? nullptr : &it->second;
-    // the workspace is shared: a search may start only after the previous one (on any stream) is done
-    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done, 0));
+    // a workspace slot is shared: a search may start only after the previous one in its slot (on any stream) is done
+    ix->ws_cur = ix->kind == UCFP_INDEX_HAMMING64 ? (ix->ws_next++ & 1u) : 0u;
+    HIP_TRY(hipStreamWaitEvent(st, ix->ws_done[ix->ws_cur], 0));
     HIP_TRY(hipStreamWaitEvent(st, ix->data_ready, 0));
     rc = search_shard_dev(ix, s, d_queries, nq, k, d_out_ids, d_out_scores, d_out_dist, d_out_counts, st);
-    HIP_TRY(hipEventRecord(ix->ws_done, st));
+    HIP_TRY(hipEventRecord(ix->ws_done[ix->ws_cur], st));
     return rc;
 }
 

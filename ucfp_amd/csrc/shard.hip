@@ -91,11 +91,12 @@ struct ucfp_shard_comm {
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
     hipStream_t xs = nullptr;       // exchange stream: all-gather + merge
+    hipStream_t ls[2] = {nullptr, nullptr};   // scan streams, one per buffer set: the shard scans of two batches in flight overlap
     std::mutex mu;
     struct Set {
         uint8_t* buf = nullptr;
         size_t cap = 0;
-        hipEvent_t searched = nullptr, done = nullptr;
+        hipEvent_t queued = nullptr, searched = nullptr, done = nullptr;
         uint64_t ticket = 0;
     } sets[2];
     uint64_t next_ticket = 1;
@@ -132,7 +133,9 @@ int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipEventCreateWithFlags(&c->sets[i].searched, hipEventDisableTiming);
+        e = hipStreamCreateWithFlags(&c->ls[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sets[i].queued, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sets[i].searched, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sets[i].done, hipEventDisableTiming);
     }
     if (e != hipSuccess) {
@@ -161,6 +164,8 @@ int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES
 void ucfp_shard_comm_destroy(ucfp_shard_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (hipStream_t l : c->ls)
+        if (l) (void)hipStreamSynchronize(l);
     if (c->xs) (void)hipStreamSynchronize(c->xs);
     if (c->comm) {
         RcclApi* api = rccl();
@@ -168,10 +173,13 @@ void ucfp_shard_comm_destroy(ucfp_shard_comm* c) {
     }
     for (auto& s : c->sets) {
         if (s.buf) (void)hipFree(s.buf);
+        if (s.queued) (void)hipEventDestroy(s.queued);
         if (s.searched) (void)hipEventDestroy(s.searched);
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (c->xs) (void)hipStreamDestroy(c->xs);
+    for (hipStream_t l : c->ls)
+        if (l) (void)hipStreamDestroy(l);
     delete c;
 }
 
@@ -244,20 +252,27 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* c, uint32
     ucfp_shard_comm::Set& S = c->sets[t & 1];
     S.ticket = t;
     *ticket = t;
-    // the exchange that last used this buffer set must be over before the scan overwrites it
-    HIP_TRY(hipStreamWaitEvent(st, S.done, 0));
     if (nq == 0 || k == 0) {
         // every rank still takes part in nothing: an empty batch is empty everywhere (queries are replicated)
+        HIP_TRY(hipStreamWaitEvent(st, S.done, 0));
         if (nq) HIP_TRY(hipMemsetAsync(d_out_counts, 0, nq * 4, st));
         HIP_TRY(hipEventRecord(S.done, st));
         return UCFP_OK;
     }
+    // The shard scan runs on the set's own stream, behind the caller's stream (the queries are written) and behind the
+    // exchange that last used this buffer set: the scans of the two batches in flight then overlap -- one batch's short
+    // staging kernels (sample, rescans, thresholds, selection) fill the gaps of the other's matrix-core scan.
+    hipStream_t ls = c->ls[t & 1];
+    HIP_TRY(hipEventRecord(S.queued, st));
+    HIP_TRY(hipStreamWaitEvent(ls, S.queued, 0));
+    HIP_TRY(hipStreamWaitEvent(ls, S.done, 0));
     const size_t e = nq * k;
     const size_t o_ids = 0, o_keys = align256(e * 8), o_cnt = align256(o_keys + e * 4), o_send = align256(o_cnt + nq * 4);
     const size_t o_recv = align256(o_send + e * 16), o_okeys = align256(o_recv + (size_t)c->world * e * 16);
     const size_t need = align256(o_okeys + e * 4);
     if (S.cap < need) {
         HIP_TRY(hipStreamSynchronize(c->xs));
+        HIP_TRY(hipStreamSynchronize(ls));
         if (S.buf) (void)hipFree(S.buf);
         S.buf = nullptr;
         S.cap = 0;
@@ -270,15 +285,15 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* c, uint32
     uint8_t* send = S.buf + o_send;
     uint8_t* recv = c->world > 1 ? S.buf + o_recv : send;
     uint32_t* okeys = d_out_keys ? d_out_keys : reinterpret_cast<uint32_t*>(S.buf + o_okeys);
-    // 1. this rank's shard, on the caller's stream
-    int rc = ucfp_index_search_dev(idx, tenant, d_queries, nq, k, l_ids, nullptr, l_keys, l_cnt, st);
+    // 1. this rank's shard, on the set's scan stream
+    int rc = ucfp_index_search_dev(idx, tenant, d_queries, nq, k, l_ids, nullptr, l_keys, l_cnt, ls);
     if (rc) return rc;
-    ucfp::launch_topk_pack_entries(l_ids, l_keys, e, send, st);
+    ucfp::launch_topk_pack_entries(l_ids, l_keys, e, send, ls);
     HIP_TRY(hipGetLastError());
-    // 2. exchange + merge, on the side stream (the caller's stream when there is nothing to exchange)
-    hipStream_t xs = c->world > 1 ? c->xs : st;
+    // 2. exchange + merge, on the side stream (the scan stream when there is nothing to exchange)
+    hipStream_t xs = c->world > 1 ? c->xs : ls;
     if (c->world > 1) {
-        HIP_TRY(hipEventRecord(S.searched, st));
+        HIP_TRY(hipEventRecord(S.searched, ls));
         HIP_TRY(hipStreamWaitEvent(xs, S.searched, 0));
         RcclApi* api = rccl();
         ncclResult_t r = api->all_gather(send, recv, e * 2, ncclUint64, c->comm, xs);   // 16-byte entries as 2 x u64

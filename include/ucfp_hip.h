@@ -443,9 +443,11 @@ int ucfp_shard_comm_info(ucfp_shard_comm* comm, int* rank, int* world, uint64_t*
 void ucfp_shard_range(uint64_t n_total, int rank, int world, uint64_t* start, uint64_t* end);
 
 /* Sharded IndexBackend::knn for a batch (device pointers; queries identical on every rank).
- * submit: the shard scan is enqueued on `stream`, the all-gather + merge on the communicator's side stream, so the
- *         exchange of this batch overlaps the scan of the next (two buffer sets: at most two batches in flight).
- *         Outputs (as ucfp_index_search_dev; d_out_scores / d_out_keys may be NULL) are written by the side stream:
+ * submit: the shard scan is enqueued BEHIND `stream` (whatever wrote the queries there has finished) on the scan stream of
+ *         one of the communicator's two buffer sets, the all-gather + merge on its exchange stream: the scans of two
+ *         successive batches run side by side (one's short staging kernels fill the gaps of the other's matrix-core
+ *         scan) and the exchange of a batch overlaps the scan of the next; at most two batches in flight.
+ *         Outputs (as ucfp_index_search_dev; d_out_scores / d_out_keys may be NULL) are written by those streams:
  *         they and the queries must stay untouched until the ticket is collected.
  * collect: makes `stream` wait for that batch's results (no host synchronisation).
  * ucfp_index_search_sharded_dev = submit + collect on the same stream. */

@@ -637,6 +637,47 @@ def test_hamming_strict_thresholds_only_when_ids_ascend(gpu_ctx, oracle, order, 
     ix.close()
 
 
+def test_hamming_searches_in_flight_on_two_streams(gpu_ctx, oracle, torch_cuda):
+    """Searches enqueued on different streams alternate between the index's two workspaces and may run side by side
+    (index.hip ws_slot): twelve batches of different queries on two streams, no host synchronisation in between, and a
+    mutation behind them -- every batch must get its own exact answer."""
+    import torch
+    from ucfp_amd import index
+    rng = np.random.default_rng(2424)
+    n, nq, k = 400_000, 300, 10
+    dev = torch.device("cuda", 0)
+    ids = rng.permutation(n).astype(np.uint64)
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    ix = index.DeviceIndex(index.HAMMING64, 0, index.APPEND_ONLY, gpu_ctx)
+    ix.upsert(0, ids, codes)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    qs, outs = [], []
+    for b in range(12):
+        q = rng.integers(0, 2**64, nq, dtype=np.uint64)
+        q[::3] = codes[rng.integers(0, n, len(q[::3]))] ^ np.uint64(1 << (b % 60))     # near neighbours for a third of them
+        qs.append(q)
+    torch.cuda.synchronize()
+    d_q = [torch.from_numpy(q.view(np.int64)).to(dev) for q in qs]
+    torch.cuda.synchronize()
+    for b in range(12):
+        o = (torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.int32, device=dev),
+             torch.empty((nq,), dtype=torch.int32, device=dev))
+        outs.append(o)
+        ix.search_dev(0, d_q[b].data_ptr(), nq, k, o[0].data_ptr(), 0, o[1].data_ptr(), o[2].data_ptr(),
+                      streams[b & 1].cuda_stream)
+    # a mutation right behind the searches must wait for both workspaces' users
+    extra_ids = np.arange(n, n + 5, dtype=np.uint64) + np.uint64(10_000_000)
+    ix.upsert(0, extra_ids, qs[0][:5].copy())
+    torch.cuda.synchronize()
+    for b in range(12):
+        o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, qs[b], k)
+        assert np.array_equal(outs[b][0].cpu().numpy().view(np.uint64), o_ids), b
+        assert np.array_equal(outs[b][1].cpu().numpy().view(np.uint32), o_d), b
+    g_ids, _, g_d, _ = ix.search(0, qs[0][:5], 1)         # the appended rows are exact matches of these queries
+    assert np.array_equal(g_d[:, 0], np.zeros(5, np.uint32))
+    ix.close()
+
+
 def test_cosine_duplicate_rows_and_any_id_order(gpu_ctx, oracle):
     """Ties are broken by record id: a corpus where every row exists in many copies (equal keys everywhere, ids in random
     order) must return the k smallest ids of the best rows (8 queries over 768-d rows: the 4x4x1 row-stream kernel)."""

@@ -28,6 +28,7 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = _lib.default_context(0)
     rng = np.random.default_rng(a.seed)
+    two = [torch.cuda.Stream(), torch.cuda.Stream()]
     t0, rounds = time.time(), 0
     while time.time() - t0 < a.seconds:
         rounds += 1
@@ -61,16 +62,21 @@ def main():
             o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
             o_d = torch.empty((nq, k), dtype=torch.int32, device=dev)
             o_c = torch.empty((nq,), dtype=torch.int32, device=dev)
-            ix.search_dev(0, q.data_ptr(), nq, k, o_ids.data_ptr(), 0, o_d.data_ptr(), o_c.data_ptr(),
-                          torch.cuda.current_stream().cuda_stream)
+            # two searches in flight on two streams (different queries): the index alternates its two workspaces
+            q2 = q ^ (q << 7) ^ 0x5DEECE66D
+            o2_ids, o2_d, o2_c = torch.empty_like(o_ids), torch.empty_like(o_d), torch.empty_like(o_c)
+            torch.cuda.synchronize()
+            ix.search_dev(0, q.data_ptr(), nq, k, o_ids.data_ptr(), 0, o_d.data_ptr(), o_c.data_ptr(), two[0].cuda_stream)
+            ix.search_dev(0, q2.data_ptr(), nq, k, o2_ids.data_ptr(), 0, o2_d.data_ptr(), o2_c.data_ptr(), two[1].cuda_stream)
             torch.cuda.synchronize()
             kk = min(k, n)
-            for j in range(0, nq, 64):
-                d = popcount64(q[j:j + 64, None] ^ codes[None, :])
-                key = d * (1 << 32) + ids[None, :]                 # (d, id) ascending
-                ref = torch.topk(key, kk, dim=1, largest=False).values
-                assert torch.equal(o_d[j:j + 64, :kk].to(torch.int64), ref >> 32), ("hamming d", n, nq, k)
-                assert torch.equal(o_ids[j:j + 64, :kk], ref & 0xFFFFFFFF), ("hamming id", n, nq, k)
+            for qq, oi, od in ((q, o_ids, o_d), (q2, o2_ids, o2_d)):
+                for j in range(0, nq, 64):
+                    d = popcount64(qq[j:j + 64, None] ^ codes[None, :])
+                    key = d * (1 << 32) + ids[None, :]                 # (d, id) ascending
+                    ref = torch.topk(key, kk, dim=1, largest=False).values
+                    assert torch.equal(od[j:j + 64, :kk].to(torch.int64), ref >> 32), ("hamming d", n, nq, k)
+                    assert torch.equal(oi[j:j + 64, :kk], ref & 0xFFFFFFFF), ("hamming id", n, nq, k)
             ix.close()
         else:
             n = int(rng.choice([900, 5000, 40_000, 270_000, 600_000]))

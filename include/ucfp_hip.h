@@ -395,7 +395,9 @@ int ucfp_index_load(ucfp_index* idx, const char* path);
  * An unknown tenant or k = 0 returns zero hits, like the reference (:275-277). */
 int ucfp_index_search(ucfp_index* idx, uint32_t tenant, const void* queries, size_t nq, uint32_t k,
                       uint64_t* out_ids, float* out_scores, uint32_t* out_dist, uint32_t* out_counts);
-/* Same with device pointers, enqueued on `stream` (no synchronisation). */
+/* Same with device pointers, enqueued on `stream` (no synchronisation).  Searches enqueued on different streams are ordered
+ * only where they share a workspace: a HAMMING64 index alternates between two, so two batches may be in flight at once
+ * (the short staging kernels of one run under the matrix-core scan of the other); cosine searches run one at a time. */
 int ucfp_index_search_dev(ucfp_index* idx, uint32_t tenant, const void* d_queries, size_t nq, uint32_t k,
                           uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_dist,
                           uint32_t* d_out_counts, void* stream);

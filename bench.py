@@ -317,16 +317,16 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
     # (submit + collect back to back, so the all-gather + merge is NOT hidden under the next scan) minus the bare
     # shard scan through ucfp_index_search_dev
     exch_ms = None
+    reps = max(4, args.ann_steps // 2)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        six.search(queries, k)          # submit + collect back to back: one batch at a time
+    barrier()
+    t_seq = (time.perf_counter() - t0) / reps
     if world > 1:
         b = six._buffers(nq, k, dev, 0)
         cur = torch.cuda.current_stream().cuda_stream
-        reps = max(4, args.ann_steps // 2)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            six.search(queries, k)
-        barrier()
-        t_seq = (time.perf_counter() - t0) / reps
         t0 = time.perf_counter()
         for _ in range(reps):
             six.local.search_dev(0, queries.data_ptr(), nq, k, b["out_ids"].data_ptr(), 0, b["out_keys"].data_ptr(),
@@ -393,7 +393,8 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
     return {
         "metric": "ANN queries/sec (Hamming k=10, brute force, exact)", "value": qps, "unit": "queries/s",
         "corpus_total": corpus_total, "corpus_per_gpu": n_local, "queries_per_batch": nq, "k": k,
-        "ms_per_batch": dt / args.ann_steps * 1e3, "batches_in_flight": 2, "scaling": "strong",
+        "ms_per_batch": dt / args.ann_steps * 1e3, "batches_in_flight": 2,
+        "ms_per_batch_one_at_a_time": t_seq * 1e3, "scaling": "strong",
         "exchange": "ONE ncclAllGather (RCCL, called by libucfp_hip.so itself) of nq*k*16 B per rank + merge on every "
                     "rank, on the library's side stream under the next batch's shard scan (exchange_ms_per_batch is "
                     "the step alone, unoverlapped)" if world > 1 else "none",

@@ -103,7 +103,7 @@ def bench_config1_phash_png(dev, ctx, n_img=1000):
     import torch
     from PIL import Image
     oracle = timed_oracle()
-    from ucfp_amd import image
+    from ucfp_amd import _lib, image
     side = 256
     yy, xx = np.mgrid[0:side, 0:side]
     rng = np.random.default_rng(0xC0F1)
@@ -202,6 +202,26 @@ def bench_config1_phash_png(dev, ctx, n_img=1000):
         done[i & 1].record(s_comp)
     torch.cuda.synchronize()
     t_png_pipe = (time.perf_counter() - t0) / 20
+    # ... and two batches in flight (bytes resident): a second context = a second decode workspace, on a second stream --
+    # a batch of 1000 files is one wave per SIMD, two of them share the chip
+    ctx2 = _lib.Context(ctx.device)
+    two_s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    two_o = [(torch.zeros_like(d_out2), torch.zeros_like(d_st)) for _ in range(2)]
+
+    def go_two(i):
+        image.fingerprint_pngs_dev(d_blob.data_ptr(), d_off.data_ptr(), n_img, png_bytes, side, side, image.PIX_RGB8,
+                                   algo=image.PHASH, out_ptr=two_o[i & 1][0].data_ptr(),
+                                   status_ptr=two_o[i & 1][1].data_ptr(), stream=two_s[i & 1].cuda_stream,
+                                   ctx=(ctx, ctx2)[i & 1])
+    go_two(0), go_two(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20):
+        go_two(i)
+    torch.cuda.synchronize()
+    t_png_two = (time.perf_counter() - t0) / 20
+    png_two_ok = bool(np.array_equal(two_o[0][0].cpu().numpy(), ref_png) and np.array_equal(two_o[1][0].cpu().numpy(), ref_png))
+    ctx2.close()
     return {
         "workload": f"{n_img} synthetic 256x256 RGB PNGs, ?algorithm=phash (168-B records)",
         "cpu": {"kind": "port", **host_cpu(), "threads": cores,
@@ -215,6 +235,8 @@ def bench_config1_phash_png(dev, ctx, n_img=1000):
                 "png_front_end": {"images_per_s_encoded_bytes_resident": n_img / t_png,
                                   "images_per_s_incl_h2d_of_encoded_bytes": n_img / t_png_h2d,
                                   "images_per_s_incl_h2d_next_batch_copied_under_decode": n_img / t_png_pipe,
+                                  "images_per_s_two_batches_in_flight_resident": n_img / t_png_two,
+                                  "two_in_flight_records_match_oracle": png_two_ok,
                                   "png_bytes_per_image": png_bytes / n_img, "records_match_oracle": png_ok}},
         "gpu_hash_over_cpu_hash_all_cores": (n_img / t_gd) / (n_img / t_hn),
         "gpu_png_front_end_over_cpu_decode_plus_hash_1_thread": (n_img / t_png_h2d) / (n_img / (t_dec + t_h1)),

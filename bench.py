@@ -40,6 +40,8 @@ def parse():
                          "100M; split evenly over the ranks = strong scaling). 0 skips the ANN leg")
     ap.add_argument("--ann-queries", type=int, default=4096)
     ap.add_argument("--ann-steps", type=int, default=20)
+    ap.add_argument("--no-forced-rccl", action="store_true",
+                    help="N = 1 only: skip the extra ANN measurement through a one-rank RCCL communicator")
     ap.add_argument("--rgb-frames", type=int, default=30_000, help="RGB8 512x512 frames for the RGB variant; 0 skips")
     ap.add_argument("--cosine-rows", type=int, default=1_000_000, help="768-d f32 rows per GPU for the cosine leg; 0 skips")
     ap.add_argument("--text-docs", type=int, default=1_000_000, help="4 KiB docs per GPU (BASELINE configs[3]); 0 skips")
@@ -288,6 +290,42 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
     corpus_total = corpus_total or args.ann_corpus
     start, end = sharded.shard_range(corpus_total, rank, world)
     n_local = end - start
+
+    def agree(err, where):
+        """All ranks leave the leg TOGETHER when any of them failed: a rank that raised alone would leave the others
+        blocked in the next collective (ncclCommInitRank, ncclAllGather, the barrier).  Every rank calls this at the
+        same points with its own error (or None); one MIN all-reduce over the job's process group decides."""
+        if world > 1:
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
+                              device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and err is None:
+                raise RuntimeError(f"another rank failed in the ANN leg ({where}); rank {rank} leaves with it")
+        if err is not None:
+            raise err
+
+    try:
+        setup_err = None
+        codes, ids, queries = _ann_inputs(torch, dev, rank, world, n_local, start, end, nq)
+    except Exception as e:   # noqa: BLE001
+        setup_err = e
+    agree(setup_err, "corpus generation")
+    six = sharded.ShardedIndex(index.HAMMING64, ctx=ctx)      # collective at N > 1 (ncclCommInitRank)
+    try:
+        six.append_local(ids, codes)
+        torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001
+        setup_err = e
+    agree(setup_err, "shard upload")
+    cpu_sample = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:      # keep a bounded corpus sample for the CPU leg below
+        m = min(n_local, 8_000_000)
+        cpu_sample = (ids[:m].cpu().numpy().view("uint64"), codes[:m].cpu().numpy().view("uint64"))
+    del codes, ids
+    return _bench_ann_run(args, rank, world, dev, ctx, six, queries, cpu_sample, corpus_total, n_local, agree)
+
+
+def _ann_inputs(torch, dev, rank, world, n_local, start, end, nq):
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED + rank)
     codes = torch.randint(-2**63, 2**63 - 1, (n_local,), dtype=torch.int64, device=dev, generator=g)
@@ -301,38 +339,64 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
         if owner == rank and n_local:
             pos = (j * 7919) % n_local
             codes[pos] = queries[j] ^ (1 << (j % 61)) ^ (1 << ((j * 3) % 59))
-    six = sharded.ShardedIndex(index.HAMMING64, ctx=ctx)
-    six.append_local(ids, codes)
-    torch.cuda.synchronize()
-    cpu_sample = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:      # keep a bounded corpus sample for the CPU leg below
-        m = min(n_local, 8_000_000)
-        cpu_sample = (ids[:m].cpu().numpy().view("uint64"), codes[:m].cpu().numpy().view("uint64"))
-    del codes, ids
+    return codes, ids, queries
+
+
+def _bench_ann_run(args, rank, world, dev, ctx, six, queries, cpu_sample, corpus_total, n_local, agree):
+    import torch
+    import torch.distributed as dist
+    from ucfp_amd import index, sharded
+    k, nq = 10, args.ann_queries
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(2):
-        six.search(queries, k)
-    barrier()
-    # batches are pipelined two deep: the library runs the shard scans of the two batches in flight on two streams (one
-    # batch's staging kernels fill the gaps of the other's matrix-core scan) and the exchange of a batch on a third
-    t0 = time.perf_counter()
-    ticket = six.submit(queries, k)
-    for _ in range(args.ann_steps - 1):
-        nxt = six.submit(queries, k)
-        out = six.collect(ticket)
-        ticket = nxt
-    out = six.collect(ticket)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_pipeline():
+        """ann_steps batches, pipelined two deep: the library runs the shard scans of the two batches in flight on two
+        streams (one batch's staging kernels fill the gaps of the other's matrix-core scan) and the exchange of a
+        batch on a third.  Returns (seconds, MAX over ranks; the last batch's outputs)."""
+        # A rank whose own submit fails has still joined that batch's all-gather inside the library (shard.hip), so it
+        # keeps submitting -- the collectives stay matched -- and the error surfaces at the agreement point below.
+        err, res = None, None
+
+        def submit():
+            nonlocal err
+            try:
+                return six.submit(queries, k)
+            except Exception as e:   # noqa: BLE001
+                err = err or e
+                return None
+
+        def collect(t):
+            nonlocal err, res
+            if t is not None:
+                try:
+                    res = six.collect(t)
+                except Exception as e:   # noqa: BLE001
+                    err = err or e
+
+        for _ in range(2):
+            collect(submit())
+        barrier()
+        t0 = time.perf_counter()
+        ticket = submit()
+        for _ in range(args.ann_steps - 1):
+            nxt = submit()
+            collect(ticket)
+            ticket = nxt
+        collect(ticket)
+        barrier()
+        el = time.perf_counter() - t0
+        agree(err, "pipelined search")
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res
+
+    dt, out = timed_pipeline()
     out_ids, _, out_keys, out_cnt = out
     planted_found = int((out_keys[0::2, 0] <= 3).sum().item())
     # the exchange step alone (SURVEY 8d: "all-gather time separately"): the same batches searched one at a time
@@ -358,6 +422,32 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
         exch_ms = max(0.0, (t_seq - t_loc) * 1e3)
     rccl_ranks = world if six.rccl else 0
     exchanges = six.comm.exchanges()
+    # One GPU: the same batches once more through a ONE-RANK RCCL communicator (UCFP_SHARD_FORCE_RCCL) -- the code a
+    # multi-GPU job runs (ncclCommInitRank, one ncclAllGather per batch on the exchange stream, merge over the gathered
+    # buffer) executed and timed on the hardware there is; results must equal the local short cut's.
+    forced = None
+    if world == 1 and not args.no_forced_rccl:
+        try:
+            base = [t.clone() for t in out]
+            plain = six.comm
+            six.comm = sharded.ShardComm(ctx, None, force_rccl=True)
+            f_dt, f_out = timed_pipeline()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                six.search(queries, k)
+            barrier()
+            f_seq = (time.perf_counter() - t0) / reps
+            same = all(bool(torch.equal(a, b)) for a, b in zip(base, f_out))
+            forced = {"rccl_ranks": 1, "uses_rccl": six.comm.uses_rccl, "rccl_all_gathers": six.comm.exchanges(),
+                      "ms_per_batch": f_dt / args.ann_steps * 1e3, "ms_per_batch_one_at_a_time": f_seq * 1e3,
+                      "exchange_ms_per_batch": max(0.0, (f_seq - t_seq) * 1e3),
+                      "value": nq * args.ann_steps / f_dt, "unit": "queries/s",
+                      "equals_local_path": same}
+            six.comm.close()
+            six.comm = plain
+        except Exception as e:   # RCCL missing on the host: say so, the leg is extra
+            forced = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if cpu_sample is not None:
         # CPU leg (the reference has NO Hamming search, F3: this is the C statement of the same scan,
@@ -420,7 +510,7 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
         "exchange": "ONE ncclAllGather (RCCL, called by libucfp_hip.so itself) of nq*k*16 B per rank + merge on every "
                     "rank, on the library's side stream under the next batch's shard scan (exchange_ms_per_batch is "
                     "the step alone, unoverlapped)" if world > 1 else "none",
-        "rccl_ranks": rccl_ranks, "rccl_all_gathers": exchanges,
+        "rccl_ranks": rccl_ranks, "rccl_all_gathers": exchanges, "rccl_forced": forced,
         "pairs_per_s": pairs_per_s, "exchange_ms_per_batch": exch_ms, "cpu_baseline": cpu,
         "roofline": {"bound": "mfma", "kernel": "hamming_scan_mfma",
                      "achieved": pairs_per_s * ops_per_pair / world / 1e12, "peak": fp4_peak / 1e12,
@@ -933,7 +1023,7 @@ def main():
                 res["watchdog"] = ("a secondary leg did not finish within 600 s at N > 1; the line carries what was "
                                    "measured before it")
                 print(json.dumps(res), flush=True)
-            os._exit(0)
+            os._exit(3)      # non-zero: the driver must record the hang, not a success
         watchdog = threading.Timer(600.0, _fire)
         watchdog.daemon = True
         watchdog.start()

@@ -431,12 +431,25 @@ int ucfp_topk_merge_packed_dev(ucfp_ctx* ctx, int kind, const void* d_entries, u
  *                                                     control channel: env, file, TCP -- like ncclUniqueId)
  *   every rank:  ucfp_shard_comm_create(ctx, uid, rank, world, &comm)     (collective: all ranks call it)
  *                ucfp_index_search_sharded_dev(idx, comm, ...)            (collective, same nq / k everywhere)
- * world = 1 needs no uid and never loads RCCL.  RCCL is dlopen()ed (librccl.so.1) when world > 1. */
+ * world = 1 needs no uid and never loads RCCL.  RCCL is dlopen()ed (librccl.so.1) when world > 1.
+ *
+ * ucfp_shard_comm_create_ex(..., flags, ...): UCFP_SHARD_FORCE_RCCL (or UCFP_SHARD_FORCE_RCCL=1 in the environment)
+ * builds a real RCCL communicator even at world = 1 (uid required) -- ncclCommInitRank(nranks = 1), one ncclAllGather
+ * per batch on the exchange stream, the merge over the gathered buffer -- so that a single-GPU host executes, and can
+ * test, exactly the code path a multi-GPU job runs.  ucfp_shard_comm_uses_rccl tells which branch a communicator takes.
+ *
+ * Failure of one rank: if this rank's own shard scan cannot be enqueued, ucfp_index_search_sharded_submit still joins
+ * the all-gather with an empty list (so the other ranks do not block), completes the ticket and returns the scan's
+ * error; the answer every rank then holds lacks that shard. */
 #define UCFP_SHARD_UID_BYTES 128
+#define UCFP_SHARD_FORCE_RCCL 1u
 typedef struct ucfp_shard_comm ucfp_shard_comm;
 int ucfp_shard_unique_id(uint8_t uid[UCFP_SHARD_UID_BYTES]);
 int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES], int rank, int world,
                            ucfp_shard_comm** out);
+int ucfp_shard_comm_create_ex(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES], int rank, int world,
+                              uint32_t flags, ucfp_shard_comm** out);
+int ucfp_shard_comm_uses_rccl(ucfp_shard_comm* comm);   /* 1: batches go through ncclAllGather; 0: local short cut */
 void ucfp_shard_comm_destroy(ucfp_shard_comm* comm);
 /* rank / world / number of all-gathers issued so far (each may be NULL) */
 int ucfp_shard_comm_info(ucfp_shard_comm* comm, int* rank, int* world, uint64_t* exchanges);

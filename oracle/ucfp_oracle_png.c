@@ -203,9 +203,11 @@ static uint32_t adler32(const uint8_t* p, size_t n) {
     return b << 16 | a;
 }
 
-/* zlib stream (RFC 1950): CMF/FLG, deflate data, Adler-32 of the output. */
-int ucfp_oracle_inflate(const uint8_t* z, size_t n, uint8_t* out, size_t cap, size_t* produced) {
+/* zlib stream (RFC 1950): CMF/FLG, deflate data, Adler-32 of the output.  *checksum_ok = 0 when the data inflated
+ * but the 4-byte trailer is absent or differs. */
+static int inflate_zlib(const uint8_t* z, size_t n, uint8_t* out, size_t cap, size_t* produced, int* checksum_ok) {
     *produced = 0;
+    *checksum_ok = 0;
     if (n < 6) return PNG_CORRUPT;
     if ((z[0] & 15) != 8 || (z[0] >> 4) > 7 || ((z[0] << 8 | z[1]) % 31) != 0 || (z[1] & 0x20)) return PNG_CORRUPT;
     Bits b = {z, n, 2, 0, 0, 0};
@@ -213,9 +215,17 @@ int ucfp_oracle_inflate(const uint8_t* z, size_t n, uint8_t* out, size_t cap, si
     if (rc) return rc;
     /* the deflate data ends inside byte pos-1 (bits already pulled into the buffer belong to whole bytes) */
     size_t end = b.pos - (size_t)(b.bitcnt / 8);
-    if (end + 4 > n) return PNG_CORRUPT;
+    if (end + 4 > n) return PNG_OK;
     uint32_t want = (uint32_t)z[end] << 24 | (uint32_t)z[end + 1] << 16 | (uint32_t)z[end + 2] << 8 | z[end + 3];
-    return adler32(out, *produced) == want ? PNG_OK : PNG_CORRUPT;
+    *checksum_ok = adler32(out, *produced) == want;
+    return PNG_OK;
+}
+
+/* As zlib's uncompress(): a missing or wrong Adler-32 is an error. */
+int ucfp_oracle_inflate(const uint8_t* z, size_t n, uint8_t* out, size_t cap, size_t* produced) {
+    int ok = 0;
+    int rc = inflate_zlib(z, n, out, cap, produced, &ok);
+    return rc ? rc : (ok ? PNG_OK : PNG_CORRUPT);
 }
 
 static uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
@@ -269,7 +279,12 @@ int ucfp_oracle_png_decode(const uint8_t* png, size_t n, uint8_t* pixels, size_t
         uint32_t len = be32(png + pos);
         const uint8_t* type = png + pos + 4;
         if (len > 0x7fffffffu || pos + 12 + (size_t)len > n) { rc = PNG_CORRUPT; break; }
-        if (crc32_png(png + pos + 4, 4 + (size_t)len) != be32(png + pos + 8 + len)) { rc = PNG_CORRUPT; break; }
+        if (crc32_png(png + pos + 4, 4 + (size_t)len) != be32(png + pos + 8 + len)) {
+            /* P5: a critical chunk with a bad CRC is damage; an ancillary one is a checksum-only failure of data the
+             * pixels do not depend on -- decoders differ, the host's decoder decides */
+            rc = (type[0] & 0x20) ? PNG_NEEDS_HOST : PNG_CORRUPT;
+            break;
+        }
         if (memcmp(type, "IDAT", 4) == 0) {
             if (idat_done) { rc = PNG_CORRUPT; break; }
             seen_idat = 1;
@@ -283,15 +298,19 @@ int ucfp_oracle_png_decode(const uint8_t* png, size_t n, uint8_t* pixels, size_t
         }
         pos += 12 + (size_t)len;
     }
+    if (rc == PNG_NEEDS_HOST) { free(z); return rc; }
     if (rc == PNG_OK && (!seen_idat || !seen_end)) rc = PNG_CORRUPT;
     if (rc == PNG_OK && needs_host) rc = PNG_NEEDS_HOST;
     if (rc) { free(z); return rc; }
     const size_t raw_n = (row + 1) * h;
     uint8_t* raw = (uint8_t*)malloc(raw_n);
     size_t got = 0;
-    rc = ucfp_oracle_inflate(z, zn, raw, raw_n, &got);
+    int checksum_ok = 0;
+    rc = inflate_zlib(z, zn, raw, raw_n, &got, &checksum_ok);
     free(z);
     if (rc == PNG_OK && got != raw_n) rc = PNG_CORRUPT;
+    /* P5: the right number of bytes but no / a wrong Adler-32: checksum-only, the host's decoder decides */
+    if (rc == PNG_OK && !checksum_ok) rc = PNG_NEEDS_HOST;
     /* unfilter (9.2): x = filtered byte, a = left pixel's byte, b = above, c = above-left */
     for (uint32_t y = 0; rc == PNG_OK && y < h; y++) {
         const uint8_t* src = raw + (row + 1) * y;

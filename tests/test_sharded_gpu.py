@@ -5,6 +5,9 @@
     `ucfp_topk_merge_packed_dev`) with the corpus split into 2 / 3 / 8 shard indexes on one device.  The RCCL
     all-gather itself needs one GPU per rank and cannot run on a one-GPU box (RCCL refuses two ranks on a device):
     it is unmeasured here and covered by construction + the 2-rank gloo wire-format test (test_sharded_cpu.py);
+  * round 3: the RCCL branch itself at world = 1 -- a ONE-RANK RCCL communicator (legal in RCCL) forced with
+    UCFP_SHARD_FORCE_RCCL: dlopen + ncclGetUniqueId + ncclCommInitRank + ONE ncclAllGather per batch on the exchange
+    stream + the merge over the gathered buffer, two tickets in flight, vs the oracle (`test_forced_rccl_*`);
   * ordering of the shared normalisation workspace across streams (ADVICE r1, high);
   * IndexBackend::upsert overwrite semantics (src/index/embedded/mod.rs:184-191; ADVICE r1, medium);
   * append on one stream, search on another.
@@ -59,6 +62,88 @@ def test_sharded_search_world1_matches_oracle(gpu_ctx, oracle, torch_cuda):
     torch.cuda.synchronize()
     assert t.value > 0 and int(c1.abs().sum().item()) == 0
     six.close()
+
+
+def test_forced_rccl_one_rank_two_tickets_in_flight(gpu_ctx, oracle, torch_cuda):
+    """The library's RCCL branch executed on the one GPU there is: ucfp_shard_unique_id -> ncclCommInitRank(nranks = 1)
+    -> per batch ONE ncclAllGather of the packed entries on the exchange stream -> topk_merge_u32<PACKED> over the
+    gathered buffer.  Two batches are submitted before either is collected (both buffer sets, both scan streams)."""
+    torch = torch_cuda
+    from ucfp_amd import index, sharded
+    rng = np.random.default_rng(808)
+    n, nq, k = 700_000, 520, 10
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(7) + np.uint64(3)
+    qa = codes[:nq] ^ np.uint64(0b1011)
+    qb = codes[-nq:] ^ (np.uint64(1) << np.uint64(40))
+    six = sharded.ShardedIndex(index.HAMMING64, ctx=gpu_ctx, force_rccl=True)
+    assert six.world == 1 and six.comm.uses_rccl and six.comm.exchanges() == 0
+    six.append_local(_dev(torch, ids.view(np.int64)), _dev(torch, codes.view(np.int64)))
+    d_qa, d_qb = _dev(torch, qa.view(np.int64)), _dev(torch, qb.view(np.int64))
+    ta = six.submit(d_qa, k)
+    tb = six.submit(d_qb, k)                      # in flight together with ta
+    ra = [t.clone() for t in six.collect(ta)]
+    rb = [t.clone() for t in six.collect(tb)]
+    torch.cuda.synchronize()
+    assert six.comm.exchanges() == 2
+    for (g_ids, g_sc, g_keys, g_cnt), q in ((ra, qa), (rb, qb)):
+        o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, q, k)
+        assert np.array_equal(g_ids.cpu().numpy().view(np.uint64), o_ids)
+        assert np.array_equal(g_keys.cpu().numpy().view(np.uint32), o_d)
+        assert np.array_equal(g_cnt.cpu().numpy().view(np.uint32), o_c)
+        assert np.allclose(g_sc.cpu().numpy(), 1.0 - o_d / 64.0)
+    # a third and fourth batch reuse the two buffer sets behind their previous exchanges
+    for rep in range(2):
+        g = six.search(d_qa if rep else d_qb, 5)
+        torch.cuda.synchronize()
+        o_ids, _, _ = oracle.hamming_topk(ids, codes, qa if rep else qb, 5)
+        assert np.array_equal(g[0].cpu().numpy().view(np.uint64), o_ids)
+    assert six.comm.exchanges() == 4
+    six.close()
+
+
+def test_forced_rccl_cosine_and_env_switch(gpu_ctx, oracle, torch_cuda, monkeypatch):
+    """Same branch for the cosine kind, switched on through the environment (what a deployment would set to rehearse
+    the multi-GPU path on one device) with the plain ucfp_shard_comm_create entry."""
+    torch = torch_cuda
+    from ucfp_amd import _lib, index
+    lib = _lib.load()
+    rng = np.random.default_rng(909)
+    n, nq, k, dim = 30_000, 19, 6, 64
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    ids = rng.permutation(n).astype(np.uint64)
+    monkeypatch.setenv("UCFP_SHARD_FORCE_RCCL", "1")
+    uid = (C.c_uint8 * 128)()
+    _lib.check(lib.ucfp_shard_unique_id(uid))
+    assert any(bytes(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.ucfp_shard_comm_create(gpu_ctx.handle, uid, 0, 1, C.byref(comm)))
+    monkeypatch.delenv("UCFP_SHARD_FORCE_RCCL")
+    assert lib.ucfp_shard_comm_uses_rccl(comm) == 1
+    # without a uid a forced communicator is refused, not silently downgraded
+    bad = C.c_void_p()
+    assert lib.ucfp_shard_comm_create_ex(gpu_ctx.handle, None, 0, 1, 1, C.byref(bad)) != 0
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    d_q = _dev(torch, q)
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    o_sc = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    _lib.check(lib.ucfp_index_search_sharded_dev(ix.handle, comm, 0, d_q.data_ptr(), nq, k, o_ids.data_ptr(),
+                                                 o_sc.data_ptr(), None, o_cnt.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream or None))
+    torch.cuda.synchronize()
+    ex = C.c_uint64(0)
+    _lib.check(lib.ucfp_shard_comm_info(comm, None, None, C.byref(ex)))
+    assert ex.value == 1
+    got, sc = o_ids.cpu().numpy().view(np.uint64), o_sc.cpu().numpy()
+    for qi in range(nq):
+        e_ids, e_sc = oracle.cosine_knn(ids, rows, q[qi], k)
+        assert np.array_equal(got[qi], e_ids), qi
+        assert np.abs(sc[qi] - e_sc).max() <= 1e-5
+    lib.ucfp_shard_comm_destroy(comm)
+    ix.close()
 
 
 @pytest.mark.parametrize("kind_name,parts", [("hamming", 2), ("hamming", 8), ("cosine", 3)])

@@ -96,6 +96,43 @@ def test_torn_tail_is_reported_and_cut_on_reopen(tmp_path):
         store.Sidecar(str(tmp_path / "junk"))
 
 
+def test_one_writer_per_log_and_snapshots_beside_it(tmp_path):
+    """a second opener must not cut the file under a live writer -- the log takes an exclusive (OFD) lock
+    for the writer's life; snapshots open beside a live writer and see a prefix of what it has appended."""
+    import threading
+    from ucfp_amd import store
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "w.sidecar")
+    sc = store.Sidecar(path)
+    sc.append([_img_record(rng, 1, i) for i in range(10)])
+    with pytest.raises(Exception, match="open for writing elsewhere"):
+        store.Sidecar(path)
+    errs = []
+
+    def second():                                        # same process, another thread: OFD locks still exclude it
+        try:
+            store.Sidecar(path).close()
+            errs.append("second writer got in")
+        except Exception:
+            pass
+    th = threading.Thread(target=second)
+    th.start()
+    th.join()
+    assert not errs
+    snap = store.Snapshot(path)                          # a reader beside the live writer
+    assert snap.live_rows == 10
+    sc.append([_img_record(rng, 1, 100 + i) for i in range(5)])
+    assert snap.live_rows == 10                          # a snapshot is a snapshot
+    snap.close()
+    sc.close()
+    sc = store.Sidecar(path)                             # the lock went with the descriptor
+    sc.append([_img_record(rng, 1, 999)])
+    sc.close()
+    snap = store.Snapshot(path)
+    assert snap.live_rows == 16 and snap.torn_bytes == 0
+    snap.close()
+
+
 @pytest.mark.gpu
 def test_rebuild_equals_the_index_that_wrote_the_log(gpu_ctx, tmp_path):
     """Ingest through a GpuIndex with the sidecar attached (overwrites, deletes, several tenants / algorithms /

@@ -100,6 +100,9 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_shard_unique_id": (C.c_int, [C.c_void_p]),
     "ucfp_shard_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ucfp_shard_comm_create_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32,
+                                            C.POINTER(C.c_void_p)]),
+    "ucfp_shard_comm_uses_rccl": (C.c_int, [C.c_void_p]),
     "ucfp_shard_comm_destroy": (None, [C.c_void_p]),
     "ucfp_shard_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "ucfp_shard_range": (None, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

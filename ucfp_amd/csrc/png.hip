@@ -20,7 +20,10 @@
 //                 outputs (a diagonal wavefront, 64 rows in flight).
 //
 // Scope: 8-bit greyscale / RGB / RGBA, non-interlaced, no tRNS -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
-// the host's decoder (like non-ASCII text).  Chunk CRCs and the Adler-32 trailer are verified, as the reference's decoder does.
+// the host's decoder (like non-ASCII text).  Every chunk's CRC-32 and the Adler-32 trailer are computed; a bad CRC on a
+// critical chunk is UCFP_E_MODALITY, while the checksum-ONLY failures decoders disagree on (Adler-32 of a stream that
+// otherwise inflated to the right length, the CRC of an ancillary chunk) are UCFP_IMAGE_NEEDS_HOST: the host's decoder
+// -- the reference's own, in a drop-in -- decides, so the device never rejects a file the reference would fingerprint.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -518,7 +521,9 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
                 break;
             }
             if (chunk_crc(p + pos + 4, 4 + cl, crc_tab, x2n, lane) != be32(p + pos + 8 + cl)) {
-                status = UCFP_E_MODALITY;
+                // a critical chunk with a bad CRC is damage; an ANCILLARY one (tEXt, pHYs ...) is a checksum-only
+                // failure of data the pixels do not depend on: the host's decoder decides (P5)
+                status = (t0 & 0x20) ? UCFP_IMAGE_NEEDS_HOST : UCFP_E_MODALITY;
                 break;
             }
             if (t0 == 'I' && t1 == 'D' && t2 == 'A' && t3 == 'T') {
@@ -544,8 +549,10 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
         }
         if (status == 0 && (!seen_idat || !seen_end)) status = UCFP_E_MODALITY;
     }
-    // zero the tail word so that a staged partial word holds no stale bytes
-    if (lane < 4) z[zn + lane] = 0;
+    // zero the tail word so that a staged partial word holds no stale bytes -- only for a file that will be inflated:
+    // a rejected file of < 16 bytes shares its (16-byte aligned) gather address with the NEXT file, whose wave is
+    // writing its zlib header there in this same launch (a valid file's zn + 4 stays inside its own byte range).
+    if (status == 0 && lane < 4) z[zn + lane] = 0;
     if (lane == 0) info[img] = PngInfo{zn, status};
 }
 
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
         bad = (cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8 | flg) % 31) != 0 || (flg & 0x20);
     }
     uint32_t bp = 16, outpos = 0;
-    bool last = false;
+    bool last = false, checksum_only = false;
     int B = C::kMaxB;
     Adler adler;
 #ifdef PNG_PROF
@@ -872,14 +879,21 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
     if (!bad) {
         // the Adler-32 of the output follows the deflate data at the next byte boundary, most significant byte first
         const uint32_t e = (bp + 7) / 8;
-        if (e + 4 > zlen) PNG_BAD(17);
-        else if (((uint32_t)z[e] << 24 | (uint32_t)z[e + 1] << 16 | (uint32_t)z[e + 2] << 8 | z[e + 3]) != adler.value()) PNG_BAD(18);
+        // A stream that inflated to exactly the announced length but whose CHECKSUM is absent or wrong is not rejected
+        // here: decoders differ on it (the reference's `png` crate can be configured either way, and its defaults
+        // have changed between releases), so the file goes to the host's decoder, which decides (P5).
+        if (e + 4 > zlen ||
+            ((uint32_t)z[e] << 24 | (uint32_t)z[e + 1] << 16 | (uint32_t)z[e + 2] << 8 | z[e + 3]) != adler.value())
+            checksum_only = true;
     }
 #ifdef PNG_PROF
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&g_png_prof[i], _acc[i]);
 #endif
-    if (bad && lane == 0) info[img].status = UCFP_E_MODALITY;
+    if (lane == 0) {
+        if (bad) info[img].status = UCFP_E_MODALITY;
+        else if (checksum_only) info[img].status = UCFP_IMAGE_NEEDS_HOST;
+    }
 }
 
 // One wave per image: PNG 9.2 reconstruction.  Lane j takes rows j, j + 64, ...; it works one pixel behind lane j - 1

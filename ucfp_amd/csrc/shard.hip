@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -117,13 +118,19 @@ int ucfp_shard_unique_id(uint8_t uid[UCFP_SHARD_UID_BYTES]) {
     return UCFP_OK;
 }
 
-int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES], int rank, int world,
-                           ucfp_shard_comm** out) {
+int ucfp_shard_comm_create_ex(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES], int rank, int world,
+                              uint32_t flags, ucfp_shard_comm** out) {
     if (!ctx || !out) return capi_fail(UCFP_E_INVALID, "ctx/out is NULL");
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world) return capi_fail(UCFP_E_INVALID, "rank %d outside world %d", rank, world);
     if (world > 64) return capi_fail(UCFP_E_UNSUPPORTED, "world %d > 64 shards per search", world);
-    if (world > 1 && !uid) return capi_fail(UCFP_E_INVALID, "uid is NULL (rank 0 makes it with ucfp_shard_unique_id)");
+    if (flags & ~(uint32_t)UCFP_SHARD_FORCE_RCCL) return capi_fail(UCFP_E_INVALID, "unknown flag bits 0x%x", flags);
+    // A one-rank communicator is legal in RCCL.  Forcing it makes a single-GPU host run the very code the multi-GPU
+    // job runs -- dlopen, ncclCommInitRank, ncclAllGather on the exchange stream, the merge over `recv` -- instead of
+    // the local short cut.
+    const char* env = getenv("UCFP_SHARD_FORCE_RCCL");
+    const bool use_rccl = world > 1 || (flags & UCFP_SHARD_FORCE_RCCL) || (env && env[0] == '1');
+    if (use_rccl && !uid) return capi_fail(UCFP_E_INVALID, "uid is NULL (rank 0 makes it with ucfp_shard_unique_id)");
     ucfp_shard_comm* c = new (std::nothrow) ucfp_shard_comm();
     if (!c) return capi_fail(UCFP_E_INDEX, "out of host memory");
     c->ctx = ctx;
@@ -142,7 +149,7 @@ int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES
         ucfp_shard_comm_destroy(c);
         return capi_fail(UCFP_E_INDEX, "shard communicator setup failed: %s", hipGetErrorString(e));
     }
-    if (world > 1) {
+    if (use_rccl) {
         RcclApi* api = rccl();
         if (!api) {
             ucfp_shard_comm_destroy(c);
@@ -159,6 +166,11 @@ int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES
     }
     *out = c;
     return UCFP_OK;
+}
+
+int ucfp_shard_comm_create(ucfp_ctx* ctx, const uint8_t uid[UCFP_SHARD_UID_BYTES], int rank, int world,
+                           ucfp_shard_comm** out) {
+    return ucfp_shard_comm_create_ex(ctx, uid, rank, world, 0, out);
 }
 
 void ucfp_shard_comm_destroy(ucfp_shard_comm* c) {
@@ -182,6 +194,8 @@ void ucfp_shard_comm_destroy(ucfp_shard_comm* c) {
         if (l) (void)hipStreamDestroy(l);
     delete c;
 }
+
+int ucfp_shard_comm_uses_rccl(ucfp_shard_comm* c) { return c && c->comm ? 1 : 0; }
 
 int ucfp_shard_comm_info(ucfp_shard_comm* c, int* rank, int* world, uint64_t* exchanges) {
     if (!c) return capi_fail(UCFP_E_INVALID, "comm is NULL");
@@ -283,16 +297,24 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* c, uint32
     uint32_t* l_keys = reinterpret_cast<uint32_t*>(S.buf + o_keys);
     uint32_t* l_cnt = reinterpret_cast<uint32_t*>(S.buf + o_cnt);
     uint8_t* send = S.buf + o_send;
-    uint8_t* recv = c->world > 1 ? S.buf + o_recv : send;
+    const bool exchange = c->comm != nullptr;   // world > 1, or a forced one-rank communicator
+    uint8_t* recv = exchange ? S.buf + o_recv : send;
     uint32_t* okeys = d_out_keys ? d_out_keys : reinterpret_cast<uint32_t*>(S.buf + o_okeys);
     // 1. this rank's shard, on the set's scan stream
-    int rc = ucfp_index_search_dev(idx, tenant, d_queries, nq, k, l_ids, nullptr, l_keys, l_cnt, ls);
-    if (rc) return rc;
-    ucfp::launch_topk_pack_entries(l_ids, l_keys, e, send, ls);
-    HIP_TRY(hipGetLastError());
+    const int rc = ucfp_index_search_dev(idx, tenant, d_queries, nq, k, l_ids, nullptr, l_keys, l_cnt, ls);
+    if (rc && !exchange) return rc;
+    if (rc) {
+        // This rank's scan could not be enqueued (workspace allocation, say) but the other ranks are about to enter the
+        // all-gather: join it with an all-invalid list (id 2^64-1, key 2^32-1 in every place: what a shard with no
+        // hit sends) so nobody blocks, and report the error after the collective has been issued.
+        HIP_TRY(hipMemsetAsync(send, 0xff, e * 16, ls));
+    } else {
+        ucfp::launch_topk_pack_entries(l_ids, l_keys, e, send, ls);
+        HIP_TRY(hipGetLastError());
+    }
     // 2. exchange + merge, on the side stream (the scan stream when there is nothing to exchange)
-    hipStream_t xs = c->world > 1 ? c->xs : ls;
-    if (c->world > 1) {
+    hipStream_t xs = exchange ? c->xs : ls;
+    if (exchange) {
         HIP_TRY(hipEventRecord(S.searched, ls));
         HIP_TRY(hipStreamWaitEvent(xs, S.searched, 0));
         RcclApi* api = rccl();
@@ -307,7 +329,7 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* c, uint32
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(S.done, xs));
-    return UCFP_OK;
+    return rc;   // non-zero: this rank's shard is missing from the answer every rank now holds (ucfp_last_error says why)
 }
 
 int ucfp_index_search_sharded_collect(ucfp_shard_comm* c, uint64_t ticket, void* stream) {

@@ -14,6 +14,14 @@
 //
 // Replay applies the log in order, the last entry of a key wins (redb insert / remove semantics).  A torn tail (crash
 // in the middle of an append) fails its CRC and is cut off on the next open.  Pure host code: no HIP here.
+//
+// Concurrency (open-file-description locks on two bytes of the header, so they work between threads and processes):
+//   byte 0  "a writer is alive": write-locked, non-blocking, for the life of a ucfp_sidecar -- a second ucfp_sidecar_open
+//           of the same log fails instead of cutting the file under the first (redb allows one writer per file too);
+//   byte 1  "the tail may move": write-locked by a writer only while it validates and cuts the torn tail at open,
+//           read-locked by ucfp_sidecar_snapshot_open while it maps and walks the file, so a snapshot never touches
+//           pages a concurrent open is truncating away (afterwards it only reads entries in front of the cut).
+// The writer's descriptor is O_APPEND: every entry lands at the end whatever else happened to the offset.
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -116,6 +124,20 @@ bool json_algorithm(const char* json, uint32_t n, const char** tag, uint32_t* ta
     return false;
 }
 
+// OFD lock on one header byte; type F_WRLCK / F_RDLCK / F_UNLCK.  Returns 0 or -1 (errno).
+int lock_byte(int fd, off_t byte, short type, bool wait) {
+    struct flock fl;
+    memset(&fl, 0, sizeof fl);
+    fl.l_type = type;
+    fl.l_whence = SEEK_SET;
+    fl.l_start = byte;
+    fl.l_len = 1;
+    int r;
+    do r = fcntl(fd, wait ? F_OFD_SETLKW : F_OFD_SETLK, &fl);
+    while (r != 0 && errno == EINTR);
+    return r;
+}
+
 struct KeyHash {
     size_t operator()(const std::pair<uint32_t, uint64_t>& k) const {
         uint64_t z = k.second * 0x9e3779b97f4a7c15ull + k.first;
@@ -145,8 +167,20 @@ extern "C" {
 int ucfp_sidecar_open(const char* path, ucfp_sidecar** out) {
     if (!path || !out) return capi_fail(UCFP_E_INVALID, "path/out is NULL");
     *out = nullptr;
-    const int fd = open(path, O_RDWR | O_CREAT, 0644);
+    const int fd = open(path, O_RDWR | O_CREAT | O_APPEND | O_CLOEXEC, 0644);
     if (fd < 0) return capi_fail(UCFP_E_INDEX, "sidecar %s: %s", path, strerror(errno));
+    if (lock_byte(fd, 0, F_WRLCK, false) != 0) {
+        const int e = errno;
+        close(fd);
+        if (e == EAGAIN || e == EACCES)
+            return capi_fail(UCFP_E_INDEX, "sidecar %s is open for writing elsewhere (one writer per log)", path);
+        return capi_fail(UCFP_E_INDEX, "sidecar %s: lock: %s", path, strerror(e));
+    }
+    if (lock_byte(fd, 1, F_WRLCK, true) != 0) {       // snapshots being opened finish their walk first
+        const int e = errno;
+        close(fd);
+        return capi_fail(UCFP_E_INDEX, "sidecar %s: lock: %s", path, strerror(e));
+    }
     struct stat st;
     if (fstat(fd, &st) != 0) {
         close(fd);
@@ -178,10 +212,7 @@ int ucfp_sidecar_open(const char* path, ucfp_sidecar** out) {
             return capi_fail(UCFP_E_INDEX, "sidecar %s: cannot cut the torn tail: %s", path, strerror(errno));
         }
     }
-    if (lseek(fd, 0, SEEK_END) < 0) {
-        close(fd);
-        return capi_fail(UCFP_E_INDEX, "sidecar %s: %s", path, strerror(errno));
-    }
+    (void)lock_byte(fd, 1, F_UNLCK, false);           // the tail is final; byte 0 stays locked until close
     ucfp_sidecar* sc = new (std::nothrow) ucfp_sidecar();
     if (!sc) {
         close(fd);
@@ -256,8 +287,14 @@ int ucfp_sidecar_snapshot_open(const char* path, ucfp_sidecar_snapshot** out, ui
                                uint64_t* torn_bytes) {
     if (!path || !out) return capi_fail(UCFP_E_INVALID, "path/out is NULL");
     *out = nullptr;
-    const int fd = open(path, O_RDONLY);
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return capi_fail(UCFP_E_NOT_FOUND, "sidecar %s: %s", path, strerror(errno));
+    // no writer may cut the tail between our fstat and the end of the walk (a read lock needs no write access)
+    struct TailLock {
+        int fd;
+        bool held;
+        ~TailLock() { if (held) (void)lock_byte(fd, 1, F_UNLCK, false); }
+    } tail{fd, lock_byte(fd, 1, F_RDLCK, true) == 0};
     struct stat st;
     if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof kMagic) {
         close(fd);

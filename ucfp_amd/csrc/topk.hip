@@ -395,12 +395,17 @@ __global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restr
     // keep the best min(n, k) candidates, sorted by (key, id), at the front of the list; returns their number
     auto prune = [&]() -> uint32_t {
         const uint32_t cn = s_n < kPruneCap ? s_n : kPruneCap;
-        // rank of every candidate = the number of candidates before it (ranks are unique: ids are)
+        // rank of every candidate = the number of candidates before it by (key, id, list position): a permutation even
+        // when an APPEND_ONLY shard holds the same id twice
         for (uint32_t e = tid; e < cn; e += 256) {
             const uint32_t dk = s_key[e];
             const uint64_t di = s_id[e];
             uint32_t rank = 0;
-            for (uint32_t o = 0; o < cn; o++) rank += key_less(s_key[o], s_id[o], dk, di) ? 1u : 0u;
+            for (uint32_t o = 0; o < cn; o++) {
+                const uint32_t ok = s_key[o];
+                const uint64_t oi = s_id[o];
+                rank += (key_less(ok, oi, dk, di) || (ok == dk && oi == di && o < e)) ? 1u : 0u;
+            }
             if (rank < k) {
                 s_tkey[rank] = dk;
                 s_tid[rank] = di;
@@ -461,8 +466,13 @@ __global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restr
                     }
                 }
         __syncthreads();
-        // a trip adds at most kPruneBatch x 1024 candidates: prune while another one might not fit
-        if (s_n > kPruneKeep) {                          // block-uniform
+        // a trip adds at most kPruneBatch x 1024 candidates: prune while another one might not fit.  The count is
+        // snapshotted behind a second barrier: without it a fast wave could fall through, start the next trip and bump
+        // s_n past the limit before a slow wave has read it -- the waves would then disagree about the branch (and
+        // about the barriers inside prune()).
+        const uint32_t cur_n = s_n;
+        __syncthreads();
+        if (cur_n > kPruneKeep) {                        // block-uniform
             // (an overfull list cannot happen: the check runs after every trip and a trip fits behind the last prune)
             const uint32_t kept = prune();
             if (kept >= k) tau = s_key[k - 1], tau_id = s_id[k - 1];   // the k-th best itself is in the list already

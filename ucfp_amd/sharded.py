@@ -24,6 +24,7 @@ from . import _lib
 from . import index as _index
 
 ENTRY_BYTES = 16
+FORCE_RCCL = 1      # UCFP_SHARD_FORCE_RCCL
 
 
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -65,7 +66,9 @@ def all_gather_entries(entries: torch.Tensor, group=None) -> torch.Tensor:
 class ShardComm:
     """RAII wrapper of one ucfp_shard_comm.  Collective: every rank of `group` constructs it."""
 
-    def __init__(self, ctx=None, group=None):
+    def __init__(self, ctx=None, group=None, force_rccl: bool = False):
+        """force_rccl: build a real RCCL communicator even for a single rank (UCFP_SHARD_FORCE_RCCL): the one-GPU
+        way to execute the multi-GPU code path (ncclCommInitRank + one ncclAllGather per batch + merge)."""
         self._lib = _lib.load()
         self.ctx = ctx or _lib.current_context()
         inited = dist.is_initialized()
@@ -75,6 +78,8 @@ class ShardComm:
         # gloo: the host moves the entries itself; the C communicator is then a world-1 one (local scan + merge only)
         c_world = self.world if self.backend == "nccl" else 1
         uid = (C.c_uint8 * 128)()
+        if c_world == 1 and force_rccl:
+            _lib.check(self._lib.ucfp_shard_unique_id(uid))
         if c_world > 1:
             if self.rank == 0:
                 _lib.check(self._lib.ucfp_shard_unique_id(uid))
@@ -82,9 +87,10 @@ class ShardComm:
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             uid = (C.c_uint8 * 128)(*t.cpu().tolist())
         h = C.c_void_p()
-        _lib.check(self._lib.ucfp_shard_comm_create(self.ctx.handle, uid, self.rank if c_world > 1 else 0, c_world,
-                                                    C.byref(h)))
+        _lib.check(self._lib.ucfp_shard_comm_create_ex(self.ctx.handle, uid, self.rank if c_world > 1 else 0, c_world,
+                                                       FORCE_RCCL if force_rccl else 0, C.byref(h)))
         self.handle = h
+        self.uses_rccl = bool(self._lib.ucfp_shard_comm_uses_rccl(h))
 
     def exchanges(self) -> int:
         n = C.c_uint64(0)
@@ -106,12 +112,12 @@ class ShardComm:
 class ShardedIndex:
     """This rank's shard plus the collective search. All tensors live on this rank's GPU."""
 
-    def __init__(self, kind: int, dim: int = 0, ctx=None, group=None, tenant: int = 0):
+    def __init__(self, kind: int, dim: int = 0, ctx=None, group=None, tenant: int = 0, force_rccl: bool = False):
         self.kind, self.dim, self.group, self.tenant = kind, dim, group, tenant
         self.ctx = ctx or _lib.current_context()
         self._lib = _lib.load()
         self.local = _index.DeviceIndex(kind, dim, _index.APPEND_ONLY, self.ctx)
-        self.comm = ShardComm(self.ctx, group)
+        self.comm = ShardComm(self.ctx, group, force_rccl)
         self.world = self.comm.world
         self.rccl = self.comm.backend == "nccl"
         self._bufs = {}

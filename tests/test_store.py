@@ -166,7 +166,12 @@ def test_rebuild_equals_the_index_that_wrote_the_log(gpu_ctx, tmp_path):
             q = rng.standard_normal((3, dim)).astype(np.float32)
             a, b = live._cos[dim].search(tenant, q, 10), again._cos[dim].search(tenant, q, 10)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (dim, tenant)
-    # keep writing through the rebuilt index: the log stays the record of both
+    # keep writing through the rebuilt index: the log stays the record of both.  One writer per log: while `live` holds
+    # it a second opener is refused; the hand-over is close, then reopen
+    with pytest.raises(Exception, match="open for writing elsewhere"):
+        store.rebuild(path, gpu_ctx, sidecar=True)
+    live._sidecar.close()
+    live.attach_sidecar(None)
     more = store.rebuild(path, gpu_ctx, sidecar=True)
     more.upsert([_img_record(rng, 1, 9999, "imgfprint-phash-v1")])
     more.flush()

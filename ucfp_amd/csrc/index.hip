@@ -13,6 +13,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -113,6 +114,7 @@ struct ucfp_index {
     // different streams run side by side (the sharded search does that); a cosine search -- its key matrix can be
     // gigabytes -- always takes slot 0.  ws_done[i] orders successive uses of slot i across streams.
     DevBuf ws_slot[2];
+    DevBuf direct_state[2];        // per slot: ticket word + published lists of the single-launch search (hamming_direct.hip)
     hipEvent_t ws_done[2] = {nullptr, nullptr};
     unsigned ws_next = 0, ws_cur = 0;
     // Mutations and searches may run on different streams: a mutation first waits for every search enqueued so far
@@ -164,6 +166,27 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
                      uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_keys, uint32_t* d_out_cnt,
                      hipStream_t st) {
     const size_t n = s ? s->n : 0;
+    if (ix->kind == UCFP_INDEX_HAMMING64 && nq <= ucfp::kHammingDirectMaxQ && ucfp::hamming_direct_ok(n, (uint32_t)nq, k) &&
+        !getenv("UCFP_HAMMING_NO_DIRECT")) {
+        // the request shape of /v1/query (one query; up to 8): ONE launch, no sample, no stages
+        DevBuf& stt = ix->direct_state[ix->ws_cur];
+        if (!stt.p) {
+            int rc = stt.ensure(ucfp::hamming_direct_state_bytes());
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(stt.p, 0, ucfp::kHammingDirectZeroBytes, st));   // ticket + global histogram: zeroed once, the kernel leaves them zero
+        }
+        uint32_t* keys = d_out_keys;
+        if (!keys) {
+            int rc = ix->ws_slot[ix->ws_cur].ensure(nq * k * 4 + 256);
+            if (rc) return rc;
+            keys = reinterpret_cast<uint32_t*>(ix->ws_slot[ix->ws_cur].p);
+        }
+        ucfp::launch_hamming_direct(reinterpret_cast<const uint64_t*>(s->rows), s->ids, n,
+                                    reinterpret_cast<const uint64_t*>(d_queries), (uint32_t)nq, k, stt.p, d_out_ids, keys,
+                                    d_out_scores, d_out_cnt, st, s->order);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (ix->kind == UCFP_INDEX_HAMMING64) {
         // query chunks of kHammingMaxBatch reuse one workspace (candidate lists are nq x cand_cap), stream-ordered
         const size_t chunk = nq < ucfp::kHammingMaxBatch ? nq : ucfp::kHammingMaxBatch;
@@ -392,6 +415,7 @@ void ucfp_index_destroy(ucfp_index* ix) {
         if (kv.second.order) (void)hipFree(kv.second.order);
     }
     for (auto& w : ix->ws_slot) w.release();
+    for (auto& w : ix->direct_state) w.release();
     ix->stage.release();
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     for (hipEvent_t ev : ix->ws_done)

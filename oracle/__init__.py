@@ -133,8 +133,16 @@ def cosine_knn_batch_omp(ids, rows, queries, k):
     return o_ids[:, :k], o_sc[:, :k], o_c
 
 
-def hamming_topk_omp(ids, codes, queries, k):
-    """Timed-baseline form of hamming_topk: OpenMP over (corpus slice, query) tiles, so one query uses every core."""
+def hamming_simd() -> bool:
+    """True when the timed Hamming scan uses its AVX-512 VPOPCNTDQ tile on this CPU."""
+    f = lib().ucfp_oracle_hamming_simd
+    f.restype = C.c_int
+    return bool(f())
+
+
+def hamming_topk_omp(ids, codes, queries, k, force_scalar=False):
+    """Timed-baseline form of hamming_topk: OpenMP over (corpus slice, query run) tiles, so one query uses every core;
+    AVX-512 VPOPCNTDQ inner loop where the CPU has it (force_scalar keeps the scalar tile)."""
     ids = np.ascontiguousarray(ids, dtype=np.uint64)
     codes = np.ascontiguousarray(codes, dtype=np.uint64)
     queries = np.ascontiguousarray(queries, dtype=np.uint64).reshape(-1)
@@ -142,11 +150,12 @@ def hamming_topk_omp(ids, codes, queries, k):
     o_ids = np.zeros((nq, max(k, 1)), np.uint64)
     o_d = np.zeros((nq, max(k, 1)), np.uint32)
     o_c = np.zeros(nq, np.uint32)
-    f = lib().ucfp_oracle_hamming_topk_omp
+    f = lib().ucfp_oracle_hamming_topk_omp2
     f.restype = None
-    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_int]
     f(ids.ctypes.data, codes.ctypes.data, codes.shape[0], queries.ctypes.data, nq, k, o_ids.ctypes.data, o_d.ctypes.data,
-      o_c.ctypes.data)
+      o_c.ctypes.data, 1 if force_scalar else 0)
     return o_ids[:, :k], o_d[:, :k], o_c
 
 

@@ -225,3 +225,19 @@ def test_resample_weight_reciprocal_form_is_exact():
         a = (rem / np.float64(sr)).astype(np.float32)
         b = (rem * (np.float64(1.0) / np.float64(sr))).astype(np.float32)
         assert np.array_equal(a, b)
+
+
+def test_timed_hamming_scan_equals_the_plain_one(oracle):
+    """The CPU baseline's OpenMP scan (AVX-512 VPOPCNTDQ tile where the CPU has it, scalar tile otherwise) returns exactly
+    what the plain oracle returns: ties, copies, slices that are not multiples of the 32-code vector trip."""
+    rng = np.random.default_rng(77)
+    for n, nq, k in ((1, 2, 10), (31, 3, 4), (1000, 3, 10), (65_537, 5, 1), (200_003, 70, 10), (150_000, 9, 37)):
+        codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+        if n == 65_537:
+            codes[:] = 7
+        ids = rng.permutation(n).astype(np.uint64)
+        q = rng.integers(0, 2**64, nq, dtype=np.uint64)
+        want = oracle.hamming_topk(ids, codes, q, k)
+        for scalar in (False, True):
+            got = oracle.hamming_topk_omp(ids, codes, q, k, force_scalar=scalar)
+            assert all(np.array_equal(a, b) for a, b in zip(want, got)), (n, nq, k, scalar)

@@ -751,7 +751,7 @@ def bench_text(args, rank, world, dev, ctx):
     res["lsh"] = bench_lsh(n_docs, rank, world, dev, ctx)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         oracle = timed_oracle()
-        ns = max(2048, 64 * oracle.num_threads())
+        ns = min(n_docs, max(32768, 2048 * oracle.num_threads()))      # ~0.1 s of CPU work and up: not a 4 ms blip
         docs = [bytes(r) for r in blob[:ns].cpu().numpy()]
         dt, dts, (o, _) = best_of(lambda: oracle.text_minhash_batch(docs))
         res["cpu_baseline"] = {"value": ns / dt, "unit": "docs/s", **host_cpu(), "threads": oracle.num_threads(), "kind": "port",

@@ -126,12 +126,15 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
  * the ENCODED files: one blob + n + 1 byte offsets (like the text calls), all announced with ONE geometry and pixel
  * format -- the host reads those 24 bytes of each upload with ucfp_png_probe and groups by them.  One wave per file:
  * chunk walk, inflate (RFC 1950/1951, speculative parallel Huffman decoding), PNG filter reconstruction.
- * Decoded on the device: 8-bit greyscale / RGB / RGBA, non-interlaced, without tRNS.  status[i]:
+ * Decoded on the device: 8-bit, non-interlaced, without tRNS -- greyscale and grey + alpha (-> GRAY8, the alpha byte is
+ * dropped: luma takes no alpha), RGB and indexed colour (-> RGB8 through the file's PLTE), RGBA (-> RGBA8); files of
+ * both layouts of a format may share a batch.  ucfp_png_probe reports the format a file DECODES to.  status[i]:
  *   0                      decoded (and hashed)
- *   UCFP_IMAGE_NEEDS_HOST  a valid PNG of another kind (palette, 16-bit, grey+alpha, interlaced, tRNS) or of another
- *                          geometry / format than announced: decode it with the host's decoder, submit the pixels
- *   UCFP_E_MODALITY        not a PNG / damaged stream (the reference answers 400)
- * Chunk CRCs and the zlib stream's Adler-32 are verified on the device.
+ *   UCFP_IMAGE_NEEDS_HOST  a valid PNG of another kind (16-bit, 1/2/4-bit, interlaced, tRNS) or of another geometry /
+ *                          format than announced, or a file whose only fault is a CHECKSUM (the Adler-32 of a stream that
+ *                          inflated to the right length, the CRC of an ancillary chunk): decoders differ on those, so
+ *                          the host's decoder decides -- decode it there, submit the pixels
+ *   UCFP_E_MODALITY        not a PNG / damaged stream / bad CRC on a critical chunk (the reference answers 400)
  * png_bytes = d_offsets[n] (the host knows it; sizes the context's workspace: about png_bytes + n x (2 x frame bytes)). */
 #define UCFP_IMAGE_NEEDS_HOST 1
 /* Host-side: geometry and pixel format of a PNG from its IHDR.  UCFP_OK, UCFP_IMAGE_NEEDS_HOST or UCFP_E_MODALITY. */

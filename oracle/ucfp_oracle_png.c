@@ -250,8 +250,10 @@ int ucfp_oracle_png_probe(const uint8_t* png, size_t n, uint32_t* w, uint32_t* h
     int depth = png[24], ctype = png[25], comp = png[26], filt = png[27], lace = png[28];
     if (*w == 0 || *h == 0 || comp != 0 || filt != 0 || lace > 1) return PNG_CORRUPT;
     if (depth != 8 || lace != 0) return PNG_NEEDS_HOST;
-    if (ctype == 0) *pixfmt = 0;
-    else if (ctype == 2) *pixfmt = 1;
+    /* the format the file DECODES to: indexed colour (3) -> RGB8 through PLTE, grey + alpha (4) -> GRAY8 (alpha dropped:
+     * luma takes no alpha, DESIGN I1; the host path's Pillow convert gives the same luma) */
+    if (ctype == 0 || ctype == 4) *pixfmt = 0;
+    else if (ctype == 2 || ctype == 3) *pixfmt = 1;
     else if (ctype == 6) *pixfmt = 2;
     else return PNG_NEEDS_HOST;
     return PNG_OK;
@@ -268,8 +270,13 @@ int ucfp_oracle_png_decode(const uint8_t* png, size_t n, uint8_t* pixels, size_t
     int fmt;
     int rc = ucfp_oracle_png_probe(png, n, &w, &h, &fmt);
     if (rc) return rc;
-    const size_t bpp = fmt == 0 ? 1 : fmt == 1 ? 3 : 4, row = (size_t)w * bpp;
-    if (row * h > cap) return PNG_CORRUPT;
+    const int ctype = png[25];
+    const size_t obpp = fmt == 0 ? 1 : fmt == 1 ? 3 : 4;                       /* bytes per pixel that leave */
+    const size_t bpp = ctype == 3 ? 1 : ctype == 4 ? 2 : obpp, row = (size_t)w * bpp;   /* ... and in the file */
+    if ((size_t)w * obpp * h > cap) return PNG_CORRUPT;
+    uint8_t plte[768];
+    size_t plte_n = 0;
+    memset(plte, 0, sizeof plte);                                              /* entries the file lacks are black */
     /* walk the chunks (5.3): length, type, data, CRC; IDATs must be consecutive (5.6) */
     uint8_t* z = (uint8_t*)malloc(n);
     size_t zn = 0, pos = 8;
@@ -294,12 +301,18 @@ int ucfp_oracle_png_decode(const uint8_t* png, size_t n, uint8_t* pixels, size_t
             if (seen_idat) idat_done = 1;
             if (memcmp(type, "IEND", 4) == 0) { seen_end = 1; break; }
             if (memcmp(type, "tRNS", 4) == 0) needs_host = 1;       /* the host decoder adds an alpha channel */
+            if (memcmp(type, "PLTE", 4) == 0) {                      /* PNG 11.2.3 */
+                if (len == 0 || len % 3 != 0 || len > 768 || seen_idat || plte_n) { rc = PNG_CORRUPT; break; }
+                memcpy(plte, png + pos + 8, len);
+                plte_n = len / 3;
+            }
             if (!(type[0] & 0x20) && memcmp(type, "IHDR", 4) != 0 && memcmp(type, "PLTE", 4) != 0) { rc = PNG_CORRUPT; break; }   /* unknown critical chunk */
         }
         pos += 12 + (size_t)len;
     }
     if (rc == PNG_NEEDS_HOST) { free(z); return rc; }
     if (rc == PNG_OK && (!seen_idat || !seen_end)) rc = PNG_CORRUPT;
+    if (rc == PNG_OK && ctype == 3 && plte_n == 0) rc = PNG_CORRUPT;
     if (rc == PNG_OK && needs_host) rc = PNG_NEEDS_HOST;
     if (rc) { free(z); return rc; }
     const size_t raw_n = (row + 1) * h;
@@ -312,9 +325,10 @@ int ucfp_oracle_png_decode(const uint8_t* png, size_t n, uint8_t* pixels, size_t
     /* P5: the right number of bytes but no / a wrong Adler-32: checksum-only, the host's decoder decides */
     if (rc == PNG_OK && !checksum_ok) rc = PNG_NEEDS_HOST;
     /* unfilter (9.2): x = filtered byte, a = left pixel's byte, b = above, c = above-left */
+    uint8_t* planes = (ctype == 3 || ctype == 4) ? (uint8_t*)malloc(row * h ? row * h : 1) : pixels;
     for (uint32_t y = 0; rc == PNG_OK && y < h; y++) {
         const uint8_t* src = raw + (row + 1) * y;
-        uint8_t* dst = pixels + row * y;
+        uint8_t* dst = planes + row * y;
         const uint8_t* up = y ? dst - row : NULL;
         int ft = src[0];
         if (ft > 4) { rc = PNG_CORRUPT; break; }
@@ -330,6 +344,13 @@ int ucfp_oracle_png_decode(const uint8_t* png, size_t n, uint8_t* pixels, size_t
             }
             dst[x] = (uint8_t)v;
         }
+    }
+    if (planes != pixels) {
+        for (size_t i = 0; rc == PNG_OK && i < (size_t)w * h; i++) {
+            if (ctype == 3) memcpy(pixels + 3 * i, plte + 3 * (size_t)planes[i], 3);
+            else pixels[i] = planes[2 * i];
+        }
+        free(planes);
     }
     free(raw);
     return rc;

@@ -106,8 +106,11 @@ def test_formats_handed_back_to_the_host(oracle):
     rng = np.random.default_rng(5)
     pal = PIL.fromarray(rng.integers(0, 256, (40, 40), dtype=np.uint8), "L").convert("P")
     b = io.BytesIO()
-    pal.save(b, "PNG")
-    assert oracle.png_decode(b.getvalue())[0] == oracle.PNG_NEEDS_HOST            # palette
+    pal.save(b, "PNG", transparency=3)
+    assert oracle.png_decode(b.getvalue())[0] == oracle.PNG_NEEDS_HOST            # palette with tRNS
+    b = io.BytesIO()
+    PIL.fromarray(rng.integers(0, 16, (40, 40), dtype=np.uint8), "L").convert("P").save(b, "PNG", bits=4)
+    assert oracle.png_decode(b.getvalue())[0] == oracle.PNG_NEEDS_HOST            # 4-bit palette
     b = io.BytesIO()
     PIL.fromarray(rng.integers(0, 65535, (40, 40), dtype=np.uint16)).save(b, "PNG")
     assert oracle.png_decode(b.getvalue())[0] == oracle.PNG_NEEDS_HOST            # 16 bit
@@ -117,3 +120,43 @@ def test_formats_handed_back_to_the_host(oracle):
     bad[len(bad) // 2] ^= 1
     assert oracle.png_decode(bytes(bad))[0] == oracle.PNG_CORRUPT                 # chunk CRC
     assert oracle.png_decode(b"GIF89a" + bytes(60))[0] == oracle.PNG_CORRUPT
+
+
+def palette_png(rng, h, w, colours=256, **kw):
+    """An 8-bit indexed-colour PNG with `colours` palette entries (PLTE shorter than 256 entries when colours < 256)."""
+    idx = rng.integers(0, colours, (h, w), dtype=np.uint8)
+    im = PIL.fromarray(idx, "P")
+    im.putpalette(rng.integers(0, 256, colours * 3, dtype=np.uint8).tobytes())
+    b = io.BytesIO()
+    im.save(b, "PNG", **kw)
+    return b.getvalue(), np.asarray(im.convert("RGB"))
+
+
+def grey_alpha_png(rng, h, w, **kw):
+    ga = rng.integers(0, 256, (h, w, 2), dtype=np.uint8)
+    ga[..., 0] = (np.add.outer(np.arange(h) * 2, np.arange(w) * 3) & 255) ^ (ga[..., 0] & 7)
+    b = io.BytesIO()
+    PIL.fromarray(ga, "LA").save(b, "PNG", **kw)
+    return b.getvalue(), ga[..., 0].copy()
+
+
+def test_palette_and_grey_alpha_decode_like_pillow(oracle):
+    """Round 3: indexed colour (8-bit) decodes to RGB8 through PLTE, grey + alpha (8-bit) to GRAY8 with the alpha dropped
+    -- what Pillow's convert("RGB") / the L band give, and what the host path feeds the hash with."""
+    rng = np.random.default_rng(11)
+    for colours, h, w, kw in ((256, 40, 53, {}), (7, 33, 64, {}), (200, 1, 1, {}), (256, 70, 129, {"compress_level": 9}),
+                              (31, 65, 200, {"optimize": True})):
+        png, rgb = palette_png(rng, h, w, colours, **kw)
+        if png[24] != 8:
+            continue                                                              # Pillow packed it below 8 bits: host
+        rc, px = oracle.png_decode(png)
+        assert rc == 0 and oracle.png_probe(png)[3] == 1 and np.array_equal(px, rgb), (colours, h, w)
+        assert np.array_equal(px, np.asarray(PIL.open(io.BytesIO(png)).convert("RGB")))
+    for h, w in ((40, 53), (1, 1), (64, 64), (129, 70)):
+        png, g = grey_alpha_png(rng, h, w)
+        rc, px = oracle.png_decode(png)
+        assert rc == 0 and oracle.png_probe(png)[3] == 0 and np.array_equal(px, g)
+        assert np.array_equal(px, np.asarray(PIL.open(io.BytesIO(png)).getchannel("L")))
+    # an index beyond the file's PLTE is black; an indexed file without PLTE is damaged
+    png, _ = palette_png(rng, 8, 8, 4)
+    assert png[24] in (2, 8)

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 PIL = pytest.importorskip("PIL.Image")
 
-from test_oracle_png import _png, config1_png   # noqa: E402
+from test_oracle_png import _png, config1_png, grey_alpha_png, palette_png   # noqa: E402
 
 
 def _chunk(t, d):
@@ -157,8 +157,8 @@ def test_needs_host_and_damaged_files(gpu_ctx, oracle):
     from ucfp_amd import image
     rng = np.random.default_rng(5)
     good, img = config1_png(7, side=64)
-    pal = io.BytesIO()
-    PIL.fromarray(rng.integers(0, 256, (64, 64), dtype=np.uint8), "L").convert("P").save(pal, "PNG")
+    pal = io.BytesIO()             # indexed colour WITH transparency: the host's decoder adds the alpha channel
+    PIL.fromarray(rng.integers(0, 256, (64, 64), dtype=np.uint8), "L").convert("P").save(pal, "PNG", transparency=3)
     deep = io.BytesIO()
     PIL.fromarray(rng.integers(0, 65535, (64, 64), dtype=np.uint16)).save(deep, "PNG")
     other_geom, _ = config1_png(8, side=32)
@@ -171,7 +171,9 @@ def test_needs_host_and_damaged_files(gpu_ctx, oracle):
     too_short = too_short[:16] + struct.pack(">II", 64, 64) + too_short[24:]
     pngs = [good, pal.getvalue(), deep.getvalue(), other_geom, gray, truncated, b"GIF89a" + bytes(80), trns, too_short, good]
     assert image.png_probe(good) == (0, 64, 64, image.PIX_RGB8)
-    assert image.png_probe(pal.getvalue())[0] == image.NEEDS_HOST and image.png_probe(b"GIF89a" + bytes(80))[0] < 0
+    # (the probe reads the IHDR only: an indexed file announces RGB8; its tRNS chunk is the device's business, below)
+    assert image.png_probe(pal.getvalue())[0] == 0 and image.png_probe(deep.getvalue())[0] == image.NEEDS_HOST
+    assert image.png_probe(b"GIF89a" + bytes(80))[0] < 0
     rec, st = image.fingerprint_pngs(pngs, 64, 64, image.PIX_RGB8, algo=image.MULTI, ctx=gpu_ctx)
     assert list(st[:5]) == [0, 1, 1, 1, 1], st
     assert st[5] < 0 and st[6] < 0 and st[7] == 1 and st[8] < 0 and st[9] == 0, st
@@ -237,6 +239,60 @@ def test_tiny_junk_files_between_valid_ones_at_unaligned_offsets(gpu_ctx, oracle
             assert st[i] == -1, (i, st[i])
         else:
             assert st[i] == 0 and np.array_equal(fr[i], im), i
+
+
+def test_palette_and_grey_alpha_files_decode_on_the_device(gpu_ctx, oracle):
+    """Round 3: 8-bit indexed colour -> RGB8 through the file's PLTE (short palettes: missing entries are
+    black), 8-bit grey + alpha -> GRAY8; in the SAME batch as plain RGB / grey files of the geometry; pixels equal to
+    Pillow's and the oracle's, records equal to the oracle's records of those pixels."""
+    from ucfp_amd import image
+    rng = np.random.default_rng(77)
+    for h, w in ((64, 64), (97, 131), (1, 1), (33, 300)):
+        files, want = [], []
+        for i in range(24):
+            if i % 3 == 0:
+                arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+                files.append(_png(arr, "RGB", compress_level=(1, 6, 9)[i % 3]))
+                want.append(arr)
+            else:
+                p, rgb = palette_png(rng, h, w, (256, 5, 77, 200)[i % 4], compress_level=(1, 6)[i % 2])
+                if p[24] != 8:
+                    continue
+                files.append(p)
+                want.append(rgb)
+        fr, st = image.decode_pngs(files, w, h, image.PIX_RGB8, ctx=gpu_ctx)
+        assert not st.any(), st
+        for i, f in enumerate(files):
+            assert image.png_probe(f) == (0, w, h, image.PIX_RGB8)
+            assert np.array_equal(fr[i], want[i]), (h, w, i)
+            assert np.array_equal(fr[i], oracle.png_decode(f)[1])
+        if h >= 32 and w >= 32:
+            rec, st = image.fingerprint_pngs(files, w, h, image.PIX_RGB8, algo=image.MULTI, ctx=gpu_ctx)
+            from ucfp_amd.blake3 import blake3_digest
+            ex = np.stack([np.frombuffer(blake3_digest(f), np.uint8) for f in files])
+            ref, _ = oracle.image_hash_batch(np.stack(want), 7, pixfmt=1, exact=ex)
+            assert not st.any() and np.array_equal(rec, ref)
+        files, want = [], []
+        for i in range(20):
+            if i % 2:
+                p, g = grey_alpha_png(rng, h, w, compress_level=(1, 9)[i % 4 == 1])
+            else:
+                g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+                p = _png(g, "L")
+            files.append(p)
+            want.append(g)
+        fr, st = image.decode_pngs(files, w, h, image.PIX_GRAY8, ctx=gpu_ctx)
+        assert not st.any(), st
+        for i, f in enumerate(files):
+            assert np.array_equal(fr[i], want[i]), (h, w, i)
+            assert np.array_equal(fr[i], np.asarray(PIL.open(io.BytesIO(f)).getchannel("L")))
+    # an indexed file that lost its PLTE chunk is damaged, not a host case
+    p, _ = palette_png(rng, 64, 64, 256)
+    i0 = p.index(b"PLTE")
+    ln = struct.unpack(">I", p[i0 - 4:i0])[0]
+    no_plte = p[:i0 - 4] + p[i0 + 8 + ln:]
+    _, st = image.decode_pngs([no_plte, p], 64, 64, image.PIX_RGB8, ctx=gpu_ctx)
+    assert list(st) == [-1, 0] and oracle.png_decode(no_plte)[0] == oracle.PNG_CORRUPT
 
 
 def test_damaged_files_never_hang_or_fault(gpu_ctx, oracle):

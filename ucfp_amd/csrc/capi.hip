@@ -235,8 +235,9 @@ int ucfp_png_probe(const uint8_t* png, size_t len, uint32_t* width, uint32_t* he
     const int depth = png[24], ctype = png[25], comp = png[26], filt = png[27], lace = png[28];
     if (*width == 0 || *height == 0 || comp != 0 || filt != 0 || lace > 1) return fail(UCFP_E_MODALITY, "damaged IHDR");
     if (depth != 8 || lace != 0) return UCFP_IMAGE_NEEDS_HOST;
-    if (ctype == 0) *pixfmt = UCFP_PIX_GRAY8;
-    else if (ctype == 2) *pixfmt = UCFP_PIX_RGB8;
+    // the format the file DECODES to: indexed colour -> RGB8 through its palette, grey + alpha -> GRAY8 (alpha dropped)
+    if (ctype == 0 || ctype == 4) *pixfmt = UCFP_PIX_GRAY8;
+    else if (ctype == 2 || ctype == 3) *pixfmt = UCFP_PIX_RGB8;
     else if (ctype == 6) *pixfmt = UCFP_PIX_RGBA8;
     else return UCFP_IMAGE_NEEDS_HOST;
     return UCFP_OK;

@@ -19,7 +19,7 @@
 //                 64 k + j one pixel behind lane j-1, so "above" and "above-left" are the neighbour lane's last two
 //                 outputs (a diagonal wavefront, 64 rows in flight).
 //
-// Scope: 8-bit greyscale / RGB / RGBA, non-interlaced, no tRNS -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
+// Scope: 8-bit greyscale / grey + alpha / RGB / indexed colour / RGBA, non-interlaced, no tRNS -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
 // the host's decoder (like non-ASCII text).  Every chunk's CRC-32 and the Adler-32 trailer are computed; a bad CRC on a
 // critical chunk is UCFP_E_MODALITY, while the checksum-ONLY failures decoders disagree on (Adler-32 of a stream that
 // otherwise inflated to the right length, the CRC of an ancillary chunk) are UCFP_IMAGE_NEEDS_HOST: the host's decoder
@@ -412,7 +412,14 @@ struct Adler {
 struct PngInfo {
     uint32_t zlen;      // bytes of the gathered zlib stream
     int32_t status;
+    uint32_t raw_n;     // filtered bytes the stream must inflate to: height x (1 + width x bytes per pixel IN THE FILE)
+    uint16_t layout;    // kLayoutPlain: the file's pixels are the announced format; kLayoutPalette: 8-bit indices into
+                        // PLTE -> RGB8; kLayoutGreyAlpha: 8-bit grey + alpha -> GRAY8 (the alpha byte is dropped, as the
+                        // host path does: luma takes no alpha, DESIGN I1)
+    uint16_t plte_n;    // palette entries
+    uint32_t plte_off;  // offset of the PLTE data inside the file
 };
+constexpr uint16_t kLayoutPlain = 0, kLayoutPalette = 1, kLayoutGreyAlpha = 2;
 
 __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
     return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3];
@@ -498,14 +505,19 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
     const size_t len = (size_t)(offsets[img + 1] - offsets[img]);
     uint8_t* z = zbuf + ((offsets[img] + 15) & ~(uint64_t)15);
     int32_t status = 0;
-    uint32_t zn = 0;
+    uint32_t zn = 0, fbpp = 1, plte_off = 0, plte_n = 0;
+    uint16_t layout = kLayoutPlain;
     if (len < 8 + 25 + 12 || p[0] != 137 || p[1] != 80 || p[2] != 78 || p[3] != 71 || p[4] != 13 || p[5] != 10 || p[6] != 26 ||
         p[7] != 10 || be32(p + 8) != 13 || p[12] != 'I' || p[13] != 'H' || p[14] != 'D' || p[15] != 'R') {
         status = UCFP_E_MODALITY;
     } else {
         const uint32_t w = be32(p + 16), h = be32(p + 20);
         const int depth = p[24], ctype = p[25], comp = p[26], filt = p[27], lace = p[28];
-        const int fmt = ctype == 0 ? UCFP_PIX_GRAY8 : ctype == 2 ? UCFP_PIX_RGB8 : ctype == 6 ? UCFP_PIX_RGBA8 : -1;
+        // what the file decodes to: palette -> RGB8 (through PLTE), grey + alpha -> GRAY8 (alpha dropped)
+        const int fmt = ctype == 0 ? UCFP_PIX_GRAY8 : ctype == 2 ? UCFP_PIX_RGB8 : ctype == 6 ? UCFP_PIX_RGBA8
+                      : ctype == 3 ? UCFP_PIX_RGB8 : ctype == 4 ? UCFP_PIX_GRAY8 : -1;
+        layout = ctype == 3 ? kLayoutPalette : ctype == 4 ? kLayoutGreyAlpha : kLayoutPlain;
+        fbpp = ctype == 0 || ctype == 3 ? 1u : ctype == 4 ? 2u : ctype == 2 ? 3u : 4u;
         if (w == 0 || h == 0 || comp != 0 || filt != 0 || lace > 1) status = UCFP_E_MODALITY;
         else if (depth != 8 || lace != 0 || fmt < 0 || fmt != pixfmt || w != width || h != height) status = UCFP_IMAGE_NEEDS_HOST;
     }
@@ -542,18 +554,25 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
                     break;
                 }
                 if (t0 == 't' && t1 == 'R' && t2 == 'N' && t3 == 'S') status = UCFP_IMAGE_NEEDS_HOST;
-                else if (!(t0 & 0x20) && !(t0 == 'P' && t1 == 'L' && t2 == 'T' && t3 == 'E')) status = UCFP_E_MODALITY;   // unknown critical chunk
+                else if (t0 == 'P' && t1 == 'L' && t2 == 'T' && t3 == 'E') {
+                    // PNG 11.2.3: 1 .. 256 entries of 3 bytes, before the first IDAT, once
+                    if (cl == 0 || cl % 3 != 0 || cl > 768 || seen_idat || plte_n) status = UCFP_E_MODALITY;
+                    plte_off = (uint32_t)(pos + 8);
+                    plte_n = cl / 3;
+                } else if (!(t0 & 0x20)) status = UCFP_E_MODALITY;   // unknown critical chunk
                 if (status == UCFP_E_MODALITY) break;
             }
             pos += 12 + (size_t)cl;
         }
         if (status == 0 && (!seen_idat || !seen_end)) status = UCFP_E_MODALITY;
+        if (status == 0 && layout == kLayoutPalette && plte_n == 0) status = UCFP_E_MODALITY;   // indexed colour needs PLTE
     }
     // zero the tail word so that a staged partial word holds no stale bytes -- only for a file that will be inflated:
     // a rejected file of < 16 bytes shares its (16-byte aligned) gather address with the NEXT file, whose wave is
     // writing its zlib header there in this same launch (a valid file's zn + 4 stays inside its own byte range).
     if (status == 0 && lane < 4) z[zn + lane] = 0;
-    if (lane == 0) info[img] = PngInfo{zn, status};
+    if (lane == 0)
+        info[img] = PngInfo{zn, status, height * (1u + width * fbpp), layout, (uint16_t)plte_n, plte_off};
 }
 
 #ifdef PNG_PROF
@@ -575,12 +594,13 @@ __device__ unsigned long long g_png_prof[16];
 template <class C>
 __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets,
                                                         size_t n, PngInfo* __restrict__ info, uint8_t* __restrict__ raw,
-                                                        size_t raw_stride, uint32_t raw_n) {
+                                                        size_t raw_stride) {
     __shared__ InflateLds<C> L;
     const size_t img = blockIdx.x;
     if (img >= n) return;
     const int lane = threadIdx.x;
     if (info[img].status != 0) return;
+    const uint32_t raw_n = info[img].raw_n;
     const uint8_t* z = zbuf + ((offsets[img] + 15) & ~(uint64_t)15);
     const uint32_t zlen = info[img].zlen;
     const uint32_t zwords = (zlen + 3) / 4, total_bits = zlen * 8;
@@ -911,22 +931,34 @@ struct UnfilterCfg {
     static constexpr int kWords = kPieces * 4;
     static constexpr int kSlot = kPieces * 16;
 };
-template <int BPP>
+// BPP = bytes per pixel IN THE FILE; LAYOUT says what leaves: kLayoutPlain the same bytes, kLayoutPalette (BPP 1) three
+// bytes per index through the file's PLTE, kLayoutGreyAlpha (BPP 2) the grey byte.  One launch per layout a batch may
+// hold; a launch skips the files of the other layouts (and only the plain launch reports the status of rejected files).
+template <int BPP, int LAYOUT>
 __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restrict__ raw, size_t raw_stride,
                                                          PngInfo* __restrict__ info, size_t n, uint32_t w, uint32_t h,
                                                          uint8_t* __restrict__ frames, size_t row_stride, size_t frame_stride,
-                                                         int32_t* __restrict__ status) {
+                                                         int32_t* __restrict__ status, const uint8_t* __restrict__ png,
+                                                         const uint64_t* __restrict__ offsets) {
     using Cfg = UnfilterCfg<BPP>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint8_t* slots = lds_raw;                               // [2][64 lanes][kSlot]; byte 3 = the byte before the block, byte 4.. = its pixels
     uint8_t* uprow = lds_raw + 2 * 64 * Cfg::kSlot;         // w * BPP bytes: the last row lane 63 finished
+    uint8_t* plte = uprow + (((size_t)w * BPP + 15) & ~(size_t)15);   // kLayoutPalette: 256 x 3 bytes, black beyond the file's entries
     const size_t img = blockIdx.x;
     if (img >= n) return;
     const int lane = threadIdx.x;
     const int32_t st = info[img].status;
     if (st != 0) {
-        if (lane == 0 && status) status[img] = st;
+        if (LAYOUT == kLayoutPlain && lane == 0 && status) status[img] = st;
         return;
+    }
+    if (info[img].layout != LAYOUT) return;
+    if (LAYOUT == kLayoutPalette) {
+        const uint8_t* pp = png + offsets[img] + info[img].plte_off;
+        const uint32_t pn = (uint32_t)info[img].plte_n * 3;
+        for (uint32_t i = lane; i < 768; i += 64) plte[i] = i < pn ? pp[i] : 0;
+        wave_lds_fence();
     }
     const uint8_t* src = raw + img * raw_stride;
     uint8_t* dst = frames + img * frame_stride;
@@ -966,6 +998,23 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restr
         if (x0 >= w) return;
         const uint32_t px = w - x0 < 64 ? w - x0 : 64, len = px * BPP;         // bytes per row segment
         const uint8_t* t0 = slots + (size_t)(bl & 1) * 64 * Cfg::kSlot + 4;
+        if (LAYOUT != kLayoutPlain) {
+            // lane = pixel of the 64-pixel segment: a palette index becomes its three PLTE bytes, a grey + alpha pair its grey
+            const uint32_t rows = h - k * 64 < 64 ? h - k * 64 : 64;
+            for (uint32_t r = 0; r < rows; r++) {
+                const uint8_t* t = t0 + (size_t)r * Cfg::kSlot;
+                if ((uint32_t)lane < px) {
+                    if (LAYOUT == kLayoutPalette) {
+                        uint8_t* d = dst + (size_t)(k * 64 + r) * row_stride + (size_t)(x0 + lane) * 3;
+                        const uint32_t e = (uint32_t)t[lane] * 3;
+                        d[0] = plte[e], d[1] = plte[e + 1], d[2] = plte[e + 2];
+                    } else {
+                        dst[(size_t)(k * 64 + r) * row_stride + x0 + lane] = t[2 * lane];
+                    }
+                }
+            }
+            return;
+        }
         const uint32_t wpr = words_ok ? len / 4 : 0;                           // <= 64: one word per lane and row
         const uint32_t rows = h - k * 64 < 64 ? h - k * 64 : 64;
         for (uint32_t r = 0; r < rows; r++) {
@@ -1097,7 +1146,7 @@ extern "C" int ucfp_debug_png_prof(unsigned long long* out16, int reset) {
 #endif
 
 size_t png_ws_bytes(size_t n, size_t png_bytes, uint32_t w, uint32_t h, int pixfmt, PngWs* ws) {
-    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 2 /* a grey + alpha file */ : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
     const size_t raw_n = (size_t)h * ((size_t)w * bpp + 1);
     PngWs l;
     l.raw_n = raw_n;
@@ -1125,24 +1174,31 @@ int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uin
     // 3000: 189 k | 164 k -- the chip holds about 1024 wide or 1536 narrow waves at a time
     if (n <= 512)           // two waves per CU hold such a batch: 512-bit rounds, 10 % less latency than 256-bit ones
         hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<512>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
-                           ws + l.raw, l.raw_stride, (uint32_t)l.raw_n);
+                           ws + l.raw, l.raw_stride);
     else if (n <= 1024 || (n > 1536 && n <= 2048))
         hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<256>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
-                           ws + l.raw, l.raw_stride, (uint32_t)l.raw_n);
+                           ws + l.raw, l.raw_stride);
     else
         hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<128>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
-                           ws + l.raw, l.raw_stride, (uint32_t)l.raw_n);
-    const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 1 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
-    const size_t lds = (size_t)w * bpp + 2 * 64 * (size_t)((3 + 1 + 64 * bpp + 15 + 15) / 16) * 16;
-    auto go = [&](auto kern) {
+                           ws + l.raw, l.raw_stride);
+    // one unfilter launch per file layout the announced format admits: GRAY8 <- grey | grey + alpha, RGB8 <- RGB | palette
+    auto go = [&](auto kern, size_t fbpp, bool palette) {
+        const size_t lds = (((size_t)w * fbpp + 15) & ~(size_t)15) + (palette ? 768 : 0) +
+                           2 * 64 * (size_t)((3 + 1 + 64 * fbpp + 15 + 15) / 16) * 16;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, stream, ws + l.raw, l.raw_stride, info, n, w, h, frames,
-                           row_stride, frame_stride, status);
+                           row_stride, frame_stride, status, png, offsets);
     };
-    if (bpp == 1) go(png_unfilter_kernel<1>);
-    else if (bpp == 3) go(png_unfilter_kernel<3>);
-    else go(png_unfilter_kernel<4>);
+    if (pixfmt == UCFP_PIX_GRAY8) {
+        go(png_unfilter_kernel<1, kLayoutPlain>, 1, false);
+        go(png_unfilter_kernel<2, kLayoutGreyAlpha>, 2, false);
+    } else if (pixfmt == UCFP_PIX_RGB8) {
+        go(png_unfilter_kernel<3, kLayoutPlain>, 3, false);
+        go(png_unfilter_kernel<1, kLayoutPalette>, 1, true);
+    } else {
+        go(png_unfilter_kernel<4, kLayoutPlain>, 4, false);
+    }
     return 0;
 }
 

@@ -477,6 +477,29 @@ int ucfp_index_search_sharded_dev(ucfp_index* idx, ucfp_shard_comm* comm, uint32
                                   size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
                                   uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream);
 
+/* ---- JPEG front end ----
+ * The reference's image route also takes JPEG uploads (src/modality/image.rs:54 "PNG / JPEG / WebP / GIF / BMP", decoders at
+ * Cargo.toml:143) and decodes them inside the same SDK call (image.rs:68-70, :176-179).  Same call shape as the PNG entry
+ * points: one blob + n + 1 byte offsets, ONE announced geometry (ucfp_jpeg_probe reads it from the frame header).  What
+ * is decoded of a JPEG is its LUMA component (DESIGN J1: the Y plane of a YCbCr file, the plane of a greyscale one; chroma
+ * is parsed, never transformed): frames are GRAY8, and what libjpeg returns for out_color_space = JCS_GRAYSCALE with the
+ * accurate integer IDCT, bit for bit.  One wave per file, one lane per restart interval (Huffman decoding is serial
+ * within one), one thread per 8x8 block for the inverse DCT.  status[i]:
+ *   0                      decoded (and hashed)
+ *   UCFP_IMAGE_NEEDS_HOST  a JPEG this path does not decode (progressive, arithmetic-coded, 12-bit, CMYK / RGB-coded,
+ *                          several scans, luma below the MCU's resolution, 16-bit quantisation tables), another geometry
+ *                          than announced, or ANY irregularity of the entropy-coded data: the host's decoder decides
+ *   UCFP_E_MODALITY        no SOI marker: not a JPEG (the reference answers 400)
+ * jpg_bytes = d_offsets[n]; workspace about jpg_bytes + n x 3 x width x height bytes. */
+int ucfp_jpeg_probe(const uint8_t* jpg, size_t len, uint32_t* width, uint32_t* height);
+int ucfp_image_jpeg_decode_batch_dev(ucfp_ctx* ctx, const uint8_t* d_jpg, const uint64_t* d_offsets, size_t n,
+                                     size_t jpg_bytes, uint32_t width, uint32_t height, uint8_t* d_frames,
+                                     size_t row_stride, size_t frame_stride, int32_t* d_status, void* stream);
+/* Encoded files -> records (as ucfp_image_png_hash_batch_dev; d_exact NULL: BLAKE3 of every file on the device). */
+int ucfp_image_jpeg_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_jpg, const uint64_t* d_offsets, size_t n,
+                                   size_t jpg_bytes, uint32_t width, uint32_t height, const ucfp_image_preprocess* pre,
+                                   const uint8_t* d_exact, uint8_t* d_out, int32_t* d_status, void* stream);
+
 /* BLAKE3-256 (default hash mode) of a HOST buffer: the `exact` digest the reference stores in
  * ImageFingerprint.exact (BLAKE3 of the uploaded bytes). Host code; no device needed. */
 int ucfp_blake3(const uint8_t* data, size_t len, uint8_t out[32]);

@@ -379,6 +379,32 @@ def png_decode(png: bytes):
     return rc, (px if rc == PNG_OK else None)
 
 
+JPG_OK, JPG_NEEDS_HOST, JPG_CORRUPT = 0, 1, -1
+
+
+def jpeg_probe(jpg: bytes):
+    """-> (status, width, height)."""
+    f = lib().ucfp_oracle_jpeg_probe
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    rc = f(jpg, len(jpg), C.byref(w), C.byref(h))
+    return rc, w.value, h.value
+
+
+def jpeg_decode_luma(jpg: bytes):
+    """-> (status, luma uint8 [h, w] (None unless status == JPG_OK)): the file's Y component, accurate integer IDCT."""
+    rc, w, h = jpeg_probe(jpg)
+    if rc != JPG_OK:
+        return rc, None
+    px = np.zeros((h, w), np.uint8)
+    f = lib().ucfp_oracle_jpeg_decode_luma
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    rc = f(jpg, len(jpg), px.ctypes.data, px.size)
+    return rc, (px if rc == JPG_OK else None)
+
+
 def image_normalize(frame: np.ndarray, pixfmt: int = 0) -> np.ndarray:
     frame = np.ascontiguousarray(frame, dtype=np.uint8)
     h, w = frame.shape[:2]

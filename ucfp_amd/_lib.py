@@ -138,6 +138,12 @@ SIGNATURES = {
     "ucfp_image_png_hash_batch_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                                 C.c_uint32, C.c_uint32, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_jpeg_probe": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ucfp_image_jpeg_decode_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                                   C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ucfp_image_jpeg_hash_batch_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                 C.c_uint32, C.c_uint32, C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]),
     "ucfp_sidecar_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ucfp_sidecar_close": (None, [C.c_void_p]),
     "ucfp_sidecar_append_upsert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint32, C.c_void_p,

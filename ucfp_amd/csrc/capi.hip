@@ -331,6 +331,112 @@ int ucfp_image_png_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d
     return UCFP_OK;
 }
 
+// ---------------------------------- JPEG front end ------------------------------------
+int ucfp_jpeg_probe(const uint8_t* jpg, size_t len, uint32_t* width, uint32_t* height) {
+    if (!jpg || !width || !height) return fail(UCFP_E_INVALID, "NULL argument");
+    *width = *height = 0;
+    if (len < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return fail(UCFP_E_MODALITY, "not a JPEG file");
+    size_t pos = 2;
+    for (;;) {
+        if (pos + 4 > len || jpg[pos] != 0xFF) return UCFP_IMAGE_NEEDS_HOST;
+        while (pos < len && jpg[pos] == 0xFF) pos++;
+        if (pos >= len) return UCFP_IMAGE_NEEDS_HOST;
+        const int m = jpg[pos++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9 || m == 0xDA || pos + 2 > len) return UCFP_IMAGE_NEEDS_HOST;      // a scan before any frame header
+        const size_t l = (size_t)jpg[pos] << 8 | jpg[pos + 1];
+        if (l < 2 || pos + l > len) return UCFP_IMAGE_NEEDS_HOST;
+        if (m == 0xC0 || m == 0xC1) {
+            if (l < 8 || jpg[pos + 2] != 8) return UCFP_IMAGE_NEEDS_HOST;
+            *height = (uint32_t)jpg[pos + 3] << 8 | jpg[pos + 4];
+            *width = (uint32_t)jpg[pos + 5] << 8 | jpg[pos + 6];
+            const int nc = jpg[pos + 7];
+            if (*width == 0 || *height == 0 || (nc != 1 && nc != 3)) return UCFP_IMAGE_NEEDS_HOST;
+            return UCFP_OK;
+        }
+        if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8) return UCFP_IMAGE_NEEDS_HOST;   // progressive, arithmetic ...
+        pos += l;
+    }
+}
+
+static int jpeg_check(ucfp_ctx* ctx, const void* d_jpg, const void* d_offsets, size_t n, size_t jpg_bytes, uint32_t w, uint32_t h) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (n && (!d_jpg || !d_offsets)) return fail(UCFP_E_INVALID, "jpg/offsets is NULL");
+    if (w == 0 || h == 0 || w > 16384 || h > 16384) return fail(UCFP_E_MODALITY, "JPEG geometry %ux%u outside 1 .. 16384", w, h);
+    if (n > 0x7fffffffu || jpg_bytes >= ((size_t)1 << 32)) return fail(UCFP_E_INVALID, "JPEG batch too large for one call");
+    return UCFP_OK;
+}
+
+// Decode into caller frames (frames != NULL) or into the workspace's own frame area (shares the PNG front end's workspace).
+static int jpeg_decode_impl(ucfp_ctx* ctx, const uint8_t* d_jpg, const uint64_t* d_offsets, size_t n, size_t jpg_bytes, uint32_t w,
+                            uint32_t h, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* d_status,
+                            hipStream_t st, ucfp::JpegWs* layout, uint8_t** own_frames) {
+    ucfp::JpegWs l;
+    size_t need = ucfp::jpeg_ws_bytes(n, jpg_bytes, w, h, &l);
+    const size_t frames_off = need;
+    if (!frames) need += n * frame_stride;
+    int rc = grow(&ctx->png_ws, &ctx->png_ws_cap, need);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, ctx->png_done, 0));
+    uint8_t* fr = frames ? frames : ctx->png_ws + frames_off;
+    ucfp::launch_jpeg_decode(d_jpg, d_offsets, n, w, h, ctx->png_ws, l, fr, row_stride, frame_stride, d_status, st);
+    HIP_TRY(hipGetLastError());
+    if (layout) *layout = l;
+    if (own_frames) *own_frames = fr;
+    return UCFP_OK;
+}
+
+int ucfp_image_jpeg_decode_batch_dev(ucfp_ctx* ctx, const uint8_t* d_jpg, const uint64_t* d_offsets, size_t n, size_t jpg_bytes,
+                                     uint32_t width, uint32_t height, uint8_t* d_frames, size_t row_stride, size_t frame_stride,
+                                     int32_t* d_status, void* stream) {
+    int rc = jpeg_check(ctx, d_jpg, d_offsets, n, jpg_bytes, width, height);
+    if (rc) return rc;
+    if (n == 0) return UCFP_OK;
+    if (!d_frames) return fail(UCFP_E_INVALID, "frames is NULL");
+    if (row_stride < (size_t)width || (n > 1 && frame_stride < row_stride * (size_t)(height - 1) + (size_t)width))
+        return fail(UCFP_E_INVALID, "row_stride / frame_stride too small for %ux%u", width, height);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = jpeg_decode_impl(ctx, d_jpg, d_offsets, n, jpg_bytes, width, height, d_frames, row_stride, frame_stride, d_status,
+                          (hipStream_t)stream, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->png_done, (hipStream_t)stream));
+    return UCFP_OK;
+}
+
+int ucfp_image_jpeg_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_jpg, const uint64_t* d_offsets, size_t n,
+                                   size_t jpg_bytes, uint32_t width, uint32_t height, const ucfp_image_preprocess* pre,
+                                   const uint8_t* d_exact, uint8_t* d_out, int32_t* d_status, void* stream) {
+    int rc = jpeg_check(ctx, d_jpg, d_offsets, n, jpg_bytes, width, height);
+    if (rc) return rc;
+    const size_t rec = ucfp_image_record_bytes(algo);
+    if (!rec) return fail(UCFP_E_UNSUPPORTED, "image algo mask %u is not one of ahash|phash|dhash|multi", algo);
+    if (n == 0) return UCFP_OK;
+    if (!d_out) return fail(UCFP_E_INVALID, "out is NULL");
+    const size_t row = ((size_t)width + 15) & ~(size_t)15, frame = row * height;   // luma planes, 16-byte rows: the fused hash path
+    const uint32_t min_dim = pre ? pre->min_dimension : 32u, max_dim = pre ? pre->max_dimension : 8192u;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ucfp::JpegWs l;
+    uint8_t* fr = nullptr;
+    rc = jpeg_decode_impl(ctx, d_jpg, d_offsets, n, jpg_bytes, width, height, nullptr, row, frame, nullptr, st, &l, &fr);
+    if (rc) return rc;
+    if (!d_exact) {
+        const size_t cvb = (ucfp::blake3_ws_bytes(n, jpg_bytes) + 255) & ~(size_t)255;
+        rc = grow(&ctx->b3_ws, &ctx->b3_ws_cap, cvb + n * 32);
+        if (rc) return rc;
+        ucfp::launch_blake3_batch(d_jpg, d_offsets, n, ctx->b3_ws, ctx->b3_ws + cvb, st);
+        d_exact = ctx->b3_ws + cvb;
+    }
+    HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, fr, n, width, height, row, frame, UCFP_PIX_GRAY8, min_dim, max_dim,
+                                                 d_exact, d_out, d_status, st));
+    ucfp::launch_jpeg_merge_status(ctx->png_ws, l, n, d_out, (uint32_t)rec, d_status, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->png_done, st));
+    return UCFP_OK;
+}
+
 int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t n,
                           uint32_t width, uint32_t height, size_t row_stride, size_t frame_stride,
                           int pixfmt, const ucfp_image_preprocess* pre, const uint8_t* exact,

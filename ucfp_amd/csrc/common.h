@@ -49,6 +49,18 @@ int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uin
 int launch_png_merge_status(const uint8_t* ws, const PngWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
                             hipStream_t stream);
 
+// jpeg.hip
+struct JpegWs {
+    size_t clean = 0, info = 0, seg = 0, qtab = 0, coef = 0, coef_stride = 0, total = 0;
+    uint32_t bxp = 0, byp = 0, max_seg = 0;
+};
+size_t jpeg_ws_bytes(size_t n, size_t jpg_bytes, uint32_t w, uint32_t h, JpegWs* ws);
+int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, uint8_t* ws,
+                       const JpegWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
+                       hipStream_t stream);
+int launch_jpeg_merge_status(const uint8_t* ws, const JpegWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
+                             hipStream_t stream);
+
 // hamming.hip
 struct HammingPlan {
     uint32_t qgroups = 0;       // ceil(nq / 64)

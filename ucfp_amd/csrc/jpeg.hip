@@ -1,0 +1,603 @@
+// jpeg.hip -- JPEG front end on the device: baseline files -> luma planes, for gfx950.
+//
+// The reference's image route takes JPEG uploads (src/modality/image.rs:54; decoders enabled at Cargo.toml:143) and
+// decodes them inside the SDK call (image.rs:68-70, :176-179: imgfprint -> image::load_from_memory).  What the hash needs
+// of a JPEG is its LUMA COMPONENT (DESIGN J1): the Y plane of a YCbCr file or the single plane of a greyscale one, at
+// full resolution.  Chroma blocks are parsed -- the entropy-coded stream interleaves them -- and never transformed; no
+// upsampling, no colour conversion.  The result is bit-equal to libjpeg's own luma output (out_color_space =
+// JCS_GRAYSCALE, JDCT_ISLOW), which the oracle restates and tests/test_oracle_jpeg.py pins against Pillow.
+//
+// Three kernels, everything else is bookkeeping:
+//   jpeg_scan_kernel   one wave per file.  Lane 0 walks the marker segments (SOF0/1, DQT, DHT, DRI, APP0/14, SOS) and
+//                      records where things are; then the wave removes the byte stuffing of the entropy-coded data
+//                      (FF 00 -> FF) 64 bytes per step -- ballot + prefix count compaction -- and cuts it at the RSTn
+//                      markers into SEGMENTS (one per restart interval, each starting on a byte).
+//   jpeg_huff_kernel   one wave per file, one LANE per segment (files without restart markers have one: Huffman decoding
+//                      is serial in the bit stream).  Code tables are built once per file in LDS: a 9-bit look-ahead table
+//                      per Huffman table + the canonical (mincode / maxcode / valptr) form for longer codes.  A lane keeps
+//                      a 64-bit window of its segment (aligned dword loads, the next one always in flight) and decodes
+//                      MCU by MCU; coefficients of luma blocks go, de-zigzagged, to the lane's 128 bytes of LDS and from
+//                      there as eight 16-byte stores to the coefficient plane.  Chroma coefficients are decoded and dropped.
+//   jpeg_idct_kernel   one THREAD per luma block over the whole batch: dequantisation + the accurate integer inverse DCT
+//                      (IJG jidctint "islow": 13-bit fixed point, two 1-D passes of 8, all in registers), range limit,
+//                      eight 8-byte row stores.
+// Anything this file does not decode -- progressive / arithmetic / 12-bit / CMYK / RGB-coded files, several scans, luma
+// coded below the MCU's resolution, 16-bit quantisation tables -- and any irregularity of the entropy-coded data gets
+// UCFP_IMAGE_NEEDS_HOST: decoders differ in what they forgive, the host's decides.  No SOI at all: UCFP_E_MODALITY.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ucfp_hip.h"
+#include "common.h"
+
+namespace ucfp {
+
+namespace {
+
+constexpr int kMaxSeg = 1 << 20;          // restart intervals per file the segment table may hold (bounded by its allocation)
+
+struct JpgInfo {
+    int32_t status;
+    uint32_t scan_off;      // offset of the entropy-coded data inside the file
+    uint32_t clean_len;     // bytes of it after unstuffing
+    uint32_t nseg;          // segments found (restart intervals)
+    uint32_t restart;       // MCUs per restart interval (0: none)
+    uint32_t dqt_off[4];    // file offset of each quantisation table's 64 bytes (0: absent)
+    uint32_t dht_off[8];    // file offset of the 16 length counts of table (class << 2 | id) (0: absent)
+    uint8_t ncomp, hmax, vmax, tq0;
+    uint8_t hs[3], vs[3], td[3], ta[3];
+};
+
+__constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__device__ __forceinline__ uint32_t be16(const uint8_t* p) { return (uint32_t)p[0] << 8 | p[1]; }
+
+// ---- header walk (lane 0; a few dozen dependent byte loads) ----
+__device__ int jpeg_parse(const uint8_t* p, size_t n, uint32_t width, uint32_t height, JpgInfo& J) {
+    J.status = 0;
+    J.scan_off = J.clean_len = J.nseg = J.restart = 0;
+    for (int i = 0; i < 4; i++) J.dqt_off[i] = 0;
+    for (int i = 0; i < 8; i++) J.dht_off[i] = 0;
+    J.ncomp = J.hmax = J.vmax = J.tq0 = 0;
+    if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) return UCFP_E_MODALITY;
+    size_t pos = 2;
+    bool have_sof = false, jfif = false;
+    int adobe = -1;
+    uint32_t w = 0, h = 0;
+    uint8_t cid[3] = {0, 0, 0}, tq[3] = {0, 0, 0};
+    for (;;) {
+        if (pos + 4 > n) return have_sof ? UCFP_IMAGE_NEEDS_HOST : UCFP_E_MODALITY;
+        if (p[pos] != 0xFF) return UCFP_IMAGE_NEEDS_HOST;
+        while (pos < n && p[pos] == 0xFF) pos++;
+        if (pos >= n) return UCFP_IMAGE_NEEDS_HOST;
+        const int m = p[pos++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) return UCFP_IMAGE_NEEDS_HOST;
+        if (pos + 2 > n) return UCFP_IMAGE_NEEDS_HOST;
+        const size_t len = be16(p + pos);
+        if (len < 2 || pos + len > n) return UCFP_IMAGE_NEEDS_HOST;
+        const uint8_t* s = p + pos + 2;
+        const size_t sl = len - 2;
+        if (m == 0xC0 || m == 0xC1) {
+            if (have_sof || sl < 6) return UCFP_IMAGE_NEEDS_HOST;
+            have_sof = true;
+            if (s[0] != 8) return UCFP_IMAGE_NEEDS_HOST;
+            h = be16(s + 1);
+            w = be16(s + 3);
+            J.ncomp = s[5];
+            if (w == 0 || h == 0 || (J.ncomp != 1 && J.ncomp != 3) || sl < 6 + 3 * (size_t)J.ncomp) return UCFP_IMAGE_NEEDS_HOST;
+            for (int c = 0; c < J.ncomp; c++) {
+                cid[c] = s[6 + 3 * c];
+                J.hs[c] = s[7 + 3 * c] >> 4;
+                J.vs[c] = s[7 + 3 * c] & 15;
+                tq[c] = s[8 + 3 * c];
+                if (J.hs[c] < 1 || J.hs[c] > 4 || J.vs[c] < 1 || J.vs[c] > 4 || tq[c] > 3) return UCFP_IMAGE_NEEDS_HOST;
+                if (J.hs[c] > J.hmax) J.hmax = J.hs[c];
+                if (J.vs[c] > J.vmax) J.vmax = J.vs[c];
+            }
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8) {
+            return UCFP_IMAGE_NEEDS_HOST;       // progressive, lossless, hierarchical, arithmetic coding (incl. DAC)
+        } else if (m == 0xC4) {
+            size_t o = 0;
+            while (o < sl) {
+                if (o + 17 > sl) return UCFP_IMAGE_NEEDS_HOST;
+                const int tc = s[o] >> 4, th = s[o] & 15;
+                if (tc > 1 || th > 3) return UCFP_IMAGE_NEEDS_HOST;
+                int cnt = 0, code = 0;
+                for (int l = 1; l <= 16; l++) {
+                    const int b = s[o + l];
+                    cnt += b;
+                    code += b;
+                    if (code > (1 << l)) return UCFP_IMAGE_NEEDS_HOST;     // over-subscribed: not a prefix code
+                    code <<= 1;
+                }
+                if (cnt > 256 || o + 17 + (size_t)cnt > sl) return UCFP_IMAGE_NEEDS_HOST;
+                J.dht_off[tc << 2 | th] = (uint32_t)(pos + 2 + o + 1);
+                o += 17 + (size_t)cnt;
+            }
+        } else if (m == 0xDB) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = s[o] >> 4, t = s[o] & 15;
+                if (pq != 0 || t > 3 || o + 65 > sl) return UCFP_IMAGE_NEEDS_HOST;
+                J.dqt_off[t] = (uint32_t)(pos + 2 + o + 1);
+                o += 65;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) return UCFP_IMAGE_NEEDS_HOST;
+            J.restart = be16(s);
+        } else if (m == 0xE0) {
+            if (sl >= 5 && s[0] == 'J' && s[1] == 'F' && s[2] == 'I' && s[3] == 'F' && s[4] == 0) jfif = true;
+        } else if (m == 0xEE) {
+            if (sl >= 12 && s[0] == 'A' && s[1] == 'd' && s[2] == 'o' && s[3] == 'b' && s[4] == 'e') adobe = s[11];
+        } else if (m == 0xDA) {
+            if (!have_sof || sl < 1) return UCFP_IMAGE_NEEDS_HOST;
+            const int ns = s[0];
+            if (ns != J.ncomp || sl < 1 + 2 * (size_t)ns + 3) return UCFP_IMAGE_NEEDS_HOST;
+            for (int c = 0; c < ns; c++) {
+                if (s[1 + 2 * c] != cid[c]) return UCFP_IMAGE_NEEDS_HOST;
+                J.td[c] = s[2 + 2 * c] >> 4;
+                J.ta[c] = s[2 + 2 * c] & 15;
+                if (J.td[c] > 3 || J.ta[c] > 3 || !J.dht_off[J.td[c]] || !J.dht_off[4 | J.ta[c]] || !J.dqt_off[tq[c]])
+                    return UCFP_IMAGE_NEEDS_HOST;
+            }
+            if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return UCFP_IMAGE_NEEDS_HOST;
+            J.scan_off = (uint32_t)(pos + len);
+            break;
+        }
+        pos += len;
+    }
+    J.tq0 = tq[0];
+    if (J.ncomp == 3) {
+        // libjpeg's colour space rule (jdapimin.c): JFIF -> YCbCr; Adobe transform 1 -> YCbCr, else not; otherwise by ids
+        bool ycc = true;
+        if (jfif) ycc = true;
+        else if (adobe >= 0) ycc = adobe == 1;
+        else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') ycc = false;
+        if (!ycc || J.hs[0] != J.hmax || J.vs[0] != J.vmax) return UCFP_IMAGE_NEEDS_HOST;
+    } else {
+        J.hmax = J.vmax = 1;          // a one-component scan is not interleaved: one block per MCU (T.81 A.2.2)
+        J.hs[0] = J.vs[0] = 1;
+    }
+    if (w != width || h != height) return UCFP_IMAGE_NEEDS_HOST;      // another geometry than the batch announced
+    return 0;
+}
+
+// One wave per file.  clean: the file's unstuffed entropy-coded bytes (at the 16-byte rounded file offset of a buffer as
+// large as the batch); seg: (max_seg + 2) offsets per file.
+__global__ __launch_bounds__(64) void jpeg_scan_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
+                                                      uint32_t width, uint32_t height, uint32_t max_seg,
+                                                      uint8_t* __restrict__ clean, uint32_t* __restrict__ seg,
+                                                      JpgInfo* __restrict__ info) {
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    const uint8_t* p = jpg + offsets[img];
+    const size_t len = (size_t)(offsets[img + 1] - offsets[img]);
+    __shared__ JpgInfo J;
+    if (lane == 0) J.status = jpeg_parse(p, len, width, height, J);
+    wave_lds_sync();
+    int32_t status = J.status;
+    uint8_t* out = clean + ((offsets[img] + 15) & ~(uint64_t)15);
+    uint32_t* sg = seg + img * (size_t)(max_seg + 2);
+    uint32_t o = 0, nseg = 0;       // wave-uniform: clean bytes written, RSTn markers seen
+    if (status == 0) {
+        if (lane == 0) sg[0] = 0;
+        const size_t s0 = J.scan_off;
+        uint32_t prev = 0;          // the byte before this step's first byte (never FF at the start of the scan)
+        bool ended = false;
+        for (size_t base = s0; base < len && !ended && status == 0; base += 64) {
+            const size_t i = base + lane;
+            const uint32_t b = i < len ? p[i] : 0x100u;        // 0x100: beyond the file
+            uint32_t before = (uint32_t)__shfl_up((int)b, 1, 64), after = (uint32_t)__shfl_down((int)b, 1, 64);
+            if (lane == 0) before = prev;
+            if (lane == 63) after = i + 1 < len ? p[i + 1] : 0x100u;
+            const bool second = before == 0xFF;                 // (FF FF is refused, so a byte after FF is never a first FF)
+            const bool ff = b == 0xFF && !second;
+            const bool rst_next = after >= 0xD0 && after <= 0xD7;
+            const bool is_end = (ff && after != 0x00 && !rst_next && after != 0xFF) || b == 0x100u;   // EOI, any other marker, end of file
+            const bool is_bad = ff && after == 0xFF;           // fill bytes inside the scan: host
+            const bool is_rst = second && b >= 0xD0 && b <= 0xD7;
+            const uint64_t endm = __ballot(is_end);
+            const uint32_t live = endm ? (uint32_t)__builtin_ctzll(endm) : 64u;     // lanes before the first end take part
+            const bool on = (uint32_t)lane < live;
+            if (__ballot(on && is_bad)) status = UCFP_IMAGE_NEEDS_HOST;
+            const bool keep = on && !(second && (b == 0x00 || is_rst)) && !(ff && rst_next);
+            const uint64_t km = __ballot(keep), rm = __ballot(on && is_rst);
+            const uint32_t kpos = o + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            if (keep) out[kpos] = (uint8_t)b;
+            if (on && is_rst) {
+                const uint32_t k = nseg + __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+                if ((b & 7u) != (k & 7u)) status = UCFP_IMAGE_NEEDS_HOST;           // restart markers count modulo 8 (T.81 E.1.4)
+                if (k + 1 <= max_seg) sg[k + 1] = kpos;                              // the next segment starts at the next kept byte
+            }
+            status = __ballot(status != 0) ? UCFP_IMAGE_NEEDS_HOST : 0;
+            o += (uint32_t)__popcll(km);
+            nseg += (uint32_t)__popcll(rm);
+            if (nseg > max_seg) status = UCFP_IMAGE_NEEDS_HOST;
+            prev = (uint32_t)__shfl((int)b, 63, 64);
+            ended = endm != 0;
+        }
+        nseg += 1;                                              // the last segment ends where the data ends
+        if (status == 0 && nseg <= max_seg + 1 && lane == 0) sg[nseg] = o;
+        if (lane < 16) out[o + lane] = 0;                        // (a reader's look-ahead past the end)
+    }
+    if (lane == 0) {
+        J.status = status;
+        J.clean_len = o;
+        J.nseg = nseg;
+        info[img] = J;
+    }
+}
+
+// ---- Huffman decoding ----
+struct HuffLds {
+    uint16_t look[6][512];     // 9 look-ahead bits -> length << 8 | symbol (0: the code is longer)
+    int32_t maxcode[6][18];    // canonical form for the long codes (T.81 F.2.2.3); [17] is a sentinel
+    int32_t valoff[6][17];     // valptr - mincode
+    uint8_t vals[6][256];
+    int16_t blk[64][72];       // one coefficient block per lane, natural order (144-byte rows: the lanes' 16-byte reads spread over the banks)
+    uint16_t qn[64];           // luma quantisation table, natural order
+    uint8_t zz[64];            // zigzag -> natural order (per-lane indices: LDS, not the constant cache)
+};
+
+// One wave per file: lane = restart interval (in rounds of 64).
+__global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
+                                                      uint32_t width, uint32_t height, uint32_t max_seg,
+                                                      const uint8_t* __restrict__ clean, const uint32_t* __restrict__ seg,
+                                                      JpgInfo* __restrict__ info, int16_t* __restrict__ coef,
+                                                      size_t coef_stride /* int16 per file */, uint32_t bxp /* luma blocks per row of the plane */,
+                                                      uint16_t* __restrict__ qtab) {
+    __shared__ HuffLds L;
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    const JpgInfo J = info[img];
+    if (J.status != 0) return;
+    const uint8_t* p = jpg + offsets[img];
+    // table slots: 0..2 = DC of component 0..2, 3..5 = AC (components sharing a table build it twice: three tiny builds)
+    for (int slot = 0; slot < 2 * (int)J.ncomp; slot++) {
+        const int c = slot % J.ncomp, ac = slot / J.ncomp;
+        const int sl = ac ? 3 + c : c;
+        const uint8_t* t = p + J.dht_off[ac ? (4 | J.ta[c]) : J.td[c]];     // 16 counts, then the symbols
+        for (int i = lane; i < 512; i += 64) L.look[sl][i] = 0;
+        wave_lds_sync();
+        // lane l < 16 owns code length l + 1: first code and first symbol index by a prefix scan over the counts
+        const int cnt = lane < 16 ? t[lane] : 0;
+        int ksum = cnt;                                 // inclusive symbol count
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int v = __shfl_up(ksum, off, 64);
+            if (lane >= off) ksum += v;
+        }
+        // mincode[l] = (mincode[l-1] + count[l-1]) << 1, serial over 16 lengths: lane 0 does it, 16 steps
+        int first = 0;
+        {
+            int code = 0;
+            for (int l = 0; l < 16; l++) {
+                const int cl = __shfl(cnt, l, 64);
+                if (lane == l) first = code;
+                code = (code + cl) << 1;
+            }
+        }
+        const int kfirst = ksum - cnt;
+        if (lane < 16) {
+            L.maxcode[sl][lane + 1] = cnt ? first + cnt - 1 : -1;
+            L.valoff[sl][lane + 1] = kfirst - first;
+        }
+        if (lane == 16) L.maxcode[sl][17] = 0x7fffffff;
+        const int total = __shfl(ksum, 15, 64);
+        for (int i = lane; i < total; i += 64) L.vals[sl][i] = t[16 + i];
+        wave_lds_sync();
+        // look-ahead entries of the codes of <= 9 bits: every code fills 2^(9 - l) entries
+        if (lane < 9) {
+            const int l = lane + 1;
+            for (int j = 0; j < cnt; j++) {
+                const int code = first + j, sym = L.vals[sl][kfirst + j];
+                const int lo = code << (9 - l), nfill = 1 << (9 - l);
+                for (int f = 0; f < nfill; f++) L.look[sl][lo + f] = (uint16_t)(l << 8 | sym);
+            }
+        }
+        wave_lds_sync();
+    }
+    {
+        const uint8_t* q = p + J.dqt_off[J.tq0];
+        L.zz[lane] = c_zigzag[lane];
+        L.qn[c_zigzag[lane]] = q[lane];
+        wave_lds_sync();
+        qtab[img * 64 + lane] = L.qn[lane];
+    }
+    const uint32_t mcu_w = 8u * J.hmax, mcu_h = 8u * J.vmax;
+    const uint32_t mx = (width + mcu_w - 1) / mcu_w, my = (height + mcu_h - 1) / mcu_h, total_mcu = mx * my;
+    const uint32_t per = J.restart ? J.restart : total_mcu;
+    const uint32_t need = (total_mcu + per - 1) / per;
+    bool bad = J.nseg != need;                     // one segment per restart interval, no more, no fewer
+    const uint8_t* cl = clean + ((offsets[img] + 15) & ~(uint64_t)15);
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(cl);
+    const uint32_t* sg = seg + img * (size_t)(max_seg + 2);
+    int16_t* cplane = coef + img * coef_stride;
+    int16_t* myblk = L.blk[lane];
+    for (int i = 0; i < 64; i += 8) *reinterpret_cast<uint4*>(myblk + i) = make_uint4(0, 0, 0, 0);
+    const uint32_t nb_c[3] = {(uint32_t)(J.ncomp == 1 ? 1 : J.hs[0] * J.vs[0]), (uint32_t)(J.ncomp == 3 ? J.hs[1] * J.vs[1] : 0),
+                              (uint32_t)(J.ncomp == 3 ? J.hs[2] * J.vs[2] : 0)};
+    for (uint32_t s0 = 0; s0 < need && !bad; s0 += 64) {
+        const uint32_t sgi = s0 + lane;
+        const bool mine = sgi < need;
+        const uint32_t b0 = mine ? sg[sgi] : 0, b1 = mine ? sg[sgi + 1] : 0;
+        const uint32_t avail = (b1 - b0) * 8;
+        // bit window: acc holds `cnt` valid bits at its top; wp = the next aligned dword to append; nxt is in flight
+        uint32_t wp = b0 >> 2;
+        uint64_t acc = 0;
+        int cnt = 0;
+        uint32_t fed = 0;                           // bits appended so far, counted from the segment's first bit
+        {
+            const uint32_t w0 = __builtin_bswap32(cw[wp++]);
+            const uint32_t skip = (b0 & 3u) * 8;
+            acc = (uint64_t)w0 << (32 + skip);
+            cnt = 32 - (int)skip;
+            fed = (uint32_t)cnt;
+        }
+        uint32_t nxt = __builtin_bswap32(cw[wp++]);
+        auto refill = [&]() {                       // keeps cnt >= 32 (a symbol needs <= 16 + 11 bits)
+            if (cnt <= 32) {
+                acc |= (uint64_t)nxt << (32 - cnt);
+                cnt += 32;
+                fed += 32;
+                nxt = __builtin_bswap32(cw[wp++]);
+            }
+        };
+        auto decode = [&](int sl) -> int {          // one Huffman symbol; -1: no such code
+            refill();
+            const uint32_t e = L.look[sl][(uint32_t)(acc >> 55)];
+            if (e) {
+                acc <<= (e >> 8);
+                cnt -= (int)(e >> 8);
+                return (int)(e & 255u);
+            }
+            const uint32_t top = (uint32_t)(acc >> 48);
+            int l = 10;
+            while (l <= 16 && (int)(top >> (16 - l)) > L.maxcode[sl][l]) l++;
+            if (l > 16) return -1;
+            const int sym = L.vals[sl][(int)(top >> (16 - l)) + L.valoff[sl][l]];
+            acc <<= l;
+            cnt -= l;
+            return sym;
+        };
+        auto receive = [&](int s) -> int {          // s more bits, sign-extended (T.81 F.2.2.1)
+            refill();
+            const int v = (int)(acc >> (64 - s));
+            acc <<= s;
+            cnt -= s;
+            return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+        };
+        int pred0 = 0, pred1 = 0, pred2 = 0;
+        bool err = false;
+        if (mine) {
+            const uint32_t m1 = (sgi + 1) * per < total_mcu ? (sgi + 1) * per : total_mcu;
+            for (uint32_t m = sgi * per; m < m1 && !err; m++) {
+                for (int c = 0; c < (int)J.ncomp && !err; c++) {
+                    for (uint32_t bi = 0; bi < nb_c[c] && !err; bi++) {
+                        const int s = decode(c);
+                        if (s < 0 || s > 11) { err = true; break; }
+                        const int diff = s ? receive(s) : 0;
+                        int dcv;
+                        if (c == 0) dcv = (pred0 += diff);
+                        else if (c == 1) dcv = (pred1 += diff);
+                        else dcv = (pred2 += diff);
+                        if (c == 0) myblk[0] = (int16_t)dcv;
+                        for (int k = 1; k < 64;) {
+                            const int rs = decode(3 + c);
+                            if (rs < 0) { err = true; break; }
+                            const int r = rs >> 4, sz = rs & 15;
+                            if (sz == 0) {
+                                if (r != 15) break;
+                                k += 16;
+                                if (k > 64) err = true;
+                                continue;
+                            }
+                            k += r;
+                            if (k > 63 || sz > 10) { err = true; break; }
+                            const int v = receive(sz);
+                            if (c == 0) myblk[L.zz[k]] = (int16_t)v;
+                            k++;
+                        }
+                        // bits used so far = fed - cnt - (what nxt would add: not yet appended); past the segment: irregular
+                        if (fed - (uint32_t)cnt > avail) err = true;
+                        if (c == 0 && !err) {
+                            const uint32_t bx = (m % mx) * J.hmax + bi % J.hs[0], by = (m / mx) * J.vmax + bi / J.hs[0];
+                            uint4* dst = reinterpret_cast<uint4*>(cplane + ((size_t)by * bxp + bx) * 64);
+#pragma unroll
+                            for (int i = 0; i < 8; i++) {
+                                dst[i] = *reinterpret_cast<const uint4*>(myblk + 8 * i);
+                                *reinterpret_cast<uint4*>(myblk + 8 * i) = make_uint4(0, 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(err)) bad = true;
+    }
+    if (bad && lane == 0) info[img].status = UCFP_IMAGE_NEEDS_HOST;
+}
+
+// ---- inverse DCT: one thread per luma block of the batch ----
+#define JD(x, n) (((x) + ((int32_t)1 << ((n)-1))) >> (n))
+// in[0..7] -> out[0..7] before descaling (jidctint.c, both passes share this butterfly)
+__device__ __forceinline__ void islow_1d(const int32_t in0, const int32_t in1, const int32_t in2, const int32_t in3, const int32_t in4,
+                                         const int32_t in5, const int32_t in6, const int32_t in7, int32_t (&o)[8]) {
+    int32_t z2 = in2, z3 = in6;
+    int32_t z1 = (z2 + z3) * 4433;
+    int32_t tmp2 = z1 + z3 * (-15137), tmp3 = z1 + z2 * 6270;
+    int32_t tmp0 = (in0 + in4) * 8192, tmp1 = (in0 - in4) * 8192;
+    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in7;
+    tmp1 = in5;
+    tmp2 = in3;
+    tmp3 = in1;
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    int32_t z4 = tmp1 + tmp3;
+    const int32_t z5 = (z3 + z4) * 9633;
+    tmp0 *= 2446;
+    tmp1 *= 16819;
+    tmp2 *= 25172;
+    tmp3 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 *= -16069;
+    z4 *= -3196;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    o[0] = tmp10 + tmp3;
+    o[7] = tmp10 - tmp3;
+    o[1] = tmp11 + tmp2;
+    o[6] = tmp11 - tmp2;
+    o[2] = tmp12 + tmp1;
+    o[5] = tmp12 - tmp1;
+    o[3] = tmp13 + tmp0;
+    o[4] = tmp13 - tmp0;
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpgInfo* __restrict__ info, size_t n, uint32_t width, uint32_t height,
+                                                       const int16_t* __restrict__ coef, size_t coef_stride, uint32_t bxp, uint32_t byp,
+                                                       const uint16_t* __restrict__ qtab, uint8_t* __restrict__ frames, size_t row_stride,
+                                                       size_t frame_stride) {
+    const size_t per = (size_t)bxp * byp;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * per) return;
+    const size_t img = t / per;
+    const uint32_t b = (uint32_t)(t % per), bx = b % bxp, by = b / bxp;
+    if (info[img].status != 0) return;
+    if (bx * 8 >= width || by * 8 >= height) return;                 // MCU padding
+    const int16_t* c = coef + img * coef_stride + (size_t)b * 64;
+    const uint16_t* q = qtab + img * 64;
+    int32_t ws[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint4 cv = *reinterpret_cast<const uint4*>(c + 8 * r);
+        const uint4 qv = *reinterpret_cast<const uint4*>(q + 8 * r);
+        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ws[8 * r + 2 * i] = (int32_t)(int16_t)(cw[i] & 0xffffu) * (int32_t)(qw[i] & 0xffffu);
+            ws[8 * r + 2 * i + 1] = (int32_t)(int16_t)(cw[i] >> 16) * (int32_t)(qw[i] >> 16);
+        }
+    }
+    // pass 1: columns
+#pragma unroll
+    for (int col = 0; col < 8; col++) {
+        int32_t o[8];
+        islow_1d(ws[col], ws[8 + col], ws[16 + col], ws[24 + col], ws[32 + col], ws[40 + col], ws[48 + col], ws[56 + col], o);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[8 * r + col] = JD(o[r], 13 - 2);
+    }
+    // pass 2: rows, range limit, store
+    uint8_t* dst = frames + img * frame_stride + (size_t)(by * 8) * row_stride + (size_t)bx * 8;
+    const bool whole = bx * 8 + 8 <= width && ((reinterpret_cast<uintptr_t>(dst) | row_stride) & 7u) == 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int32_t o[8];
+        islow_1d(ws[8 * r], ws[8 * r + 1], ws[8 * r + 2], ws[8 * r + 3], ws[8 * r + 4], ws[8 * r + 5], ws[8 * r + 6], ws[8 * r + 7], o);
+        uint32_t px[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const int32_t v = JD(o[x], 13 + 2 + 3) + 128;
+            px[x] = (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+        if (by * 8 + r < height) {
+            uint8_t* d = dst + (size_t)r * row_stride;
+            if (whole) {
+                *reinterpret_cast<uint2*>(d) = make_uint2(px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24,
+                                                          px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 8; x++)
+                    if (bx * 8 + x < width) d[x] = (uint8_t)px[x];
+            }
+        }
+    }
+}
+
+__global__ void jpeg_status_kernel(const JpgInfo* __restrict__ info, size_t n, int32_t* __restrict__ status) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) status[i] = info[i].status;
+}
+
+// Records of files that did not decode are zeroed and carry the decoder's status.
+__global__ void jpeg_merge_status_kernel(const JpgInfo* __restrict__ info, size_t n, uint8_t* __restrict__ out, uint32_t rec,
+                                         int32_t* __restrict__ status) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x / 64 + threadIdx.x / 64;
+    if (i >= n) return;
+    const int32_t st = info[i].status;
+    if (st == 0) return;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t b = lane * 4; b < rec; b += 256) *reinterpret_cast<uint32_t*>(out + i * rec + b) = 0;
+    if (lane == 0 && status) status[i] = st;
+}
+
+}  // namespace
+
+size_t jpeg_ws_bytes(size_t n, size_t jpg_bytes, uint32_t w, uint32_t h, JpegWs* ws) {
+    JpegWs l;
+    // the luma plane in blocks, with room for the padding of the largest MCU (up to 3 more blocks each way)
+    l.bxp = (w + 7) / 8 + 4;
+    l.byp = (h + 7) / 8 + 4;
+    l.max_seg = ((w + 7) / 8) * ((h + 7) / 8);               // restart interval = 1 MCU of one block: the most segments
+    if (l.max_seg > (uint32_t)kMaxSeg) l.max_seg = (uint32_t)kMaxSeg;
+    l.coef_stride = (size_t)l.bxp * l.byp * 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    l.clean = take(jpg_bytes + 16 + 64 + 512);
+    l.info = take(n * sizeof(JpgInfo));
+    l.seg = take(n * (size_t)(l.max_seg + 2) * 4);
+    l.qtab = take(n * 64 * 2);
+    l.coef = take(n * l.coef_stride * 2);
+    l.total = off;
+    if (ws) *ws = l;
+    return off;
+}
+
+int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, uint8_t* ws,
+                       const JpegWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
+                       hipStream_t stream) {
+    if (n == 0) return 0;
+    JpgInfo* info = reinterpret_cast<JpgInfo*>(ws + l.info);
+    uint32_t* seg = reinterpret_cast<uint32_t*>(ws + l.seg);
+    int16_t* coef = reinterpret_cast<int16_t*>(ws + l.coef);
+    uint16_t* qtab = reinterpret_cast<uint16_t*>(ws + l.qtab);
+    hipLaunchKernelGGL(jpeg_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h, l.max_seg, ws + l.clean,
+                       seg, info);
+    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h, l.max_seg,
+                       (const uint8_t*)(ws + l.clean), (const uint32_t*)seg, info, coef, l.coef_stride, l.bxp, qtab);
+    const size_t blocks = n * (size_t)l.bxp * l.byp;
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, stream, (const JpgInfo*)info, n, w, h,
+                       (const int16_t*)coef, l.coef_stride, l.bxp, l.byp, (const uint16_t*)qtab, frames, row_stride,
+                       frame_stride);
+    if (status)
+        hipLaunchKernelGGL(jpeg_status_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const JpgInfo*)info, n,
+                           status);
+    return 0;
+}
+
+int launch_jpeg_merge_status(const uint8_t* ws, const JpegWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
+                             hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(jpeg_merge_status_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
+                       reinterpret_cast<const JpgInfo*>(ws + l.info), n, out, rec, status);
+    return 0;
+}
+
+}  // namespace ucfp

@@ -186,6 +186,67 @@ def fingerprint_pngs(pngs: Sequence[bytes], width: int, height: int, pixfmt: int
     return d_out[:n].cpu().numpy(), d_st[:n].cpu().numpy()
 
 
+# ---- JPEG uploads: luma plane on the device (DESIGN J1) ----
+
+def jpeg_probe(data: bytes):
+    """Frame header of a JPEG -> (status, width, height); status 0, NEEDS_HOST (progressive, 12-bit, CMYK ...: the host's
+    decoder takes it) or a negative UCFP_E_* (not a JPEG)."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    rc = _lib.load().ucfp_jpeg_probe(data, len(data), C.byref(w), C.byref(h))
+    return int(rc), int(w.value), int(h.value)
+
+
+def decode_jpegs(jpgs: Sequence[bytes], width: int, height: int, ctx=None):
+    """Decode the LUMA plane of a batch of baseline JPEG files announced as width x height on the GPU.
+    -> (frames uint8 [n, h, w], status int32 [n]); frames of files with status != 0 are undefined."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    dev = f"cuda:{ctx.device}"
+    n = len(jpgs)
+    d_blob, d_off, total = _upload_pngs(jpgs, dev)
+    d_fr = torch.zeros((n, height, width), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().ucfp_image_jpeg_decode_batch_dev(
+        ctx.handle, d_blob.data_ptr(), d_off.data_ptr(), n, total, width, height, d_fr.data_ptr(), width, width * height,
+        d_st.data_ptr(), torch.cuda.current_stream().cuda_stream or None))
+    return d_fr.cpu().numpy(), d_st[:n].cpu().numpy()
+
+
+def fingerprint_jpegs_dev(jpg_ptr: int, offsets_ptr: int, n: int, jpg_bytes: int, width: int, height: int, *,
+                          algo: int = MULTI, exact_ptr: int = 0, out_ptr: int, status_ptr: int = 0, stream: int = 0,
+                          preprocess: Optional[PreprocessConfig] = None, ctx=None) -> None:
+    """Device-resident encoded files -> records; raw device addresses, no sync (ucfp_image_jpeg_hash_batch_dev)."""
+    ctx = ctx or _lib.current_context()
+    pre = (preprocess or PreprocessConfig())._c()
+    _lib.check(_lib.load().ucfp_image_jpeg_hash_batch_dev(
+        ctx.handle, algo, jpg_ptr, offsets_ptr, n, jpg_bytes, width, height, C.byref(pre), exact_ptr or None, out_ptr,
+        status_ptr or None, stream or None))
+
+
+def fingerprint_jpegs(jpgs: Sequence[bytes], width: int, height: int, *, algo: int = MULTI,
+                      exact: Optional[np.ndarray] = None, preprocess: Optional[PreprocessConfig] = None, ctx=None):
+    """Host convenience: encoded JPEG files -> (records uint8 [n, record_bytes], status int32 [n])."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    dev = f"cuda:{ctx.device}"
+    n = len(jpgs)
+    rec = record_bytes(algo)
+    d_blob, d_off, total = _upload_pngs(jpgs, dev)
+    d_out = torch.zeros((max(n, 1), rec), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    d_ex = None
+    if exact is not None:
+        ex = np.ascontiguousarray(exact, dtype=np.uint8)
+        if ex.shape != (n, 32):
+            raise ModalityError("exact must be [n, 32] bytes")
+        d_ex = torch.from_numpy(ex).to(dev)
+    fingerprint_jpegs_dev(d_blob.data_ptr(), d_off.data_ptr(), n, total, width, height, algo=algo,
+                          exact_ptr=d_ex.data_ptr() if d_ex is not None else 0, out_ptr=d_out.data_ptr(),
+                          status_ptr=d_st.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                          preprocess=preprocess, ctx=ctx)
+    return d_out[:n].cpu().numpy(), d_st[:n].cpu().numpy()
+
+
 class PngBatcher:
     """Host micro-batcher for encoded uploads (SURVEY 8f N1 + N4): request threads `submit` PNG bytes of one announced
     geometry; the library copies them to the device together and decodes, BLAKE3-hashes and fingerprints them there."""
@@ -236,6 +297,10 @@ def _decode(data: bytes, pre: PreprocessConfig):
     try:
         from PIL import Image  # decode only; not part of the hashing path
         img = Image.open(io.BytesIO(data))
+        if img.format == "JPEG" and img.mode in ("RGB", "L"):
+            # DESIGN J1: of a JPEG the LUMA component is what gets hashed -- libjpeg decodes just that plane (draft "L" =
+            # out_color_space JCS_GRAYSCALE), exactly what the device front end (jpeg.hip) produces
+            img.draft("L", img.size)
         img.load()
     except Exception as e:  # noqa: BLE001 - any decoder failure is a modality error
         raise ModalityError(f"image decode: {e}") from None

@@ -273,7 +273,9 @@ def bench_config1_phash_png(dev, ctx, n_img=1000):
     t_png_two = (time.perf_counter() - t0) / 20
     png_two_ok = bool(np.array_equal(two_o[0][0].cpu().numpy(), ref_png) and np.array_equal(two_o[1][0].cpu().numpy(), ref_png))
     ctx2.close()
+    jpeg = bench_config1_jpeg(dev, ctx, frames, oracle, cores)
     return {
+        "jpeg_front_end": jpeg,
         "workload": f"{n_img} synthetic 256x256 RGB PNGs, ?algorithm=phash (168-B records)",
         "cpu": {"kind": "port", **host_cpu(), "threads": cores,
                 "png_decode_s": t_dec, "decode_images_per_s_1_thread": n_img / t_dec,
@@ -299,6 +301,80 @@ def bench_config1_phash_png(dev, ctx, n_img=1000):
                 "gpu.png_front_end: encoded files in, records out, decode on the device (ucfp_image_png_hash_batch_dev; "
                 "SURVEY 8f N4), including the BLAKE3 of every file for the records' exact field",
     }
+
+
+def bench_config1_jpeg(dev, ctx, frames, oracle, cores):
+    """The config-1 images as JPEG uploads (quality 85, 4:2:0 -- what cameras and browsers send): CPU = libjpeg (Pillow) decoding
+    the luma plane + the C restatement's hash, 1 and N threads; GPU = the encoded files through the JPEG front end (decode,
+    BLAKE3 of every file, hash).  Records are checked against the oracle's records of libjpeg's luma planes."""
+    import io
+    import numpy as np
+    import torch
+    from PIL import Image
+    from concurrent.futures import ThreadPoolExecutor
+    from ucfp_amd import image
+    from ucfp_amd.blake3 import blake3_digest
+    n_img, side = frames.shape[0], frames.shape[1]
+    jpgs = []
+    for i in range(n_img):
+        b = io.BytesIO()
+        Image.fromarray(frames[i], "RGB").save(b, "JPEG", quality=85, subsampling=2)
+        jpgs.append(b.getvalue())
+
+    def decode(j):
+        im = Image.open(io.BytesIO(j))
+        im.draft("L", im.size)
+        return np.asarray(im)
+    t0 = time.perf_counter()
+    planes = np.stack([decode(j) for j in jpgs])
+    t_dec = time.perf_counter() - t0
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        list(pool.map(decode, jpgs[:cores * 2]))
+        t_decn, _, _ = best_of(lambda: list(pool.map(decode, jpgs, chunksize=max(1, n_img // (cores * 8)))))
+    oracle.set_threads(1)
+    t0 = time.perf_counter()
+    ref, _ = oracle.image_hash_batch(planes, 2, pixfmt=0)
+    t_h1 = time.perf_counter() - t0
+    oracle.set_threads(cores)
+    t_hn, _, _ = best_of(lambda: oracle.image_hash_batch(planes, 2, pixfmt=0))
+    ref[:, :32] = np.stack([np.frombuffer(blake3_digest(j), np.uint8) for j in jpgs])
+    offs = np.zeros(n_img + 1, np.int64)
+    np.cumsum([len(j) for j in jpgs], out=offs[1:])
+    jb = int(offs[-1])
+    h_blob = torch.from_numpy(np.frombuffer(b"".join(jpgs) + b"\0" * 16, np.uint8).copy()).pin_memory()
+    d_blob, d_off = h_blob.to(dev), torch.from_numpy(offs).to(dev)
+    d_out = torch.zeros((n_img, 168), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(n_img, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def go():
+        image.fingerprint_jpegs_dev(d_blob.data_ptr(), d_off.data_ptr(), n_img, jb, side, side, algo=image.PHASH,
+                                    out_ptr=d_out.data_ptr(), status_ptr=d_st.data_ptr(), stream=stream, ctx=ctx)
+    go()
+    torch.cuda.synchronize()
+    ok = bool(not d_st.any().item() and np.array_equal(d_out.cpu().numpy(), ref))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    t_g = e0.elapsed_time(e1) / 10 / 1e3
+    t0 = time.perf_counter()
+    for _ in range(10):
+        d_blob.copy_(h_blob, non_blocking=True)
+        go()
+    torch.cuda.synchronize()
+    t_gh = (time.perf_counter() - t0) / 10
+    return {"workload": f"the {n_img} config-1 images as JPEG (quality 85, 4:2:0; {jb / n_img:.0f} B per file), ?algorithm=phash",
+            "cpu": {"decoder": "libjpeg-turbo through Pillow, luma plane only (draft L)", "threads": cores,
+                    "decode_images_per_s_1_thread": n_img / t_dec, "decode_images_per_s_n_threads": n_img / t_decn,
+                    "decode_plus_hash_images_per_s_1_thread": n_img / (t_dec + t_h1),
+                    "decode_plus_hash_images_per_s_n_threads": n_img / (t_decn + t_hn)},
+            "gpu": {"images_per_s_encoded_bytes_resident": n_img / t_g, "images_per_s_incl_h2d_of_encoded_bytes": n_img / t_gh,
+                    "records_match_oracle_records_of_libjpeg_luma": ok},
+            "gpu_over_cpu_decode_plus_hash_1_thread": (n_img / t_gh) / (n_img / (t_dec + t_h1)),
+            "gpu_over_cpu_decode_plus_hash_n_threads": (n_img / t_gh) / (n_img / (t_decn + t_hn))}
 
 
 def cpu_baseline(sample: int, gpu_records_head):

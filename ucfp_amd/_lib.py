@@ -10,7 +10,7 @@ import threading
 from . import errors
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libucfp_hip.so")
+SO_PATH = os.environ.get("UCFP_HIP_SO") or os.path.join(_HERE, "libucfp_hip.so")   # (UCFP_HIP_SO: a tuning build of the same library)
 
 _lib = None
 _lock = threading.Lock()

@@ -340,13 +340,15 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
             cnt = 32 - (int)skip;
             fed = (uint32_t)cnt;
         }
-        uint32_t nxt = __builtin_bswap32(cw[wp++]);
+        // the dword in flight is kept RAW: swapping its bytes right behind the load would make the wave wait for it there
+        // (measured: every refill then cost a full memory round trip -- 45 % of the kernel)
+        uint32_t nxt = cw[wp++];
         auto refill = [&]() {                       // keeps cnt >= 32 (a symbol needs <= 16 + 11 bits)
             if (cnt <= 32) {
-                acc |= (uint64_t)nxt << (32 - cnt);
+                acc |= (uint64_t)__builtin_bswap32(nxt) << (32 - cnt);
                 cnt += 32;
                 fed += 32;
-                nxt = __builtin_bswap32(cw[wp++]);
+                nxt = cw[wp++];
             }
         };
         auto decode = [&](int sl) -> int {          // one Huffman symbol; -1: no such code

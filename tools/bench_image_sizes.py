@@ -16,7 +16,10 @@ def main():
     cases = [(512, 512, image.PIX_GRAY8), (512, 512, image.PIX_RGB8), (256, 256, image.PIX_RGB8),
              (1024, 1024, image.PIX_GRAY8), (640, 480, image.PIX_RGB8), (1280, 720, image.PIX_RGB8),
              (1920, 1080, image.PIX_RGB8), (1920, 1080, image.PIX_GRAY8), (300, 200, image.PIX_RGB8),
-             (3840, 2160, image.PIX_RGB8), (1000, 1000, image.PIX_RGBA8)]
+             (3840, 2160, image.PIX_RGB8), (1000, 1000, image.PIX_RGBA8),
+             # round 3: widths that are not multiples of 4 (byte-granular strips; the gather kernel before), small frames
+             (301, 200, image.PIX_RGB8), (641, 481, image.PIX_GRAY8), (1023, 767, image.PIX_RGB8), (1366, 768, image.PIX_RGB8),
+             (300, 200, image.PIX_GRAY8), (640, 480, image.PIX_GRAY8)]
     bpp = {image.PIX_GRAY8: 1, image.PIX_RGB8: 3, image.PIX_RGBA8: 4}
     for w, h, fmt in cases:
         fb = w * h * bpp[fmt]

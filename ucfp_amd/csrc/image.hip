@@ -635,15 +635,43 @@ template <int BPP>
 struct RawStrip {
     uint32_t w[BPP == 1 ? 1 : BPP];
 };
-template <int BPP>
-__device__ __forceinline__ RawStrip<BPP> load_raw_strip(const uint8_t* __restrict__ p) {
+// ALIGNED: the strip starts on its natural boundary (4 / 4 / 16 bytes).  Otherwise -- any width, any stride, any base --
+// the strip is assembled from the aligned dwords around it (one more load, v_alignbyte); the few strips whose dwords
+// would reach outside [lo, hi) (the first of the first row, the last of the last) are read byte by byte.
+template <int BPP, bool ALIGNED>
+__device__ __forceinline__ RawStrip<BPP> load_raw_strip(const uint8_t* __restrict__ p, const uint8_t* lo, const uint8_t* hi) {
     RawStrip<BPP> r;
-    if (BPP == 1) {
-        r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
-    } else {
-        const StripRow<BPP> t = load_strip<BPP>(p);
+    constexpr int NW = BPP == 1 ? 1 : BPP;
+    if (ALIGNED) {
+        if (BPP == 1) {
+            r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+        } else {
+            const StripRow<BPP> t = load_strip<BPP>(p);
 #pragma unroll
-        for (int i = 0; i < BPP; i++) r.w[i] = t.w[i];
+            for (int i = 0; i < BPP; i++) r.w[i] = t.w[i];
+        }
+        return r;
+    }
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    if (reinterpret_cast<const uint8_t*>(q) >= lo && reinterpret_cast<const uint8_t*>(q + NW + 1) <= hi) {
+        uint32_t d[NW + 1];
+#pragma unroll
+        for (int i = 0; i <= NW; i++) d[i] = q[i];
+#pragma unroll
+        for (int i = 0; i < NW; i++) r.w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint8_t* pb = p + 4 * i + b;
+                if (pb >= lo && pb < hi) v |= (uint32_t)*pb << (8 * b);
+            }
+            r.w[i] = v;
+        }
     }
     return r;
 }
@@ -672,7 +700,7 @@ __device__ __forceinline__ void strip_luma4(const RawStrip<BPP>& r, uint32_t (&l
 
 // SP = strips per lane (1, 2, 4, 8: w <= 256 SP): the register arrays are sized by it, so narrow frames run at
 // high occupancy
-template <int BPP, int SP>
+template <int BPP, int SP, bool ALIGNED>
 __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
     const uint8_t* __restrict__ frames, uint32_t w, uint32_t h, size_t row_stride, size_t frame_stride,
     uint8_t* __restrict__ norm) {
@@ -681,18 +709,43 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
     const uint32_t t = threadIdx.x;  // ONE WAVE per band: no workgroup barrier anywhere
     const size_t img = blockIdx.y;
     const uint8_t* __restrict__ f = frames + img * frame_stride;
-    const uint32_t nrow = w / 4;                              // strips in a source row (w % 4 == 0)
+    // the bytes this launch may read: [lo, hi) (the unaligned loader stays inside)
+    const uint8_t* lo = frames;
+    const uint8_t* hi = frames + (size_t)(gridDim.y - 1) * frame_stride + (size_t)(h - 1) * row_stride + (size_t)w * BPP;
     // column part: destination columns [c0, c1) and the source strips [blk0, blk0 + nblk) that overlap them
-    const uint32_t c0 = 256u * blockIdx.z / gridDim.z, c1 = 256u * (blockIdx.z + 1) / gridDim.z;
+    // (boundaries on multiples of 4: a lane stores its four columns as one dword)
+    const uint32_t c0 = (256u * blockIdx.z / gridDim.z) & ~3u, c1 = blockIdx.z + 1 == gridDim.z ? 256u : (256u * (blockIdx.z + 1) / gridDim.z) & ~3u;
     const uint32_t blk0 = (uint32_t)(((uint64_t)w * c0) >> 8) / 4;
     const uint32_t blk1 = ((uint32_t)(((uint64_t)w * c1 - 1) >> 8)) / 4 + 1;
     const uint32_t nblk = blk1 - blk0;                        // <= 64 SP (launcher)
+    const uint32_t wl = w - 4 * blk0;                         // source pixels from this part's first strip to the row's end
     const uint32_t j0 = 256u * blockIdx.x / gridDim.x, j1 = 256u * (blockIdx.x + 1) / gridDim.x;
     const uint32_t ys = (uint32_t)(((uint64_t)h * j0) / 256);
     const uint64_t D = (uint64_t)w * h;
     uint32_t acc[SP][4];
 #pragma unroll
     for (int s = 0; s < SP; s++) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
+    // 32-bit horizontal pass (see emit): the four destination columns of this lane, c0 + 4 t .. + 3
+    const bool small = D < ((uint64_t)1 << 23) && (c0 & 3u) == 0 && c1 - c0 <= 256u;
+    const uint32_t D32 = (uint32_t)D, den32 = 2 * D32;
+    const float rden = 1.0f / (float)den32;
+    uint32_t cxa[4], cxb[4], covA[4], cmid[4], covB[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t i = c0 + 4 * t + c < c1 ? c0 + 4 * t + c : c1 - 1;       // (lanes past the part's end compute, never store)
+        const uint32_t di0 = w * i, di1 = di0 + w;
+        cxa[c] = (di0 >> 8) - 4 * blk0;
+        cxb[c] = ((di1 - 1) >> 8) - 4 * blk0;
+        if (cxa[c] == cxb[c]) {              // inside one source pixel: R = w T[xa]
+            covA[c] = w;
+            cmid[c] = 0;
+            covB[c] = 0;
+        } else {
+            covA[c] = 256u * (cxa[c] + 4 * blk0 + 1) - di0;
+            cmid[c] = 256u;
+            covB[c] = di1 - 256u * (cxb[c] + 4 * blk0);
+        }
+    }
     // rows in flight ahead of the one being consumed: narrow frames have registers to spare and need the depth
     // (a wave moves only 64 x 4 BPP bytes per row and strip)
     constexpr int PF = SP <= 1 ? 6 : SP <= 2 ? 4 : SP <= 4 ? 2 : 1;
@@ -703,7 +756,7 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
         for (int s = 0; s < SP; s++) {
             const uint32_t blk = s * 64 + t;   // interleaved strips: a load instruction reads 64 x 4 BPP contiguous bytes
             // strips past the row end re-read the last strip: their accumulators are never emitted
-            dst[s] = load_raw_strip<BPP>(row + (size_t)(blk0 + (blk < nblk ? blk : nblk - 1)) * 4 * BPP);
+            dst[s] = load_raw_strip<BPP, ALIGNED>(row + (size_t)(blk0 + (blk < nblk ? blk : nblk - 1)) * 4 * BPP, lo, hi);
         }
     };
     // emit destination row j: prefix sums of the accumulated row -> LDS -> 4 output pixels per lane
@@ -736,8 +789,10 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
             {
                 const uint32_t blk = s * 64 + t;
                 const bool in_row = blk < nblk;   // strips past the row end accumulated a re-read of the last strip: drop
-                const uint32_t p1 = in_row ? acc[s][0] : 0u, p2 = p1 + (in_row ? acc[s][1] : 0u),
-                               p3 = p2 + (in_row ? acc[s][2] : 0u), tot = p3 + (in_row ? acc[s][3] : 0u);
+                // (and so do the pixels of the last strip that lie past the row's end when w % 4 != 0)
+                const uint32_t p1 = (in_row && 4 * blk + 0 < wl) ? acc[s][0] : 0u, p2 = p1 + ((in_row && 4 * blk + 1 < wl) ? acc[s][1] : 0u),
+                               p3 = p2 + ((in_row && 4 * blk + 2 < wl) ? acc[s][2] : 0u),
+                               tot = p3 + ((in_row && 4 * blk + 3 < wl) ? acc[s][3] : 0u);
                 uint32_t inc = tot;   // inclusive scan of the strip totals of this round of 64 strips
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -752,6 +807,34 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
         }
         if (t == 0) P[4 * nblk] = base;
         wave_lds_sync();
+        if (small) {
+            // R <= 255 D and 2 R + D < 2^32: the whole horizontal pass and the rounding division in 32 bits (frames up to
+            // 8.3 M pixels, i.e. every practical upload; the 64-bit form below is for the rest).  A lane owns FOUR ADJACENT
+            // destination columns whose geometry (first / last source pixel, edge overlaps) sits in registers since the
+            // kernel's start, so a pixel is four LDS reads, three multiplies and ONE float multiply + ONE correction step
+            // (|estimate - true| < 1: q <= 255 and a float carries 24 bits), and a row leaves as one dword per lane.
+            uint32_t q4 = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t pa0 = P[cxa[c]], pa1 = P[cxa[c] + 1], pb0 = P[cxb[c]], pb1 = P[cxb[c] + 1];
+                // (a column inside ONE source pixel has the weights w, 0, 0 from the setup: R = w T[xa])
+                const uint32_t R = covA[c] * (pa1 - pa0) + cmid[c] * (pb0 - pa1) + covB[c] * (pb1 - pb0);
+                const uint32_t num = 2 * R + D32;
+                uint32_t q = (uint32_t)((float)num * rden);
+                q = q > 255u ? 255u : q;
+                const int32_t rem = (int32_t)(num - q * den32);        // in (-den, 2 den): one step either way
+                q += rem >= (int32_t)den32 ? 1u : 0u;
+                q -= rem < 0 ? 1u : 0u;
+                q4 |= q << (8 * c);
+            }
+            const uint32_t i0 = c0 + 4 * t;
+            if (i0 + 4 <= c1) {
+                *reinterpret_cast<uint32_t*>(norm + img * 65536 + (size_t)j * 256 + i0) = q4;     // c0 is a multiple of 4 (below)
+            } else {
+                for (uint32_t c = 0; c < 4 && i0 + c < c1; c++) norm[img * 65536 + (size_t)j * 256 + i0 + c] = (uint8_t)(q4 >> (8 * c));
+            }
+            return;
+        }
         for (uint32_t i = c0 + t; i < c1; i += 64) {   // destination column
             const uint64_t di0 = (uint64_t)w * i, di1 = di0 + w;
             const uint32_t xa = (uint32_t)(di0 >> 8) - 4 * blk0, xb = (uint32_t)((di1 - 1) >> 8) - 4 * blk0;   // local pixels
@@ -921,19 +1004,21 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
     }
     // generic: normalise into the workspace in chunks, then hash the 256x256 planes (S = 1).
     const size_t align_need = pixfmt == 2 ? 15u : 3u;
-    const bool stream_ok = w % 4 == 0 && ((((uintptr_t)frames) | row_stride | frame_stride) & align_need) == 0;
+    const bool aligned = w % 4 == 0 && ((((uintptr_t)frames) | row_stride | frame_stride) & align_need) == 0;
+    // (any width / stride / base streams: the unaligned loader covers what `aligned` excludes; the per-pixel gather
+    // kernel image_normalize_kernel of round 1 -- 1-1.5 TB/s -- is kept as the plain statement of spec I3, unused)
     // column parts so that a wave owns at most 4 x 64 strips (+ the strip shared with its neighbour)
-    const unsigned parts = (unsigned)((w / 4 + 251) / 252);
+    const unsigned parts = (unsigned)(((w + 3) / 4 + 251) / 252);
     uint32_t part_strips = 0;   // widest part, exactly as the kernel derives it
     for (unsigned z = 0; z < parts; z++) {
-        const uint32_t c0 = 256u * z / parts, c1 = 256u * (z + 1) / parts;
+        const uint32_t c0 = (256u * z / parts) & ~3u, c1 = z + 1 == parts ? 256u : (256u * (z + 1) / parts) & ~3u;
         const uint32_t b0 = (uint32_t)(((uint64_t)w * c0) >> 8) / 4, b1 = ((uint32_t)(((uint64_t)w * c1 - 1) >> 8)) / 4 + 1;
         part_strips = b1 - b0 > part_strips ? b1 - b0 : part_strips;
     }
     const size_t ns_lds = ((size_t)4 * part_strips + 8) * 4;
     for (size_t done = 0; done < n;) {
         const size_t chunk = (n - done) < norm_ws_frames ? (n - done) : norm_ws_frames;
-        if (stream_ok) {
+        {
             // waves = bands x frames x parts: enough to fill 256 CUs x 16 waves, at least 8 destination rows per band
             unsigned bands = (unsigned)((16384 + chunk * parts - 1) / (chunk * parts));
             if (bands > 32) bands = 32;
@@ -952,19 +1037,22 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
                 else if (nblk <= 384) launch(k6);
                 else launch(k8);
             };
-            if (pixfmt == 0)
-                go(image_normalize_stream_kernel<1, 1>, image_normalize_stream_kernel<1, 2>, image_normalize_stream_kernel<1, 3>,
-                   image_normalize_stream_kernel<1, 4>, image_normalize_stream_kernel<1, 6>, image_normalize_stream_kernel<1, 8>);
-            else if (pixfmt == 1)
-                go(image_normalize_stream_kernel<3, 1>, image_normalize_stream_kernel<3, 2>, image_normalize_stream_kernel<3, 3>,
-                   image_normalize_stream_kernel<3, 4>, image_normalize_stream_kernel<3, 6>, image_normalize_stream_kernel<3, 8>);
-            else
-                go(image_normalize_stream_kernel<4, 1>, image_normalize_stream_kernel<4, 2>, image_normalize_stream_kernel<4, 3>,
-                   image_normalize_stream_kernel<4, 4>, image_normalize_stream_kernel<4, 6>, image_normalize_stream_kernel<4, 8>);
-        } else
-        hipLaunchKernelGGL(image_normalize_kernel, dim3(256, (unsigned)chunk), dim3(256), 0, stream,
-                           frames + done * frame_stride, w, h, row_stride, frame_stride, pixfmt,
-                           norm_ws);
+#define UCFP_NS_GO(BPP, AL)                                                                                            \
+    go(image_normalize_stream_kernel<BPP, 1, AL>, image_normalize_stream_kernel<BPP, 2, AL>,                              \
+       image_normalize_stream_kernel<BPP, 3, AL>, image_normalize_stream_kernel<BPP, 4, AL>,                              \
+       image_normalize_stream_kernel<BPP, 6, AL>, image_normalize_stream_kernel<BPP, 8, AL>)
+            if (pixfmt == 0) {
+                if (aligned) UCFP_NS_GO(1, true);
+                else UCFP_NS_GO(1, false);
+            } else if (pixfmt == 1) {
+                if (aligned) UCFP_NS_GO(3, true);
+                else UCFP_NS_GO(3, false);
+            } else {
+                if (aligned) UCFP_NS_GO(4, true);
+                else UCFP_NS_GO(4, false);
+            }
+#undef UCFP_NS_GO
+        }
         hipLaunchKernelGGL(image_hash_gray_kernel<1>, dim3((unsigned)chunk), dim3(kNT), 0, stream,
                            norm_ws, chunk, (size_t)256, (size_t)65536, algo,
                            exact ? exact + 32 * done : nullptr, out + done * rec,

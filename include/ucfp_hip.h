@@ -500,6 +500,11 @@ int ucfp_image_jpeg_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* 
                                    size_t jpg_bytes, uint32_t width, uint32_t height, const ucfp_image_preprocess* pre,
                                    const uint8_t* d_exact, uint8_t* d_out, int32_t* d_status, void* stream);
 
+/* Micro-batcher for JPEG uploads: the object of ucfp_png_batcher_create with the JPEG front end behind it (records of the
+ * files' luma planes).  Submit / stats / destroy with the ucfp_png_batcher_* calls. */
+int ucfp_jpeg_batcher_create(ucfp_ctx* ctx, uint32_t algo, uint32_t width, uint32_t height, const ucfp_image_preprocess* pre,
+                             size_t max_batch, size_t max_bytes, uint32_t max_delay_us, ucfp_png_batcher** out);
+
 /* BLAKE3-256 (default hash mode) of a HOST buffer: the `exact` digest the reference stores in
  * ImageFingerprint.exact (BLAKE3 of the uploaded bytes). Host code; no device needed. */
 int ucfp_blake3(const uint8_t* data, size_t len, uint8_t out[32]);

@@ -123,3 +123,39 @@ def test_randomly_damaged_files_never_hang_and_agree_with_the_oracle(gpu_ctx, or
             assert np.array_equal(fr[i], o_px), i
             agree += 1
     assert agree >= 20
+
+
+def test_micro_batcher_for_jpeg_uploads(gpu_ctx, oracle):
+    """48 request threads submit JPEG uploads one at a time (the reference's per-request shape, handlers.rs:232-302): every
+    answer equals the oracle's record of libjpeg's luma plane with the file's BLAKE3; a progressive file comes back NEEDS_HOST."""
+    import threading
+    from ucfp_amd import image
+    from ucfp_amd.blake3 import blake3_digest
+    files, want = [], []
+    for i in range(96):
+        f = jpeg_of(picture(64, 64, seed=i), quality=(50, 80, 95)[i % 3], subsampling=i % 3)
+        files.append(f)
+        ex = np.frombuffer(blake3_digest(f), np.uint8)[None]
+        want.append(oracle.image_hash_batch(libjpeg_luma(f)[None], 7, pixfmt=0, exact=ex)[0][0].tobytes())
+    prog = jpeg_of(picture(64, 64), progressive=True)
+    b = image.JpegBatcher(64, 64, algo=image.MULTI, max_batch=64, ctx=gpu_ctx)
+    got, errs = [None] * len(files), []
+
+    def worker(t):
+        try:
+            for i in range(t, len(files), 48):
+                got[i] = b.submit(files[i])
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(48)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs
+    for i, (rec, st) in enumerate(got):
+        assert st == 0 and rec == want[i], i
+    rec, st = b.submit(prog)
+    assert st == image.NEEDS_HOST and not any(rec)
+    assert b.stats()[1] == len(files) + 1
+    b.close()

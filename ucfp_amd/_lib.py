@@ -166,6 +166,8 @@ SIGNATURES = {
     "ucfp_blake3_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ucfp_png_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(ImagePreprocess),
                                           C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ucfp_jpeg_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ImagePreprocess),
+                                           C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ucfp_png_batcher_destroy": (None, [C.c_void_p]),
     "ucfp_png_batcher_submit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32)]),
     "ucfp_png_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -25,7 +25,7 @@ using ucfp::capi_fail;
 
 namespace {
 
-enum Kind { kTextMinhash, kTextSimhash, kAudioWang, kPngHash };
+enum Kind { kTextMinhash, kTextSimhash, kAudioWang, kPngHash, kJpegHash };
 
 // Pinned / device staging of one set.  Input: [max_batch + 1 payload offsets | payload], one H2D copy.
 // Result (text): [max_batch status words | n records], one D2H copy.  Result (audio): [max_batch + 1 hash offsets],
@@ -78,6 +78,11 @@ int run_set(Ragged* b, int s, size_t n, size_t units) {
             // encoded uploads: decode, BLAKE3 (exact = NULL) and hash on the device
             rc = ucfp_image_png_hash_batch_dev(b->ctx, b->algo, d_pay, d_off, n, units, b->width, b->height, b->pixfmt, &b->pre,
                                                nullptr, b->d_out + b->out_head, reinterpret_cast<int32_t*>(b->d_out), b->stream);
+            break;
+        case kJpegHash:
+            // JPEG uploads: luma plane decoded on the device (DESIGN J1), BLAKE3, hash
+            rc = ucfp_image_jpeg_hash_batch_dev(b->ctx, b->algo, d_pay, d_off, n, units, b->width, b->height, &b->pre, nullptr,
+                                                b->d_out + b->out_head, reinterpret_cast<int32_t*>(b->d_out), b->stream);
             break;
         case kAudioWang:
             rc = ucfp_audio_wang_batch_dev(b->ctx, reinterpret_cast<const float*>(d_pay), d_off, units, n, b->sample_rate,
@@ -266,6 +271,17 @@ int ucfp_png_batcher_create(ucfp_ctx* ctx, uint32_t algo, uint32_t width, uint32
         return rc;
     }
     *out = b;
+    return UCFP_OK;
+}
+
+int ucfp_jpeg_batcher_create(ucfp_ctx* ctx, uint32_t algo, uint32_t width, uint32_t height, const ucfp_image_preprocess* pre,
+                             size_t max_batch, size_t max_bytes, uint32_t max_delay_us, ucfp_png_batcher** out) {
+    // the same batcher object with the JPEG front end behind it: submit / stats / destroy through ucfp_png_batcher_*
+    const int rc = ucfp_png_batcher_create(ctx, algo, width, height, UCFP_PIX_GRAY8, pre, max_batch, max_bytes, max_delay_us, out);
+    if (rc) return rc;
+    // (the worker is idle until the first submit: switching the kind here is ordered before it by the caller's own
+    // hand-over of the handle to its request threads)
+    (*out)->r.kind = kJpegHash;
     return UCFP_OK;
 }
 

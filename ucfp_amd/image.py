@@ -186,6 +186,11 @@ def fingerprint_pngs(pngs: Sequence[bytes], width: int, height: int, pixfmt: int
     return d_out[:n].cpu().numpy(), d_st[:n].cpu().numpy()
 
 
+def JpegBatcher(width: int, height: int, **kw):
+    """Micro-batcher for JPEG uploads of one announced geometry (records of the files' luma planes, DESIGN J1)."""
+    return PngBatcher(width, height, PIX_GRAY8, jpeg=True, **kw)
+
+
 # ---- JPEG uploads: luma plane on the device (DESIGN J1) ----
 
 def jpeg_probe(data: bytes):
@@ -249,17 +254,23 @@ def fingerprint_jpegs(jpgs: Sequence[bytes], width: int, height: int, *, algo: i
 
 class PngBatcher:
     """Host micro-batcher for encoded uploads (SURVEY 8f N1 + N4): request threads `submit` PNG bytes of one announced
-    geometry; the library copies them to the device together and decodes, BLAKE3-hashes and fingerprints them there."""
+    geometry (or, with jpeg=True, JPEG bytes: `JpegBatcher`); the library copies them to the device together and decodes,
+    BLAKE3-hashes and fingerprints them there."""
 
     def __init__(self, width: int, height: int, pixfmt: int = PIX_RGB8, *, algo: int = MULTI, max_batch: int = 1024,
-                 max_bytes: int = 256 << 20, max_delay_us: int = 0, preprocess: Optional[PreprocessConfig] = None, ctx=None):
+                 max_bytes: int = 256 << 20, max_delay_us: int = 0, preprocess: Optional[PreprocessConfig] = None, ctx=None,
+                 jpeg: bool = False):
         self._lib = _lib.load()
         self.ctx = ctx or _lib.current_context()
         self.rec = record_bytes(algo)
         pre = (preprocess or PreprocessConfig())._c()
         h = C.c_void_p()
-        _lib.check(self._lib.ucfp_png_batcher_create(self.ctx.handle, algo, width, height, pixfmt, C.byref(pre), max_batch,
-                                                     max_bytes, max_delay_us, C.byref(h)))
+        if jpeg:
+            _lib.check(self._lib.ucfp_jpeg_batcher_create(self.ctx.handle, algo, width, height, C.byref(pre), max_batch,
+                                                          max_bytes, max_delay_us, C.byref(h)))
+        else:
+            _lib.check(self._lib.ucfp_png_batcher_create(self.ctx.handle, algo, width, height, pixfmt, C.byref(pre), max_batch,
+                                                         max_bytes, max_delay_us, C.byref(h)))
         self.handle = h
 
     def submit(self, png: bytes):

@@ -7,17 +7,21 @@
 // upsampling, no colour conversion.  The result is bit-equal to libjpeg's own luma output (out_color_space =
 // JCS_GRAYSCALE, JDCT_ISLOW), which the oracle restates and tests/test_oracle_jpeg.py pins against Pillow.
 //
-// Three kernels, everything else is bookkeeping:
+// Four kernels, everything else is bookkeeping:
 //   jpeg_scan_kernel   one wave per file.  Lane 0 walks the marker segments (SOF0/1, DQT, DHT, DRI, APP0/14, SOS) and
 //                      records where things are; then the wave removes the byte stuffing of the entropy-coded data
 //                      (FF 00 -> FF) 64 bytes per step -- ballot + prefix count compaction -- and cuts it at the RSTn
 //                      markers into SEGMENTS (one per restart interval, each starting on a byte).
-//   jpeg_huff_kernel   one wave per file, one LANE per segment (files without restart markers have one: Huffman decoding
-//                      is serial in the bit stream).  Code tables are built once per file in LDS: a 9-bit look-ahead table
-//                      per Huffman table + the canonical (mincode / maxcode / valptr) form for longer codes.  A lane keeps
-//                      a 64-bit window of its segment (aligned dword loads, the next one always in flight) and decodes
-//                      MCU by MCU; coefficients of luma blocks go, de-zigzagged, to the lane's 128 bytes of LDS and from
-//                      there as eight 16-byte stores to the coefficient plane.  Chroma coefficients are decoded and dropped.
+//   jpeg_huff_kernel   files WITH restart markers: one wave per file, one LANE per segment (Huffman decoding is serial
+//                      within one).  Code tables are built once per file in LDS: a 9-bit look-ahead table per Huffman table
+//                      + the canonical (mincode / maxcode / valptr) form for longer codes.  A lane keeps a 64-bit window of
+//                      its segment (aligned dword loads, the next one always in flight) and decodes MCU by MCU; coefficients
+//                      of luma blocks go, de-zigzagged, to the lane's 128 bytes of LDS and from there as eight 16-byte
+//                      stores to the coefficient plane.  Chroma coefficients are decoded and dropped.
+//   jpeg_huff_spec_kernel   files WITHOUT restart markers (what encoders write by default): one wave per file, the ONE
+//                      segment decoded by 64 lanes at once through speculation on the stream's self-synchronisation --
+//                      see the section's own comment; 2.8-5 x the serial lane (445 k against 160 k files/s at 1000 config-1
+//                      files, 909 k against 292 k at 8000).
 //   jpeg_idct_kernel   one THREAD per luma block over the whole batch: dequantisation + the accurate integer inverse DCT
 //                      (IJG jidctint "islow": 13-bit fixed point, two 1-D passes of 8, all in registers), range limit,
 //                      eight 8-byte row stores.
@@ -234,31 +238,24 @@ __global__ __launch_bounds__(64) void jpeg_scan_kernel(const uint8_t* __restrict
 }
 
 // ---- Huffman decoding ----
-struct HuffLds {
+// files of ONE segment (no restart markers) are decoded by the speculative kernel below, the others lane-per-segment
+__device__ __forceinline__ bool jpeg_takes_spec(const JpgInfo& J);
+
+struct HuffTables {
     uint16_t look[6][512];     // 9 look-ahead bits -> length << 8 | symbol (0: the code is longer)
     int32_t maxcode[6][18];    // canonical form for the long codes (T.81 F.2.2.3); [17] is a sentinel
     int32_t valoff[6][17];     // valptr - mincode
     uint8_t vals[6][256];
-    int16_t blk[64][72];       // one coefficient block per lane, natural order (144-byte rows: the lanes' 16-byte reads spread over the banks)
     uint16_t qn[64];           // luma quantisation table, natural order
     uint8_t zz[64];            // zigzag -> natural order (per-lane indices: LDS, not the constant cache)
 };
+struct HuffLds : HuffTables {
+    int16_t blk[64][72];       // one coefficient block per lane, natural order (144-byte rows: the lanes' 16-byte reads spread over the banks)
+};
 
-// One wave per file: lane = restart interval (in rounds of 64).
-__global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
-                                                      uint32_t width, uint32_t height, uint32_t max_seg,
-                                                      const uint8_t* __restrict__ clean, const uint32_t* __restrict__ seg,
-                                                      JpgInfo* __restrict__ info, int16_t* __restrict__ coef,
-                                                      size_t coef_stride /* int16 per file */, uint32_t bxp /* luma blocks per row of the plane */,
-                                                      uint16_t* __restrict__ qtab) {
-    __shared__ HuffLds L;
-    const size_t img = blockIdx.x;
-    if (img >= n) return;
-    const int lane = threadIdx.x;
-    const JpgInfo J = info[img];
-    if (J.status != 0) return;
-    const uint8_t* p = jpg + offsets[img];
-    // table slots: 0..2 = DC of component 0..2, 3..5 = AC (components sharing a table build it twice: three tiny builds)
+// One wave builds a file's code tables in LDS.  Slots: 0..2 = DC of component 0..2, 3..5 = AC (components sharing a table
+// build it twice: tiny builds).  Also the zigzag map and the luma quantisation table in natural order (copied to qtab).
+__device__ void build_tables(HuffTables& L, const JpgInfo& J, const uint8_t* __restrict__ p, int lane, uint16_t* __restrict__ qtab_img) {
     for (int slot = 0; slot < 2 * (int)J.ncomp; slot++) {
         const int c = slot % J.ncomp, ac = slot / J.ncomp;
         const int sl = ac ? 3 + c : c;
@@ -273,7 +270,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
             const int v = __shfl_up(ksum, off, 64);
             if (lane >= off) ksum += v;
         }
-        // mincode[l] = (mincode[l-1] + count[l-1]) << 1, serial over 16 lengths: lane 0 does it, 16 steps
+        // mincode[l] = (mincode[l-1] + count[l-1]) << 1, serial over the 16 lengths
         int first = 0;
         {
             int code = 0;
@@ -303,13 +300,28 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
         }
         wave_lds_sync();
     }
-    {
-        const uint8_t* q = p + J.dqt_off[J.tq0];
-        L.zz[lane] = c_zigzag[lane];
-        L.qn[c_zigzag[lane]] = q[lane];
-        wave_lds_sync();
-        qtab[img * 64 + lane] = L.qn[lane];
-    }
+    const uint8_t* q = p + J.dqt_off[J.tq0];
+    L.zz[lane] = c_zigzag[lane];
+    L.qn[c_zigzag[lane]] = q[lane];
+    wave_lds_sync();
+    qtab_img[lane] = L.qn[lane];
+}
+
+// One wave per file: lane = restart interval (in rounds of 64).
+__global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
+                                                      uint32_t width, uint32_t height, uint32_t max_seg,
+                                                      const uint8_t* __restrict__ clean, const uint32_t* __restrict__ seg,
+                                                      JpgInfo* __restrict__ info, int16_t* __restrict__ coef,
+                                                      size_t coef_stride /* int16 per file */, uint32_t bxp /* luma blocks per row of the plane */,
+                                                      uint16_t* __restrict__ qtab) {
+    __shared__ HuffLds L;
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    const JpgInfo J = info[img];
+    if (J.status != 0 || jpeg_takes_spec(J)) return;          // (single-segment files: jpeg_huff_spec_kernel)
+    const uint8_t* p = jpg + offsets[img];
+    build_tables(L, J, p, lane, qtab + img * 64);
     const uint32_t mcu_w = 8u * J.hmax, mcu_h = 8u * J.vmax;
     const uint32_t mx = (width + mcu_w - 1) / mcu_w, my = (height + mcu_h - 1) / mcu_h, total_mcu = mx * my;
     const uint32_t per = J.restart ? J.restart : total_mcu;
@@ -424,6 +436,292 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
         if (__ballot(err)) bad = true;
     }
     if (bad && lane == 0) info[img].status = UCFP_IMAGE_NEEDS_HOST;
+}
+
+
+// ---- files without restart markers: ONE segment, decoded by 64 lanes at once -------------------------------------------
+// Huffman decoding is serial in the bit stream; what a wave can add is SPECULATION, as in the PNG front end.  The segment
+// is cut into 64 subsequences of S bits.  A decoder's state at a symbol boundary is (bit position, block b of the MCU,
+// coefficient index k).  A JPEG stream re-synchronises itself: a parse begun at a wrong bit falls into step with the true
+// code boundaries within a few dozen symbols and, at the next end-of-block, with the true coefficient index.  It does NOT
+// find the block PHASE b by itself (which of the MCU's B blocks -- hence which Huffman tables -- comes next), and a parse in
+// the wrong phase never settles (measured: a chain that only guessed phase 0 needed one round per lane, 3 x slower than the
+// serial decode).  So:
+//   round 0   lane i parses the LAST kSpecTail bits of its subsequence B times, once per phase h, from (start, h, k = 0):
+//             B candidate exit states, one of which is (almost always) the state the true parse leaves the subsequence with;
+//   round 1   lane i parses its whole subsequence from EACH candidate exit of lane i - 1;
+//   walk      lane 0's entry is known; following the chain -- "my true entry is my predecessor's true exit: look up what I
+//             left with when I entered like that" -- is 64 table look-ups; a miss (a true entry nobody guessed) is repaired
+//             by one more parse of that lane;
+//   decode    every lane decodes its subsequence for real from its true entry: coefficients of luma blocks go straight to
+//             the (zeroed) coefficient plane -- a block cut by a subsequence boundary is simply written by two lanes -- with
+//             the DC DIFFERENCE in place 0; block numbers come from a prefix sum of the lanes' completed-block counts; a
+//             last pass turns the differences into DC values (prefix sum in decoding order).
+// About B + B/3 + 1 parses of 1/64 of the stream instead of one of all of it.  The symbol step is written without
+// data-dependent branches (DC / AC, run / end-of-block / ZRL are selects): 64 lanes on 64 pieces of the stream would
+// otherwise take turns.  The bit stream is read from global memory one dword ahead (no staging buffer), which keeps the
+// kernel at 20 KiB of LDS -- eight waves per CU; a first version with a 32 KiB stage and 12-bit tables ran two.
+constexpr uint32_t kSpecMaxB = 6;                        // blocks per MCU this path takes (4:2:0 and 4:1:1 have 6)
+constexpr uint32_t kSpecTail = 768;                      // bits of a subsequence the phase guesses of round 0 parse
+
+__device__ __forceinline__ uint32_t jpeg_blocks_per_mcu(const JpgInfo& J) {
+    return J.ncomp == 1 ? 1u : (uint32_t)J.hs[0] * J.vs[0] + (uint32_t)J.hs[1] * J.vs[1] + (uint32_t)J.hs[2] * J.vs[2];
+}
+__device__ __forceinline__ bool jpeg_takes_spec(const JpgInfo& J) {
+    return J.nseg == 1 && J.restart == 0 && J.clean_len >= 512 && jpeg_blocks_per_mcu(J) <= kSpecMaxB;
+}
+
+struct SpecCand {
+    uint32_t pos;
+    uint16_t b, k;
+    uint32_t done;
+};
+struct SpecLds : HuffTables {
+    uint8_t comp_of[8], ybi_of[8];                       // block of the MCU -> component, index among the luma blocks
+    SpecCand c0[64][kSpecMaxB];                          // round 0: a lane's exit for each guessed block phase
+    SpecCand m1[64][kSpecMaxB];                          // round 1: a lane's exit when entered with its predecessor's j-th exit
+    SpecCand tin[64];                                    // the walk: every lane's TRUE entry (done: its blocks completed)
+};
+
+struct SpecState {
+    uint32_t pos;       // bit position (from the segment's first bit) of the next symbol
+    uint32_t b, k;      // block of the MCU, coefficient index (0: a DC code comes next)
+};
+
+// One subsequence: symbols that BEGIN before end_bit, from the state st.  OUT = false: states only (the speculation
+// rounds); OUT = true: coefficients of luma blocks are stored as well.
+template <bool OUT>
+__device__ __forceinline__ void spec_run(const SpecLds& L, const uint32_t* __restrict__ cw, SpecState st, uint32_t end_bit,
+                                         uint32_t data_bits, uint32_t B, uint32_t hs0, uint32_t hmax, uint32_t vmax, uint32_t mx,
+                                         uint32_t bxp, uint32_t blk_abs, uint32_t blk_total, int16_t* __restrict__ cplane,
+                                         SpecState& out, uint32_t& done, bool& err) {
+    // bit window: acc holds `cnt` valid bits at its top, wn = the next dword to append, nxt = that dword, in flight (raw:
+    // swapping its bytes right behind the load would make the wave wait for it there)
+    uint32_t wn = st.pos >> 5;
+    uint64_t acc = ((uint64_t)__builtin_bswap32(cw[wn]) << 32 | __builtin_bswap32(cw[wn + 1])) << (st.pos & 31u);
+    int cnt = 64 - (int)(st.pos & 31u);
+    wn += 2;
+    uint32_t nxt = cw[wn];
+    uint32_t b = st.b, k = st.k, c = L.comp_of[b];
+    done = 0;
+    err = false;
+    int16_t* dst = nullptr;                 // OUT: the luma block being filled (null: a chroma block)
+    auto locate = [&]() {
+        if (!OUT) return;
+        dst = nullptr;
+        if (c == 0) {
+            const uint32_t m = blk_abs / B;
+            const uint32_t bi = L.ybi_of[b];
+            const uint32_t bx = (m % mx) * hmax + bi % hs0, by = (m / mx) * vmax + bi / hs0;
+            dst = cplane + ((size_t)by * bxp + bx) * 64;
+        }
+    };
+    locate();
+    for (;;) {
+        const uint32_t pos = wn * 32u - (uint32_t)cnt;
+        if (pos >= end_bit || (OUT && blk_abs >= blk_total)) {
+            out.pos = pos;
+            break;
+        }
+        if (cnt <= 32) {                    // afterwards cnt >= 33: a code (<= 16 bits) and its value bits (<= 11) fit
+            acc |= (uint64_t)__builtin_bswap32(nxt) << (32 - cnt);
+            cnt += 32;
+            nxt = cw[++wn];
+        }
+        const bool isdc = k == 0;
+        const uint32_t sl = isdc ? c : 3u + c;
+        uint32_t e = L.look[sl][(uint32_t)(acc >> 55)];
+        if (e == 0) {                       // a code of more than 9 bits
+            const uint32_t top = (uint32_t)(acc >> 48);
+            int l = 10;
+            while (l <= 16 && (int)(top >> (16 - l)) > L.maxcode[sl][l]) l++;
+            if (l > 16) { err = true; break; }
+            e = (uint32_t)l << 8 | L.vals[sl][(int)(top >> (16 - l)) + L.valoff[sl][l]];
+        }
+        const uint32_t nb = e >> 8, sym = e & 255u;
+        acc <<= nb;
+        const uint32_t sz = isdc ? sym : (sym & 15u), r = isdc ? 0u : sym >> 4;
+        int v = 0;
+        if (OUT) {
+            const int raw = (int)((acc >> 32) >> (32 - sz));          // sz = 0: the shift by 32 of a 32-bit value would be undefined
+            v = sz == 0 ? 0 : (raw < (1 << (sz - 1)) ? raw - (1 << sz) + 1 : raw);
+        }
+        acc <<= sz;
+        cnt -= (int)(nb + sz);
+        const uint32_t kt = k + r;                                    // where an AC coefficient lands
+        const uint32_t kn = isdc ? 1u : sz ? kt + 1u : (r == 15u ? k + 16u : 64u);
+        if (kn > 64u || sz > (isdc ? 11u : 10u)) { err = true; break; }
+        if (OUT) {
+            if (dst && (isdc || sz)) dst[isdc ? 0u : (uint32_t)L.zz[kt]] = (int16_t)v;
+            if (wn * 32u - (uint32_t)cnt > data_bits) { err = true; break; }          // the symbol read past the data
+        }
+        k = kn;
+        if (k >= 64u) {
+            k = 0;
+            b = b + 1 == B ? 0 : b + 1;
+            c = L.comp_of[b];
+            done++;
+            blk_abs++;
+            locate();
+        }
+    }
+    out.b = b;
+    out.k = k;
+    if (err) out.pos = 0xffffffffu;        // (a speculative parse that ran into nonsense: a state no true parse has)
+}
+
+__global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
+                                                           uint32_t width, uint32_t height, const uint8_t* __restrict__ clean,
+                                                           JpgInfo* __restrict__ info, int16_t* __restrict__ coef, size_t coef_stride,
+                                                           uint32_t bxp, uint16_t* __restrict__ qtab) {
+    __shared__ SpecLds L;
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    const JpgInfo J = info[img];
+    if (J.status != 0 || !jpeg_takes_spec(J)) return;
+    const uint8_t* p = jpg + offsets[img];
+    build_tables(L, J, p, lane, qtab + img * 64);
+    const uint32_t nby = J.ncomp == 1 ? 1u : (uint32_t)J.hs[0] * J.vs[0];
+    const uint32_t nb1 = J.ncomp == 3 ? (uint32_t)J.hs[1] * J.vs[1] : 0u;
+    const uint32_t B = jpeg_blocks_per_mcu(J);
+    if (lane < (int)B) {
+        L.comp_of[lane] = (uint32_t)lane < nby ? 0 : (uint32_t)lane < nby + nb1 ? 1 : 2;
+        L.ybi_of[lane] = (uint8_t)lane;
+    }
+    const uint32_t hs0 = J.hs[0], hmax = J.hmax, vmax = J.vmax;
+    const uint32_t mx = (width + 8u * hmax - 1) / (8u * hmax), my = (height + 8u * vmax - 1) / (8u * vmax);
+    const uint32_t blk_total = mx * my * B;               // (<= 2048 x 2048 MCUs x 6 blocks)
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(clean + ((offsets[img] + 15) & ~(uint64_t)15));
+    int16_t* cplane = coef + img * coef_stride;
+    // the luma blocks' coefficients not written below are zero
+    for (size_t i = (size_t)lane * 8; i < coef_stride; i += 64 * 8) *reinterpret_cast<uint4*>(cplane + i) = make_uint4(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t data_bits = J.clean_len * 8;
+    uint32_t S = (data_bits + 63) / 64;
+    S = (S + 31) & ~31u;
+    const uint32_t my0 = (uint32_t)lane * S, my1 = my0 + S < data_bits ? my0 + S : data_bits;
+    const bool live = my0 < data_bits;
+    const uint32_t last = (data_bits + S - 1) / S - 1;    // the last live lane
+    SpecState exit_ = {my1, 0, 0};
+    uint32_t done = 0;
+    bool err = false;
+    auto put = [&](SpecCand& c, const SpecState& e, uint32_t dn) {
+        c.pos = e.pos;
+        c.b = (uint16_t)e.b;
+        c.k = (uint16_t)e.k;
+        c.done = dn;
+    };
+    auto run0 = [&](const SpecState& en) {
+        spec_run<false>(L, cw, en, my1, data_bits, B, hs0, hmax, vmax, mx, bxp, 0u, ~0u, nullptr, exit_, done, err);
+    };
+    wave_lds_sync();
+    // ---- round 0: every block phase, over the tail of the subsequence (lane 0: its one true entry, the whole of it)
+    const uint32_t tail0 = my1 - my0 > kSpecTail ? my1 - kSpecTail : my0;
+    for (uint32_t h = 0; h < B; h++) {
+        if (live && (lane > 0 || h == 0)) {
+            const SpecState en = {lane == 0 ? 0u : tail0, lane == 0 ? 0u : h, 0u};
+            run0(en);
+            put(L.c0[lane][h], exit_, done);
+        }
+    }
+    if (lane == 0)
+        for (uint32_t h = 1; h < B; h++) L.c0[0][h] = L.c0[0][0];
+    wave_lds_sync();
+    // ---- round 1: the whole subsequence from each candidate exit of the predecessor
+    for (uint32_t jx = 0; jx < B; jx++) {
+        if (live && lane > 0) {
+            const SpecCand pc = L.c0[lane - 1][jx];
+            SpecCand res = {0xffffffffu, 0, 0, 0};
+            if (pc.pos != 0xffffffffu && (jx == 0 || lane > 1)) {      // (lane 1's candidates are all lane 0's one exit)
+                const SpecState en = {pc.pos, pc.b, pc.k};
+                run0(en);
+                put(res, exit_, done);
+            }
+            L.m1[lane][jx] = res;
+        }
+    }
+    wave_lds_sync();
+    // ---- the walk (every lane runs it on the same LDS words: wave-uniform)
+    SpecCand t = L.c0[0][0];                                  // lane 0's true exit
+    if (lane == 0) L.tin[0] = SpecCand{0u, 0, 0, t.done};
+    bool bad = t.pos == 0xffffffffu;
+    for (uint32_t i = 1; i <= last && !bad; i++) {
+        // t = true exit of lane i - 1 = true entry of lane i
+        int hit = -1;
+        for (uint32_t jx = 0; jx < B; jx++) {
+            const SpecCand pc = L.c0[i - 1][jx];
+            if (hit < 0 && pc.pos == t.pos && pc.b == t.b && pc.k == t.k) hit = (int)jx;
+        }
+        if (i == 1) hit = 0;
+        SpecCand ex;
+        if (hit >= 0) {
+            ex = L.m1[i][hit];
+        } else {
+            // nobody guessed lane i's true entry: that lane parses once more
+            wave_lds_sync();
+            if ((uint32_t)lane == i) {
+                const SpecState en = {t.pos, t.b, t.k};
+                run0(en);
+                put(L.m1[i][0], exit_, done);
+            }
+            wave_lds_sync();
+            ex = L.m1[i][0];
+        }
+        if (lane == 0) L.tin[i] = SpecCand{t.pos, t.b, t.k, ex.done};
+        // the TRUE parse of lane i ran into an invalid code (the last lane may: it parses on into the padding bits -- its
+        // block count up to there is what matters, and the decode below stops at the last block)
+        if (ex.pos == 0xffffffffu && i != last) bad = true;
+        t = ex;                                               // ... and the true entry of lane i + 1
+    }
+    wave_lds_sync();
+    uint32_t blk_done = 0;
+    if (!bad) {
+        const SpecCand mine_in = L.tin[live ? lane : 0];
+        const SpecState entry = {mine_in.pos, mine_in.b, mine_in.k};
+        // ---- block numbers, then the real decode
+        uint32_t incl = live ? mine_in.done : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t my_abs = incl - (live ? mine_in.done : 0u);
+        uint32_t done2 = 0;
+        bool err2 = false;
+        SpecState ex2 = exit_;
+        if (live) spec_run<true>(L, cw, entry, my1, data_bits, B, hs0, hmax, vmax, mx, bxp, my_abs, blk_total, cplane, ex2, done2, err2);
+        if (__ballot(live && err2)) bad = true;
+        blk_done = (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    if (blk_done < blk_total) bad = true;                 // the data ended before the last block
+    if (bad) {
+        if (lane == 0) info[img].status = UCFP_IMAGE_NEEDS_HOST;
+        return;
+    }
+    // ---- DC differences -> DC values: prefix sum over the luma blocks in decoding order (MCU by MCU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t ny = mx * my * nby, run = (ny + 63) / 64;
+    auto addr_of = [&](uint32_t o) -> int16_t* {
+        const uint32_t m = o / nby, bi = o % nby;
+        const uint32_t bx = (m % mx) * hmax + bi % hs0, by = (m / mx) * vmax + bi / hs0;
+        return cplane + ((size_t)by * bxp + bx) * 64;
+    };
+    const uint32_t o0 = (uint32_t)lane * run, o1 = o0 + run < ny ? o0 + run : ny;
+    int sum = 0;
+    for (uint32_t o = o0; o < o1; o++) sum += addr_of(o)[0];
+    int incl2 = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl2, off, 64);
+        if (lane >= off) incl2 += v;
+    }
+    int acc_dc = incl2 - sum;
+    for (uint32_t o = o0; o < o1; o++) {
+        int16_t* a = addr_of(o);
+        acc_dc += a[0];
+        a[0] = (int16_t)acc_dc;
+    }
 }
 
 // ---- inverse DCT: one thread per luma block of the batch ----
@@ -584,6 +882,8 @@ int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, ui
                        seg, info);
     hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h, l.max_seg,
                        (const uint8_t*)(ws + l.clean), (const uint32_t*)seg, info, coef, l.coef_stride, l.bxp, qtab);
+    hipLaunchKernelGGL(jpeg_huff_spec_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h,
+                       (const uint8_t*)(ws + l.clean), info, coef, l.coef_stride, l.bxp, qtab);
     const size_t blocks = n * (size_t)l.bxp * l.byp;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, stream, (const JpgInfo*)info, n, w, h,
                        (const int16_t*)coef, l.coef_stride, l.bxp, l.byp, (const uint16_t*)qtab, frames, row_stride,

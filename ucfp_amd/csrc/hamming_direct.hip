@@ -515,6 +515,14 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
     const uint32_t E = G * k, total = nq * E;
     constexpr uint32_t kT = kDW * 64, kB = 8;
     if (threadIdx.x < nq) V.m[threadIdx.x] = 0;
+    // the first batch of published distances is requested BEFORE d* is known (it does not depend on it): the histogram's
+    // round trip and the lists' are one
+    uint32_t v0[kB];
+#pragma unroll
+    for (uint32_t u = 0; u < kB; u++) {
+        const uint32_t x = u * kT + threadIdx.x;
+        v0[u] = UCFP_AGENT_LOAD(wg_d + (x < total ? x : 0u));
+    }
     if (wave < nq) {
         uint32_t incl = UCFP_AGENT_LOAD(ghist + wave * 80 + lane);
         UCFP_AGENT_STORE(ghist + wave * 80 + lane, 0u);          // zero again for the next launch (bin 64 is never written)
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
 #pragma unroll
         for (uint32_t u = 0; u < kB; u++) {      // unconditional, so that the eight loads are ONE round trip
             const uint32_t x = b0 + u * kT + threadIdx.x;
-            v[u] = UCFP_AGENT_LOAD(wg_d + (x < total ? x : 0u));
+            v[u] = b0 == 0 ? v0[u] : UCFP_AGENT_LOAD(wg_d + (x < total ? x : 0u));
         }
 #pragma unroll
         for (uint32_t u = 0; u < kB; u++) {

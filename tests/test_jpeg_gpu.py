@@ -86,6 +86,25 @@ def test_files_handed_to_the_host_and_damaged_ones(gpu_ctx, oracle):
     assert list(st3) == [0, 1, 0] and not rec[1].any() and np.array_equal(rec[0], rec[2])
 
 
+def test_stray_bytes_behind_the_last_block_are_ignored(gpu_ctx, oracle):
+    """Found by tools/soak_jpeg.py: once the image's last block is decoded, what follows in the scan (stray bytes in front of
+    EOI; the tail of a stream whose bit flip made blocks end early) is nobody's business -- a sequential decoder stops there,
+    and so must the speculative one (its later lanes parse that junk and may well run into invalid codes)."""
+    from ucfp_amd import image
+    rng = np.random.default_rng(6)
+    files = []
+    for i in range(12):
+        f = jpeg_of(picture(96, 80, seed=i), quality=(40, 85, 97)[i % 3], subsampling=i % 3)
+        junk = bytes(int(x) for x in rng.integers(0, 255, int(rng.integers(30, 900))))     # no 0xFF: no markers
+        files.append(f[:-2] + junk + f[-2:])
+    fr, st = image.decode_jpegs(files, 80, 96, ctx=gpu_ctx)
+    assert not st.any(), st
+    for i, f in enumerate(files):
+        rc, px = oracle.jpeg_decode_luma(f)
+        assert rc == 0 and np.array_equal(fr[i], px), i
+        assert np.array_equal(fr[i], libjpeg_luma(f)), i
+
+
 def test_randomly_damaged_files_never_hang_and_agree_with_the_oracle(gpu_ctx, oracle):
     """300 corruptions of valid files (bit flips in the entropy-coded data, truncations, garbage runs, stray markers): a
     status for every file, equal to the oracle's; where both decode, the same pixels."""

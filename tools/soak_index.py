@@ -34,8 +34,9 @@ def main():
         rounds += 1
         if rounds % 2:
             n = int(rng.choice([300, 5000, 70_000, 300_000, 1_200_000, 3_000_000]))
-            nq = int(rng.choice([1, 3, 17, 64, 65, 200, 700, 2049, 4096]))
-            k = int(rng.choice([1, 5, 10, 16, 17, 50]))
+            # (1 .. 8 queries with k <= 32 take the single-launch search of round 3, hamming_direct.hip)
+            nq = int(rng.choice([1, 1, 2, 3, 5, 8, 8, 17, 64, 65, 200, 700, 2049, 4096]))
+            k = int(rng.choice([1, 5, 10, 16, 17, 32, 50]))
             g = torch.Generator(device=dev)
             g.manual_seed(int(rng.integers(1 << 30)))
             codes = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, generator=g)
@@ -44,6 +45,8 @@ def main():
                 near = c[torch.randint(0, 8, (n // 2,), device=dev, generator=g)]
                 near = near ^ (torch.ones_like(near) << torch.randint(0, 63, (n // 2,), device=dev, generator=g))
                 codes[: n // 2] = near
+            if rng.random() < 0.15:    # a corpus of a few distinct codes: every distance ties, the id order decides
+                codes = codes[torch.randint(0, n, (4,), device=dev, generator=g)][torch.randint(0, 4, (n,), device=dev, generator=g)]
             ids = torch.randperm(n, device=dev, generator=g).to(torch.int64)
             if rng.random() < 0.5:     # ids ascending with the row: the stages after the first filter strictly (hamming_list_tau)
                 ids = torch.sort(ids * 3 + 1).values

@@ -645,8 +645,15 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
     // ---- the walk (every lane runs it on the same LDS words: wave-uniform)
     SpecCand t = L.c0[0][0];                                  // lane 0's true exit
     if (lane == 0) L.tin[0] = SpecCand{0u, 0, 0, t.done};
-    bool bad = t.pos == 0xffffffffu;
+    uint32_t cum = t.done;                                    // blocks completed by the lanes walked so far
+    bool bad = t.pos == 0xffffffffu && cum < blk_total;
     for (uint32_t i = 1; i <= last && !bad; i++) {
+        if (cum >= blk_total) {
+            // the image is complete: what follows (padding bits, stray bytes in front of EOI) is nobody's business -- a
+            // sequential decoder stops after the last block too
+            if (lane == 0) L.tin[i] = SpecCand{0u, 0, 0, 0u};
+            continue;
+        }
         // t = true exit of lane i - 1 = true entry of lane i
         int hit = -1;
         for (uint32_t jx = 0; jx < B; jx++) {
@@ -669,9 +676,9 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
             ex = L.m1[i][0];
         }
         if (lane == 0) L.tin[i] = SpecCand{t.pos, t.b, t.k, ex.done};
-        // the TRUE parse of lane i ran into an invalid code (the last lane may: it parses on into the padding bits -- its
-        // block count up to there is what matters, and the decode below stops at the last block)
-        if (ex.pos == 0xffffffffu && i != last) bad = true;
+        cum += ex.done;
+        // the TRUE parse of lane i ran into an invalid code before the image was complete: irregular data (J3)
+        if (ex.pos == 0xffffffffu && cum < blk_total) bad = true;
         t = ex;                                               // ... and the true entry of lane i + 1
     }
     wave_lds_sync();

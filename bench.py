@@ -1130,8 +1130,27 @@ def bench_audio(args, rank, world, dev, ctx):
     return res
 
 
+_LINE_FD = None
+
+
+def emit_line(res):
+    """The ONE JSON line goes to the process's original stdout; everything else written to fd 1 while the bench runs
+    (RCCL prints a version banner there when a communicator is created) has been sent to stderr by main()."""
+    data = (json.dumps(res) + "\n").encode()
+    if _LINE_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, data)
+
+
 def main():
+    global _LINE_FD
     args = parse()
+    # keep stdout to exactly one line: native libraries (RCCL's init banner) write to fd 1 directly
+    sys.stdout.flush()
+    _LINE_FD = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1313,7 +1332,7 @@ def main():
             if rank == 0 and res is not None:
                 res["watchdog"] = ("a secondary leg did not finish within 600 s at N > 1; the line carries what was "
                                    "measured before it")
-                print(json.dumps(res), flush=True)
+                emit_line(res)
             os._exit(3)      # non-zero: the driver must record the hang, not a success
         watchdog = threading.Timer(600.0, _fire)
         watchdog.daemon = True
@@ -1353,7 +1372,7 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

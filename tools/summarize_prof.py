@@ -40,12 +40,14 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
-    shutil.copy(os.path.join(src, "bench_n1_full.json"), os.path.join(dst, "bench_n1_full.json"))
+    # keep only the bench's JSON line (RCCL's init banner used to land on stdout before bench.py sent fd 1 to stderr)
+    line = [l for l in open(os.path.join(src, "bench_n1_full.json")) if l.startswith("{")][-1]
+    open(os.path.join(dst, "bench_n1_full.json"), "w").write(line)
     shutil.copy(one(os.path.join(src, "stats_full", "**", "*_kernel_stats.csv")),
                 os.path.join(dst, "full_bench_kernel_stats.csv"))
     shutil.copy(one(os.path.join(src, "stats_image", "**", "*_kernel_stats.csv")),
                 os.path.join(dst, "image_multi_kernel_stats.csv"))
-    bench = json.load(open(os.path.join(src, "bench_n1_full.json")))
+    bench = json.loads(line)
     frames = bench["config"]["frames_per_gpu"]
     fetch, fm = counter(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
     write, wm = counter(os.path.join(src, "pmc_write"), "WRITE_SIZE")

@@ -757,3 +757,36 @@ def test_hamming_strict_thresholds_with_overflowing_lists(gpu_ctx, oracle, nq):
         o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
         assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids), k
     ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [262_144, 400_000, 524_288, 524_289, 524_288 + 127, 2_200_000])
+def test_hamming_bound_pass_edges(gpu_ctx, oracle, n):
+    """Batches on the matrix-core filter take their first thresholds from hamming_bound_mfma: the k-th smallest of 256
+    group minima over the first min(n, 2^19) & ~127 codes.  Edges: corpora that END on the bound range (one stage that
+    starts over at row 0), one row and one partial step behind it; k at and above the pass's limit (k <= 64, above it the
+    sample histogram); the best neighbours all inside ONE group (the bound then comes from the other groups); the
+    all-ones query (filtered one bit off, bound one wider); codes behind the bound range that beat everything in it."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(n % 9973)
+    nq = 96
+    codes = rng.integers(0, 2**64, n, dtype=np.uint64)
+    q = rng.integers(0, 2**64, nq, dtype=np.uint64)
+    q[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    q[1] = np.uint64(0)
+    for j in range(2, 40):                                    # 30 close neighbours of query j in consecutive rows (one group)
+        at = int(rng.integers(0, min(n, 524_288) - 64))
+        for i in range(30):
+            codes[at + i] = q[j] ^ (np.uint64(1) << np.uint64(i))
+    for j in range(40, 60):                                   # the best ones sit in the LAST rows (behind the bound range if any)
+        codes[n - 1 - (j - 40) * 3] = q[j] ^ np.uint64(3)
+    codes[n - 1] = q[0]
+    ids = rng.permutation(n).astype(np.uint64)
+    for flags, the_ids in ((0, ids), (index.APPEND_ONLY, np.arange(n, dtype=np.uint64) * 3 + 1)):
+        ix = index.DeviceIndex(index.HAMMING64, 0, flags, gpu_ctx)
+        ix.upsert(0, the_ids, codes)
+        for k in (1, 10, 64, 65):
+            g_ids, _, g_d, g_c = ix.search(0, q, k)
+            o_ids, o_d, o_c = oracle.hamming_topk(the_ids, codes, q, k)
+            assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids), (n, flags, k)
+        ix.close()

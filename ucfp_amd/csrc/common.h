@@ -71,6 +71,8 @@ struct HammingPlan {
     size_t robust_n = 0;        // robust tier covers [0, robust_n): everything when `fast` is off, nothing when on
     uint32_t slices = 0;        // robust tier: one wave per (slice, qgroup)
     size_t per_slice = 0;
+    bool bound = false;         // first bound from the matrix-core bound pass over [0, bound_n) instead of the sample histogram
+    size_t bound_n = 0;
     bool fast = false;          // matrix-core filter in stages over [0, stage_end[0]), [stage_end[0], stage_end[1]), ...
     uint32_t nstages = 0;
     size_t stage_end[12] = {0};

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -552,6 +553,160 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     if (lane == 0) log_cnt[slice] = ln < log_cap ? ln : log_cap;
 }
 
+// ---- bound pass: the first upper bounds from the matrix cores ----------------------------------
+// The k-th smallest of the minima of G disjoint groups of codes is an upper bound on the k-th smallest distance of their
+// union (the k groups below it each hold a code at least that close), and with G = 256 >> k it is the k-th distance itself
+// or its neighbour.  So the filter's own loop -- same operands, same packed fold -- run WITHOUT thresholds over the first
+// 512 k codes, keeping per (workgroup, query) the largest sum, yields in one launch at the matrix rate what the sample
+// histogram (popcounts, 3 T pairs/s) plus two stages of filter / rescan / list threshold used to approach step by step.
+// The fold's per-lane maximum goes to LDS with ds_max_u32 ([tile][query]; both 16-row halves of a query hit the same
+// word, which also merges them); the workgroup's row of the table is d'(q) = popc(fq) - max sum, 255 for "no code seen".
+#define UCFP_FOLD_PAIR_BOUND                                                                             \
+    "v_pk_maximum3_f16 %1, %5, %6, %7\n\t"                                                               \
+    "v_pk_maximum3_f16 %1, %1, %8, %9\n\t"                                                               \
+    "v_pk_maximum3_f16 %1, %1, %10, %11\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %12, %13\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %14, %15\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %16, %17\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %18, %19\n\t"                                                             \
+    "v_pk_maximum3_f16 %1, %1, %20, %20\n\t"                                                             \
+    "v_mfma_f32_32x32x64_f8f6f4 %0, %3, %4, %21 cbsz:4 blgp:4\n\t"                                       \
+    "v_pk_maximum3_f16 %2, %1, %25, %25\n\t"                                                             \
+    "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %22, %4, %0, %23, %24 op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\t"     \
+    "s_nop 0"
+
+__global__ __launch_bounds__(kMW * 64) void hamming_bound_mfma(
+    const uint64_t* __restrict__ codes, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
+    const i32x4* __restrict__ qimg, uint8_t* __restrict__ table, uint32_t table_stride) {
+    const uint32_t nthreads = blockDim.x, mw = nthreads >> 6;
+    extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
+    const uint32_t q0 = blockIdx.y * kQP;
+    const uint32_t nqp = nq - q0 < (uint32_t)kQP ? nq - q0 : (uint32_t)kQP;
+    const uint32_t ntiles = (nqp + 31) / 32;
+    i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
+    // [1 + tile][32]: largest (1088 + sum) seen for the query; row 0 takes the fold of "tile -1" (pipeline fill); 0 = nothing seen
+    uint32_t* MX = reinterpret_cast<uint32_t*>(mf_lds + (size_t)(ntiles + 2) * 1024);
+    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += nthreads * 8) {
+        i32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t s = s0 + u * nthreads;
+            v[u] = s < ntiles * 64 ? qimg[(size_t)(q0 / 32) * 64 + s] : i32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t s = s0 + u * nthreads;
+            if (s < (ntiles + 2) * 64) QB[s] = v[u];
+        }
+    }
+    for (uint32_t s = threadIdx.x; s < (ntiles + 2) * 32; s += nthreads) MX[s] = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int nn = lane & 31, hh = lane >> 5;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t gwave = (size_t)blockIdx.x * mw + wv, nwaves = (size_t)gridDim.x * mw;
+    const size_t nsuper = end / kStep;   // whole steps only (the launcher rounds `end` down): a phantom zero code would fake a minimum
+    const uint32_t* __restrict__ halves = reinterpret_cast<const uint32_t*>(codes);
+    auto load_codes = [&](uint32_t (&x)[kTB], size_t st) {
+#pragma unroll
+        for (int b = 0; b < kTB; b++) {
+            const size_t row = st * kStep + 32 * b + nn;
+            x[b] = st < nsuper ? __builtin_nontemporal_load(halves + row * 2 + hh) : 0u;
+        }
+    };
+    f32x16 D[kTB / 2];
+#pragma unroll
+    for (int p = 0; p < kTB / 2; p++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) D[p][e] = 0.f;
+    f32x16 cc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) cc[e] = 8388608.f + 4194304.f + (float)kFieldLo;
+    asm volatile("" : "+v"(cc));
+    const int sa = 127 + 16, sb = 127;
+    uint32_t x[kTB];
+    load_codes(x, gwave);
+    for (size_t st = gwave; st < nsuper; st += nwaves) {
+        i32x4 A[kTB];
+#pragma unroll
+        for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(x[b]);
+        load_codes(x, st + nwaves);
+        // as in hamming_scan_mfma: the fold inside step t covers query tile t - 1
+        auto step = [&](uint32_t t, const i32x4& bq, i32x4& nq_) {
+            uint32_t m01, m23, vs;
+            asm volatile(UCFP_FOLD_PAIR : "+v"(D[0]), "=&v"(m01) : UCFP_FOLD_PAIR_IN(0) : "memory");
+            nq_ = QB[(t + 1) * 64 + lane];
+            asm volatile(UCFP_FOLD_PAIR_BOUND
+                         : "+v"(D[1]), "=&v"(m23), "=&v"(vs)
+                         : UCFP_FOLD_PAIR_IN(1), "v"(m01)
+                         : "memory");
+            // fields: high = (0x4B00 + 64) + max sum of tiles 1 / 3, low = 1088 + max sum of tiles 0 / 2
+            const uint32_t lo = vs & 0xffffu, hi = (vs >> 16) - (kFieldHi - kFieldLo);
+            atomicMax(&MX[t * 32 + nn], lo > hi ? lo : hi);
+        };
+        i32x4 p = QB[lane], r;
+        uint32_t t = 0;
+        for (; t + 2 <= ntiles + 1; t += 2) {
+            step(t, p, r);
+            step(t + 1, r, p);
+        }
+        if (t < ntiles + 1) step(t, p, r);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < ntiles * 32; s += nthreads) {
+        const uint32_t q = q0 + s;
+        if (q >= nq) continue;
+        uint32_t slack;
+        const uint64_t fq = filter_query(queries[q], slack);
+        const uint32_t m = MX[32 + s];
+        table[(size_t)blockIdx.x * table_stride + q] = m ? (uint8_t)((uint32_t)__popcll(fq) + kFieldLo - m) : (uint8_t)255;
+    }
+}
+
+// k-th smallest group minimum per query (+ the filter query's slack) -> tau0; empties the candidate lists and the
+// overflow flag like hamming_tau0.  Block = 4 waves x 64 queries; the waves split the table's rows.
+__global__ __launch_bounds__(256) void hamming_bound_tau(const uint8_t* __restrict__ table, uint32_t groups,
+                                                         uint32_t table_stride, const uint64_t* __restrict__ queries,
+                                                         uint32_t nq, uint32_t k, uint32_t* __restrict__ tau0,
+                                                         uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t h[65 * kWave];   // [bin][query lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * kWave + lane;
+    for (int b = threadIdx.x; b < 65 * kWave; b += 256) h[b] = 0;
+    __syncthreads();
+    const uint32_t qc = q < nq ? q : nq - 1;
+    for (uint32_t g0 = wave; g0 < groups; g0 += 4 * 16) {
+        uint32_t d[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const uint32_t g = g0 + 4 * u;
+            d[u] = g < groups ? table[(size_t)g * table_stride + qc] : 255u;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (d[u] <= 64u) atomicAdd(&h[d[u] * kWave + lane], 1u);
+    }
+    __syncthreads();
+    if (wave != 0 || q >= nq) return;
+    uint32_t cum = 0, t = 64;
+    bool done = false;
+    for (int b = 0; b < 65; b++) {
+        cum += h[b * kWave + lane];
+        if (!done && cum >= k) {
+            t = b;
+            done = true;
+        }
+    }
+    uint32_t slack;
+    (void)filter_query(queries[q], slack);
+    t += slack;   // d(q, x) <= d(fq, x) + slack
+    tau0[q] = t < 64u ? t : 64u;
+    cand_cnt[q] = 0;
+    if (q == 0) *overflow = 0;
+}
+
 // gridDim.y blocks per log slice, one lane per (record, code tile): exact distances for the flagged (query, 16 results) lanes;
 // true candidates are appended to the per-query lists.
 __global__ __launch_bounds__(256) void hamming_rescan(
@@ -880,6 +1035,10 @@ int launch_ids_order_update(const uint64_t* ids, size_t n, bool first, uint32_t*
     return 0;
 }
 
+static bool few_queries(size_t n, uint32_t nq);
+constexpr uint32_t kBoundGroups = 256;        // workgroups of the bound pass = groups of codes whose minima bound the k-th distance
+constexpr size_t kBoundCodes = (size_t)1 << 19;   // codes the bound pass covers (measured against 2^18 and 2^20)
+
 HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     HammingPlan p;
     p.qgroups = (nq + kWave - 1) / kWave;
@@ -897,16 +1056,21 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     // admits ~ c k 4 candidates per query (c <= ~5: the boundary distance bin is fat)
     p.fast = n >= (size_t)1 << 18 && n - 1 <= 0xfffffff0u;
     p.robust_n = n;
+    // batches on the matrix-core filter take their first bound from the filter itself (hamming_bound_mfma): the k-th
+    // smallest of 256 group minima over the first 512 k codes -- as tight as two stages of lists used to make it
+    p.bound = p.fast && !few_queries(n, nq) && k <= 64 && !getenv("UCFP_HAMMING_NO_BOUND");
+    if (p.bound) p.bound_n = (n < kBoundCodes ? n : kBoundCodes) & ~(size_t)(128 - 1);
     if (p.fast) {
-        size_t e = p.sample_n;
+        size_t e = p.bound ? p.bound_n : p.sample_n;
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
         // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs; the same
         // for batches of 9 .. 256 queries, where 16x measured 5-20 % slower)
         constexpr size_t growth = 4;
-        while (e < n && p.nstages < 12) {
+        // (with the bound pass the first stage starts over at row 0, so there is one even when bound_n == n)
+        do {
             e = e * growth < n ? e * growth : n;
             p.stage_end[p.nstages++] = e;
-        }
+        } while (e < n && p.nstages < 12);
         p.stage_end[p.nstages - 1] = n;
         p.robust_n = 0;
         size_t cc = (size_t)k * growth * 5 * p.nstages * 2;   // 2x headroom
@@ -923,13 +1087,14 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
 
 namespace {
 struct HammingWs {
-    size_t hist, tau0, part_ids, part_d, part_cnt, tau1, tau2, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, qimg, total;
+    size_t btab, hist, tau0, part_ids, part_d, part_cnt, tau1, tau2, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, qimg, total;
 };
 HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     HammingWs w;
     size_t off = 0;
     const uint32_t ms = p.slices > p.fb_slices ? p.slices : p.fb_slices;
+    w.btab = off;      off = align(off + (p.bound ? (size_t)kBoundGroups * p.qgroups * kWave : 0));
     w.hist = off;      off = align(off + (size_t)(p.sample_parts ? p.sample_parts : 1) * 65 * p.qgroups * kWave * 4);
     w.tau0 = off;      off = align(off + (size_t)nq * 4);
     w.part_ids = off;  off = align(off + (size_t)ms * nq * k * 8);
@@ -981,9 +1146,24 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                                (size_t)nq * k, out_scores);
         return 0;
     }
-    // tau0 from the sample
+    // tau0: from the bound pass (matrix-core batches), else from the sample
     const bool few = few_queries(n, nq);
-    if (few) {
+    i32x4* qimg = reinterpret_cast<i32x4*>(ws + w.qimg);
+    if (p.bound) {
+        const size_t lds = hamming_mfma_lds_bytes(nq);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_bound_mfma),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 64 + 255) / 256), dim3(256), 0, stream, queries,
+                           nq, qimg);
+        const size_t steps = p.bound_n / kStep;
+        unsigned mw = steps >= (size_t)kBoundGroups * kMW ? kMW : steps >= (size_t)kBoundGroups * 8 ? 8 : 4;
+        const uint32_t stride = p.qgroups * kWave;
+        hipLaunchKernelGGL(hamming_bound_mfma, dim3(kBoundGroups, (nq + kQP - 1) / kQP), dim3(mw * 64), lds, stream, codes,
+                           p.bound_n, queries, nq, (const i32x4*)qimg, ws + w.btab, stride);
+        hipLaunchKernelGGL(hamming_bound_tau, dim3(p.qgroups), dim3(256), 0, stream, (const uint8_t*)(ws + w.btab),
+                           kBoundGroups, stride, queries, nq, k, u32(w.tau0), u32(w.cand_cnt), u32(w.overflow));
+    } else if (few) {
         (void)hipMemsetAsync(u32(w.hist), 0, (size_t)nq * 65 * 4, stream);
         hipLaunchKernelGGL(hamming_sample_hist_lanes, dim3((unsigned)((p.sample_n + 1023) / 1024)), dim3(256), 0, stream,
                            codes, p.sample_n, queries, nq, u32(w.hist));
@@ -1011,8 +1191,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_scan_mfma),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        i32x4* qimg = reinterpret_cast<i32x4*>(ws + w.qimg);
-        if (!few)
+        if (!few && !p.bound)
             hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 64 + 255) / 256), dim3(256), 0, stream, queries,
                                nq, qimg);
         // stage thresholds alternate between tau1 and tau2: tau0 (the sample's, never strict) stays intact for the

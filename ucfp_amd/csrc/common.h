@@ -128,7 +128,8 @@ constexpr uint32_t kCosineListCap = 1024;   // candidates kept per query by the 
 // run_flag: optional device word; when non-null the merge only runs if it is non-zero
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts,
                           uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key,
-                          uint32_t* out_cnt, const uint32_t* run_flag, hipStream_t stream);
+                          uint32_t* out_cnt, const uint32_t* run_flag, hipStream_t stream,
+                          float* hamming_scores = nullptr);   // optional: 1 - key / 64 of the final keys, written even when run_flag is 0
 // wire format of the sharded search: 16-byte entries {id u64, key u32, pad u32}
 int launch_topk_pack_entries(const uint64_t* ids, const uint32_t* keys, size_t total, void* entries, hipStream_t stream);
 int launch_topk_merge_packed(const void* entries, uint32_t parts, uint32_t nq, uint32_t k, uint64_t* out_ids,

@@ -33,6 +33,11 @@
 namespace ucfp {
 
 constexpr int kWave = 64;
+// A query's candidate list is kSub sub-lists (slots [s cap / kSub, (s + 1) cap / kSub) of its cap slots, counter
+// cand_cnt[q kSub + s]); an append takes the sub-list of its workgroup's number.  ~80 appends per query in a first stage
+// are 80 atomics with return on ONE address otherwise, a dependent chain in the memory-side atomic unit (19 of the first
+// rescan's 38 us at 12.5 M x 4096).  (A 128-byte line per counter, by itself, measured no change.)
+constexpr uint32_t kSub = 8;
 
 __device__ __forceinline__ uint32_t hamming64(uint64_t q, uint64_t x) {
     const uint32_t lo = (uint32_t)q ^ (uint32_t)x;
@@ -93,7 +98,7 @@ __global__ void hamming_tau0(const uint32_t* __restrict__ hist, uint32_t nq, uin
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     if (cand_cnt) {
-        cand_cnt[q] = 0;
+        for (uint32_t u = 0; u < kSub; u++) cand_cnt[(size_t)q * kSub + u] = 0;
         if (q == 0) *overflow = 0;
     }
     uint32_t c[65];
@@ -703,77 +708,118 @@ __global__ __launch_bounds__(256) void hamming_bound_tau(const uint8_t* __restri
     (void)filter_query(queries[q], slack);
     t += slack;   // d(q, x) <= d(fq, x) + slack
     tau0[q] = t < 64u ? t : 64u;
-    cand_cnt[q] = 0;
+    for (uint32_t u = 0; u < kSub; u++) cand_cnt[(size_t)q * kSub + u] = 0;
     if (q == 0) *overflow = 0;
 }
 
-// gridDim.y blocks per log slice, one lane per (record, code tile): exact distances for the flagged (query, 16 results) lanes;
-// true candidates are appended to the per-query lists.
-__global__ __launch_bounds__(256) void hamming_rescan(
+// gridDim.y blocks per log slice.  Pass 1, one thread per record: its four tiles' ballots of flagged lanes are
+// flattened into an LDS queue of (query, first row) entries; pass 2, one thread per ENTRY: exact distances of the 16 codes
+// that lane folded, true candidates appended to the per-query lists.  (A thread that walks its own ballot makes the whole
+// wave wait for the longest ballot, one dependent chain of loads and an atomic round trip per flagged lane.)
+constexpr uint32_t kRescanQueue = 2048, kRescanThreads = 128;
+__global__ __launch_bounds__(kRescanThreads) __attribute__((amdgpu_waves_per_eu(8))) void hamming_rescan(
     const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t begin, size_t end,
     const uint64_t* __restrict__ queries, const uint32_t* __restrict__ tau, const uint4* __restrict__ log,
     const uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ cand_cnt,
     uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id, uint32_t cand_cap, uint32_t* __restrict__ overflow) {
+    __shared__ uint2 queue[kRescanQueue];
+    __shared__ uint32_t qn;
     const uint32_t cnt = log_cnt[blockIdx.x];
-    // one thread per (record, code tile): the record's header and that tile's lane ballot
-    for (uint32_t idx = blockIdx.y * 256 + threadIdx.x; idx < cnt * kTB; idx += gridDim.y * 256) {
-        const uint32_t rix = idx / kTB, b = idx % kTB;
-        const uint32_t* rec = reinterpret_cast<const uint32_t*>(log + ((size_t)blockIdx.x * log_cap + rix) * 3);
-        const uint2 ra = *reinterpret_cast<const uint2*>(rec);
-        const uint2 mk = *reinterpret_cast<const uint2*>(rec + 2 + 2 * b);
-        {
-            uint64_t mask = (uint64_t)mk.x | ((uint64_t)mk.y << 32);
+    const uint32_t sub = blockIdx.x % kSub, sub_cap = cand_cap / kSub;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    // one flagged lane: the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
+    auto evaluate = [&](uint32_t q, uint32_t off) {
+        const uint64_t qv = queries[q];
+        const uint32_t tq = tau[q];
+        const size_t row0 = begin + off;
+        uint64_t cv[16];
+        if (row0 + 28 <= end) {   // four groups of four consecutive codes: 16-byte loads (row0 is a multiple of 4)
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const u64x2 c0 = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g);
+                const u64x2 c1 = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g + 2);
+                cv[4 * g] = c0[0];
+                cv[4 * g + 1] = c0[1];
+                cv[4 * g + 2] = c1[0];
+                cv[4 * g + 3] = c1[1];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+                cv[j] = codes[row < end ? row : begin];
+            }
+        }
+        // which of the 16 pass: a bit mask first, then ONE append per trip of a loop the whole wave walks together
+        // (a branch per position put up to 16 atomic round trips of different lanes in a row: 62 -> 41 us in a first stage)
+        uint32_t pm = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+            const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
+            pm |= (d <= tq && row < end) ? 1u << j : 0u;
+        }
+        // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
+        // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
+        // this kernel disagree about the result layout -> distrust the filter, take the robust tier
+        // (the all-ones query is filtered one bit off and one distance wider -- filter_query -- so its lanes may be
+        // flagged in vain)
+        if (!pm && (int)__popcll(qv) - (int)tq > 0 && qv != ~0ull) *overflow = 1;
+        while (pm) {
+            const int j = __builtin_ctz(pm);
+            pm &= pm - 1;
+            uint64_t c = cv[0];
+#pragma unroll
+            for (int jj = 1; jj < 16; jj++) c = j == jj ? cv[jj] : c;
+            const size_t row = row0 + (j & 3) + 8 * (j >> 2);
+            const uint64_t id = ids[row];
+            const uint32_t pos = atomicAdd(&cand_cnt[(size_t)q * kSub + sub], 1u);
+            if (pos < sub_cap) {
+                cand_d[(size_t)q * cand_cap + sub * sub_cap + pos] = (uint32_t)__popcll(qv ^ c);
+                cand_id[(size_t)q * cand_cap + sub * sub_cap + pos] = id;
+            } else {
+                *overflow = 1;
+            }
+        }
+    };
+    const uint32_t stride = gridDim.y * kRescanThreads;
+    for (uint32_t base = blockIdx.y * kRescanThreads; base < cnt; base += stride) {   // block-uniform trip count
+        const uint32_t rix = base + threadIdx.x;
+        uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, rc = ra;
+        if (rix < cnt) {
+            const uint4* rec = log + ((size_t)blockIdx.x * log_cap + rix) * 3;
+            ra = rec[0];
+            rb = rec[1];
+            rc = rec[2];
+        }
+        const uint64_t m0 = (uint64_t)ra.z | ((uint64_t)ra.w << 32), m1 = (uint64_t)rb.x | ((uint64_t)rb.y << 32),
+                       m2 = (uint64_t)rb.z | ((uint64_t)rb.w << 32), m3 = (uint64_t)rc.x | ((uint64_t)rc.y << 32);
+        const uint32_t nf = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+        uint32_t pos = nf ? atomicAdd(&qn, nf) : 0u;
+#pragma unroll
+        for (uint32_t b = 0; b < (uint32_t)kTB; b++) {
+            uint64_t mask = b == 0 ? m0 : b == 1 ? m1 : b == 2 ? m2 : m3;
             while (mask) {
                 const int l = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const uint32_t q = ra.x * 32 + (l & 31);   // a flagged lane always has a live query
-                const uint64_t qv = queries[q];
-                const uint32_t tq = tau[q];
-                // the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
-                const size_t row0 = begin + ra.y + 32 * b + 4 * (l >> 5);
-                uint64_t cv[16];
-                if (row0 + 28 <= end) {   // four groups of four consecutive codes: 16-byte loads (row0 is a multiple of 4)
-                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const u64x2 c0 = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g);
-                        const u64x2 c1 = *reinterpret_cast<const u64x2*>(codes + row0 + 8 * g + 2);
-                        cv[4 * g] = c0[0];
-                        cv[4 * g + 1] = c0[1];
-                        cv[4 * g + 2] = c1[0];
-                        cv[4 * g + 3] = c1[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const size_t row = row0 + (j & 3) + 8 * (j >> 2);
-                        cv[j] = codes[row < end ? row : begin];
-                    }
-                }
-                bool found = false;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const size_t row = row0 + (j & 3) + 8 * (j >> 2);
-                    const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
-                    if (d <= tq && row < end) {
-                        found = true;
-                        const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
-                        if (pos < cand_cap) {
-                            cand_d[(size_t)q * cand_cap + pos] = d;
-                            cand_id[(size_t)q * cand_cap + pos] = ids[row];
-                        } else {
-                            *overflow = 1;
-                        }
-                    }
-                }
-                // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
-                // are all-zero and can only flag a lane whose threshold is <= 0); anything else means the scan and
-                // this kernel disagree about the result layout -> distrust the filter, take the robust tier
-                // (the all-ones query is filtered one bit off and one distance wider -- filter_query -- so its lanes may be
-                // flagged in vain)
-                if (!found && (int)__popcll(qv) - (int)tq > 0 && qv != ~0ull) *overflow = 1;
+                // a flagged lane always has a live query; row offset of the lane's first code (a multiple of 4)
+                const uint32_t q = ra.x * 32 + (l & 31), off = ra.y + 32 * b + 4 * (l >> 5);
+                if (pos < kRescanQueue) queue[pos] = make_uint2(q, off);
+                else evaluate(q, off);   // a trip that flags more than the queue holds (dense first stages of tiny corpora)
+                pos++;
             }
         }
+        __syncthreads();
+        const uint32_t have = qn < kRescanQueue ? qn : kRescanQueue;
+        const bool last = base + stride >= cnt;
+        if (last || have + kRescanThreads * 8 > kRescanQueue) {
+            for (uint32_t e = threadIdx.x; e < have; e += kRescanThreads) evaluate(queue[e].x, queue[e].y);
+            __syncthreads();
+            if (threadIdx.x == 0) qn = 0;
+            __syncthreads();
+        }   // (entries beyond the queue's end were evaluated in place, and a full queue always drains)
     }
 }
 
@@ -845,10 +891,11 @@ __global__ __launch_bounds__(256) void hamming_scan_lanes(
 #pragma unroll
                 for (int k = 0; k < kC; k++) {
                     if (d[k] <= t && row[k] < end) {
-                        const uint32_t pos = atomicAdd(&cand_cnt[j], 1u);
-                        if (pos < cand_cap) {
-                            cand_d[(size_t)j * cand_cap + pos] = d[k];
-                            cand_id[(size_t)j * cand_cap + pos] = ids[row[k]];
+                        const uint32_t sub = blockIdx.x % kSub, sub_cap = cand_cap / kSub;
+                        const uint32_t pos = atomicAdd(&cand_cnt[(size_t)j * kSub + sub], 1u);
+                        if (pos < sub_cap) {
+                            cand_d[(size_t)j * cand_cap + sub * sub_cap + pos] = d[k];
+                            cand_id[(size_t)j * cand_cap + sub * sub_cap + pos] = ids[row[k]];
                         } else {
                             *overflow = 1;
                         }
@@ -858,6 +905,34 @@ __global__ __launch_bounds__(256) void hamming_scan_lanes(
         }
     }
 }
+
+// A query's sub-lists seen as one list of `total` entries: entry v lives in slot slot(v).  The counts are wave-uniform
+// (one scalar load of kSub words).
+struct SubLists {
+    uint32_t end[kSub];   // running totals
+    uint32_t total, sub_cap;
+    __device__ __forceinline__ SubLists(const uint32_t* __restrict__ cnt, uint32_t cand_cap) {
+        sub_cap = cand_cap / kSub;
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kSub; u++) {
+            const uint32_t c = cnt[u];
+            run += c < sub_cap ? c : sub_cap;
+            end[u] = run;
+        }
+        total = run;
+    }
+    __device__ __forceinline__ uint32_t slot(uint32_t v) const {
+        uint32_t u = 0, before = 0;
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < kSub; i++) {
+            const bool past = v >= end[i];
+            u += past ? 1u : 0u;
+            before = past ? end[i] : before;
+        }
+        return u * sub_cap + (v - before);
+    }
+};
 
 // tau1[q] = k-th smallest distance among q's candidates so far (one wave per query); also the exact
 // bound the second stage filters with.  Fewer than k candidates (only after an overflow) -> keep tau0.
@@ -871,9 +946,8 @@ __global__ __launch_bounds__(64) void hamming_list_tau(const uint32_t* __restric
     h[lane] = 0;
     if (lane == 0) h[64] = 0;
     wave_lds_sync();
-    uint32_t nc = cand_cnt[q];
-    nc = nc < cand_cap ? nc : cand_cap;
-    for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[cand_d[(size_t)q * cand_cap + c]], 1u);
+    const SubLists sl(cand_cnt + (size_t)q * kSub, cand_cap);
+    for (uint32_t c = lane; c < sl.total; c += kWave) atomicAdd(&h[cand_d[(size_t)q * cand_cap + sl.slot(c)]], 1u);
     wave_lds_sync();
     if (lane == 0) {
         uint32_t cum = 0, t = tau0[q];   // fewer than k candidates so far: the previous threshold stands
@@ -895,7 +969,7 @@ __global__ __launch_bounds__(64) void hamming_list_tau(const uint32_t* __restric
 // gives d* (the k-th smallest distance); only entries with d <= d* can win, and they are few, so
 // they are compacted into LDS and the k selection rounds run there (straight from the global list
 // when more than kSelCap of them tie).
-constexpr int kSelCap = 1024;
+constexpr int kSelCap = 512;   // 6 KiB of LDS per query: all 4096 one-wave workgroups of a batch are resident at once
 __global__ __launch_bounds__(64) void hamming_final_select(
     const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ cand_d, const uint64_t* __restrict__ cand_id,
     uint32_t cand_cap, uint32_t k, uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_d,
@@ -908,11 +982,11 @@ __global__ __launch_bounds__(64) void hamming_final_select(
     h[lane] = 0;
     if (lane == 0) h[64] = 0;
     wave_lds_sync();
-    uint32_t nc = cand_cnt[q];
-    nc = nc < cand_cap ? nc : cand_cap;
+    const SubLists sl(cand_cnt + (size_t)q * kSub, cand_cap);
+    const uint32_t nc = sl.total;
     const uint32_t* __restrict__ gd = cand_d + (size_t)q * cand_cap;
     const uint64_t* __restrict__ gi = cand_id + (size_t)q * cand_cap;
-    for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[gd[c]], 1u);
+    for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[gd[sl.slot(c)]], 1u);
     wave_lds_sync();
     uint32_t dstar = 64, cum = 0;   // wave-uniform: every lane walks the same 65 bins
     for (uint32_t b = 0; b < 65; b++) {
@@ -926,14 +1000,15 @@ __global__ __launch_bounds__(64) void hamming_final_select(
     uint32_t m = 0;   // wave-uniform
     for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
         const uint32_t c = c0 + lane;
-        const uint32_t dd = c < nc ? gd[c] : 0xffffffffu;
+        const uint32_t at = c < nc ? sl.slot(c) : 0u;
+        const uint32_t dd = c < nc ? gd[at] : 0xffffffffu;
         const bool w = dd <= dstar;
         const uint64_t mask = __ballot(w);
         const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (w && pos < (uint32_t)kSelCap) {
             sd[pos] = dd;
-            si[pos] = gi[c];
+            si[pos] = gi[at];
         }
         m += (uint32_t)__popcll(mask);
     }
@@ -947,8 +1022,9 @@ __global__ __launch_bounds__(64) void hamming_final_select(
         uint32_t bd = 0xffffffffu;
         uint64_t bi = ~0ull;
         for (uint32_t c = lane; c < total; c += kWave) {
-            const uint32_t dd = in_lds ? sd[c] : gd[c];
-            const uint64_t ii = in_lds ? si[c] : gi[c];
+            const uint32_t at = in_lds ? c : sl.slot(c);
+            const uint32_t dd = in_lds ? sd[c] : gd[at];
+            const uint64_t ii = in_lds ? si[c] : gi[at];
             if ((first || key_less(ld, li, dd, ii)) && key_less(dd, ii, bd, bi)) {
                 bd = dd;
                 bi = ii;
@@ -985,7 +1061,8 @@ __global__ __launch_bounds__(64) void hamming_final_select(
 __global__ void hamming_reset_lists(uint32_t nq, uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q == 0) *overflow = 0;
-    if (q < nq) cand_cnt[q] = 0;
+    if (q < nq)
+        for (uint32_t u = 0; u < kSub; u++) cand_cnt[(size_t)q * kSub + u] = 0;
 }
 
 // score = 1 - d/64 (higher is better, src/core/mod.rs:113-115); invalid -> 0 count handles it
@@ -1059,13 +1136,16 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     // batches on the matrix-core filter take their first bound from the filter itself (hamming_bound_mfma): the k-th
     // smallest of 256 group minima over the first 512 k codes -- as tight as two stages of lists used to make it
     p.bound = p.fast && !few_queries(n, nq) && k <= 64 && !getenv("UCFP_HAMMING_NO_BOUND");
-    if (p.bound) p.bound_n = (n < kBoundCodes ? n : kBoundCodes) & ~(size_t)(128 - 1);
+    size_t bcodes = kBoundCodes;
+    if (const char* e = getenv("UCFP_TUNE_BOUND_LOG2")) bcodes = (size_t)1 << atoi(e);
+    if (p.bound) p.bound_n = (n < bcodes ? n : bcodes) & ~(size_t)(128 - 1);
     if (p.fast) {
         size_t e = p.bound ? p.bound_n : p.sample_n;
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
         // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs; the same
         // for batches of 9 .. 256 queries, where 16x measured 5-20 % slower)
-        constexpr size_t growth = 4;
+        size_t growth = 4;
+        if (const char* e = getenv("UCFP_TUNE_GROWTH")) growth = (size_t)atoi(e);
         // (with the bound pass the first stage starts over at row 0, so there is one even when bound_n == n)
         do {
             e = e * growth < n ? e * growth : n;
@@ -1076,6 +1156,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         size_t cc = (size_t)k * growth * 5 * p.nstages * 2;   // 2x headroom
         if (cc < 2048) cc = 2048;
         if (cc > 65536) cc = 65536;
+        cc = (cc + 63) & ~(size_t)63;   // kSub equal sub-lists
         p.cand_cap = (uint32_t)cc;
         p.log_cap = 1024;   // suspect steps per scan wave: 4096 slices x 1024 records x 48 B
         slice_range(n, p.qgroups, 256 * 16, 4096, p.fb_slices, p.fb_per_slice);
@@ -1102,7 +1183,7 @@ HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     w.part_cnt = off;  off = align(off + (size_t)ms * nq * 4);
     w.tau1 = off;      off = align(off + (size_t)nq * 4);
     w.tau2 = off;      off = align(off + (size_t)nq * 4);
-    w.cand_cnt = off;  off = align(off + (size_t)nq * 4);
+    w.cand_cnt = off;  off = align(off + (size_t)nq * 4 * kSub);
     w.overflow = off;  off = align(off + 4);
     w.cand_d = off;    off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 4 : 0));
     w.cand_id = off;   off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 8 : 0));
@@ -1234,7 +1315,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(mw * 64), lds, stream, codes, begin, end,
                                queries, nq, (const i32x4*)qimg, (const uint32_t*)tau_cur,
                                reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow));
-            hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw, rescan_parts), dim3(256), 0, stream, codes, ids, begin, end, queries,
+            hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw, rescan_parts), dim3(kRescanThreads), 0, stream, codes, ids, begin, end, queries,
                                (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
                                u64(w.cand_id), p.cand_cap, u32(w.overflow));
@@ -1256,8 +1337,10 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         launch_robust(p.cap, dim3(p.fb_slices, p.qgroups), stream, codes, ids, n, p.fb_per_slice, queries, nq, k,
                       (const uint32_t*)u32(w.tau0), u64(w.part_ids), u32(w.part_d), u32(w.part_cnt),
                       (const uint32_t*)u32(w.overflow));
+        // (the gated merge also turns the final distances into scores, whichever kernel selected them)
         launch_topk_merge_u32(u64(w.part_ids), u32(w.part_d), p.fb_slices, nq, k, out_ids, out_dist, out_cnt,
-                              u32(w.overflow), stream);
+                              u32(w.overflow), stream, out_scores);
+        return 0;
     }
     if (out_scores)
         hipLaunchKernelGGL(hamming_scores, dim3(score_blocks), dim3(256), 0, stream, out_dist, (size_t)nq * k,

@@ -192,8 +192,19 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
                                                      uint64_t* __restrict__ out_ids,
                                                      uint32_t* __restrict__ out_key,
                                                      uint32_t* __restrict__ out_cnt,
-                                                     const uint32_t* __restrict__ run_flag, uint32_t group_parts) {
-    if (run_flag && *run_flag == 0) return;
+                                                     const uint32_t* __restrict__ run_flag, uint32_t group_parts,
+                                                     float* __restrict__ hscores) {
+    // hscores (optional; only with one group): Hamming similarity 1 - d / 64 of the FINAL keys of this query, written
+    // whether or not the merge runs -- the gated fallback of the Hamming search ends with it, so that the distances another
+    // kernel selected get their scores without a launch of their own
+    if (run_flag && *run_flag == 0) {
+        if (hscores)
+            for (uint32_t e = threadIdx.x; e < k; e += kWave) {
+                const uint32_t d = out_key[(size_t)blockIdx.x * k + e];
+                hscores[(size_t)blockIdx.x * k + e] = d == 0xffffffffu ? -1.0f : 1.0f - (float)d * (1.0f / 64.0f);
+            }
+        return;
+    }
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     // blockIdx.y = group of `group_parts` consecutive parts (tree merge: one output list per group and query)
@@ -263,6 +274,7 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
         if (lane == 0) {
             out_ids[(size_t)q * k + r] = bi;
             out_key[(size_t)q * k + r] = bd;
+            if (hscores) hscores[(size_t)q * k + r] = 1.0f - (float)bd * (1.0f / 64.0f);
         }
         ld = bd;
         li = bi;
@@ -273,6 +285,7 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
         for (uint32_t r = emitted; r < k; r++) {
             out_ids[(size_t)q * k + r] = ~0ull;
             out_key[(size_t)q * k + r] = 0xffffffffu;
+            if (hscores) hscores[(size_t)q * k + r] = -1.0f;
         }
         if (out_cnt) out_cnt[(size_t)blockIdx.y * nq + q] = emitted;
     }
@@ -607,10 +620,10 @@ int launch_topk_select_lists_u32(const uint64_t* base_ids, const uint32_t* base_
 
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,
                           uint32_t k, uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt,
-                          const uint32_t* run_flag, hipStream_t stream) {
+                          const uint32_t* run_flag, hipStream_t stream, float* hamming_scores) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(topk_merge_u32<false>, dim3(nq), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, out_ids,
-                       out_key, out_cnt, run_flag, parts);
+                       out_key, out_cnt, run_flag, parts, hamming_scores);
     return 0;
 }
 
@@ -635,7 +648,7 @@ int launch_topk_merge_packed(const void* entries, uint32_t parts, uint32_t nq, u
                              uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(topk_merge_u32<true>, dim3(nq), dim3(64), 0, stream, reinterpret_cast<const uint64_t*>(entries),
-                       (const uint32_t*)nullptr, parts, nq, k, out_ids, out_key, out_cnt, (const uint32_t*)nullptr, parts);
+                       (const uint32_t*)nullptr, parts, nq, k, out_ids, out_key, out_cnt, (const uint32_t*)nullptr, parts, (float*)nullptr);
     return 0;
 }
 
@@ -651,10 +664,10 @@ int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_ke
                                uint32_t* out_cnt, hipStream_t stream, const uint32_t* run_flag) {
     if (nq == 0) return 0;
     if (parts <= kMergeFan)
-        return launch_topk_merge_u32(part_ids, part_key, parts, nq, k, out_ids, out_key, out_cnt, run_flag, stream);
+        return launch_topk_merge_u32(part_ids, part_key, parts, nq, k, out_ids, out_key, out_cnt, run_flag, stream, nullptr);
     const uint32_t groups = (parts + kMergeFan - 1) / kMergeFan;
     hipLaunchKernelGGL(topk_merge_u32<false>, dim3(nq, groups), dim3(64), 0, stream, part_ids, part_key, parts, nq, k, tmp_ids,
-                       tmp_key, (uint32_t*)nullptr, run_flag, kMergeFan);
+                       tmp_key, (uint32_t*)nullptr, run_flag, kMergeFan, (float*)nullptr);
     return launch_topk_merge_tree_u32(tmp_ids, tmp_key, groups, nq, k, tmp_ids + (size_t)groups * nq * k,
                                       tmp_key + (size_t)groups * nq * k, out_ids, out_key, out_cnt, stream, run_flag);
 }

@@ -760,10 +760,10 @@ def test_hamming_strict_thresholds_with_overflowing_lists(gpu_ctx, oracle, nq):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [262_144, 400_000, 524_288, 524_289, 524_288 + 127, 2_200_000])
+@pytest.mark.parametrize("n", [262_144, 262_145, 262_144 + 127, 400_000, 524_288, 2_200_000])
 def test_hamming_bound_pass_edges(gpu_ctx, oracle, n):
     """Batches on the matrix-core filter take their first thresholds from hamming_bound_mfma: the k-th smallest of 256
-    group minima over the first min(n, 2^19) & ~127 codes.  Edges: corpora that END on the bound range (one stage that
+    group minima over the first min(n, 2^18) & ~127 codes.  Edges: corpora that END on the bound range (one stage that
     starts over at row 0), one row and one partial step behind it; k at and above the pass's limit (k <= 64, above it the
     sample histogram); the best neighbours all inside ONE group (the bound then comes from the other groups); the
     all-ones query (filtered one bit off, bound one wider); codes behind the bound range that beat everything in it."""
@@ -775,7 +775,7 @@ def test_hamming_bound_pass_edges(gpu_ctx, oracle, n):
     q[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
     q[1] = np.uint64(0)
     for j in range(2, 40):                                    # 30 close neighbours of query j in consecutive rows (one group)
-        at = int(rng.integers(0, min(n, 524_288) - 64))
+        at = int(rng.integers(0, 262_144 - 64))
         for i in range(30):
             codes[at + i] = q[j] ^ (np.uint64(1) << np.uint64(i))
     for j in range(40, 60):                                   # the best ones sit in the LAST rows (behind the bound range if any)

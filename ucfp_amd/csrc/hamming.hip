@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __res
 __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint64_t* __restrict__ codes, size_t begin, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
     const i32x4* __restrict__ qimg, const uint32_t* __restrict__ tau, uint4* __restrict__ log,
-    uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ overflow) {
+    uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ overflow, size_t strict_from,
+    const uint32_t* __restrict__ ids_ascending) {
     const uint32_t nthreads = blockDim.x, mw = nthreads >> 6;   // waves in this workgroup
     extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
     const uint32_t q0 = blockIdx.y * kQP;
@@ -411,7 +412,11 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     // [tile][lane] 16 B: the B operand of query tile t is one ds_read_b128 per lane
     i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
     uint32_t* THR = reinterpret_cast<uint32_t*>(mf_lds + (size_t)(ntiles + 2) * 1024);   // [tile][32]: packed, threshold - 1 per field
-    constexpr uint32_t kNever = 0xffffffffu;                                               // no field exceeds it
+    constexpr uint32_t kNever = 0xfffefffeu;   // no field exceeds it (nor after the strict rows' + 1 per field)
+    // rows from strict_from on are filtered with tau - 1 where ids ascend with the row: the thresholds of the stage that
+    // follows the bound pass are the k-th smallest of group minima over rows < strict_from, so k records at most that far
+    // AND with smaller ids exist already -- a tie from a later row cannot displace them (as in hamming_list_tau)
+    const bool strict_rows = ids_ascending && *ids_ascending;
     // copy of the prebuilt image + 2 zero pad tiles; 8 loads in flight per thread (a plain loop would pay the
     // global latency 17 times in a row)
     for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += nthreads * 8) {
@@ -456,7 +461,11 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const int lane = threadIdx.x & 63;
     const int nn = lane & 31, hh = lane >> 5;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, in an SGPR
-    const size_t gwave = (size_t)blockIdx.x * mw + wv, nwaves = (size_t)gridDim.x * mw;
+    // step st goes to wave (st / workgroups) % mw of workgroup st % workgroups: the steps of a last, partial round land on
+    // different CUs and SIMDs (the waves of a SIMD share its matrix pipe, so a stage takes as long as the busiest SIMD has
+    // steps: with the partial round's steps all in the first workgroups it cost a whole round, 231 us instead of ~160 for
+    // the 1.6 M codes behind 8.4 M of a 10 M corpus)
+    const size_t gwave = (size_t)wv * gridDim.x + blockIdx.x, nwaves = (size_t)gridDim.x * mw;
     const size_t nsuper = (end - begin + kStep - 1) / kStep;
     const size_t slice = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * mw + wv;
     uint4* __restrict__ mylog = log + slice * log_cap * 3;   // 48-byte records
@@ -493,6 +502,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(x[b]);
         load_codes(x, st + nwaves);   // next step's codes travel while this one computes
         const uint32_t off = (uint32_t)(st * kStep);   // row - begin of code tile 0 (the span is < 2^32)
+        const uint32_t dlt = strict_rows && begin + st * kStep >= strict_from ? 0x00010001u : 0u;   // wave-uniform
         // Software pipeline over the query tiles: per pair of code tiles, the v_pk_maximum3 folding query tile t-1's
         // results, then the two MFMAs of query tile t into the same registers.  4 MFMAs (128 matrix-pipe cycles)
         // carry 19 vector instructions (76 issue cycles) + their own 32: the matrix pipe is the bound again, and the
@@ -502,9 +512,10 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         // MFMA follows its producer back to back (forwarded), and the MFMA that overwrites a result issues after the
         // fold that read it; B operands come from LDS (waitcnt on the asm operands), A was written by VALU hundreds of
         // cycles earlier.
-        auto step = [&](uint32_t t, const i32x4& bq, uint32_t thr, i32x4& nq_, uint32_t& nthr) {
+        auto step = [&](uint32_t t, const i32x4& bq, uint32_t thr0, i32x4& nq_, uint32_t& nthr) {
             uint32_t m01, m23, vs;
             uint64_t hit;
+            const uint32_t thr = thr0 + dlt;
             // The "memory" clobbers keep the operand prefetch of the next tile (plain LDS loads: the compiler
             // places their address arithmetic and waitcnt) where it is written, early in the step.
             asm volatile(UCFP_FOLD_PAIR : "+v"(D[0]), "=&v"(m01) : UCFP_FOLD_PAIR_IN(0) : "memory");
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
 // The k-th smallest of the minima of G disjoint groups of codes is an upper bound on the k-th smallest distance of their
 // union (the k groups below it each hold a code at least that close), and with G = 256 >> k it is the k-th distance itself
 // or its neighbour.  So the filter's own loop -- same operands, same packed fold -- run WITHOUT thresholds over the first
-// 512 k codes, keeping per (workgroup, query) the largest sum, yields in one launch at the matrix rate what the sample
+// 256 k codes, keeping per (workgroup, query) the largest sum, yields in one launch at the matrix rate what the sample
 // histogram (popcounts, 3 T pairs/s) plus two stages of filter / rescan / list threshold used to approach step by step.
 // The fold's per-lane maximum goes to LDS with ds_max_u32 ([tile][query]; both 16-row halves of a query hit the same
 // word, which also merges them); the workgroup's row of the table is d'(q) = popc(fq) - max sum, 255 for "no code seen".
@@ -721,8 +732,10 @@ __global__ __launch_bounds__(kRescanThreads) __attribute__((amdgpu_waves_per_eu(
     const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t begin, size_t end,
     const uint64_t* __restrict__ queries, const uint32_t* __restrict__ tau, const uint4* __restrict__ log,
     const uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ cand_cnt,
-    uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id, uint32_t cand_cap, uint32_t* __restrict__ overflow) {
+    uint32_t* __restrict__ cand_d, uint64_t* __restrict__ cand_id, uint32_t cand_cap, uint32_t* __restrict__ overflow,
+    size_t strict_from, const uint32_t* __restrict__ ids_ascending) {
     __shared__ uint2 queue[kRescanQueue];
+    const bool strict_rows = ids_ascending && *ids_ascending;   // see hamming_scan_mfma
     __shared__ uint32_t qn;
     const uint32_t cnt = log_cnt[blockIdx.x];
     const uint32_t sub = blockIdx.x % kSub, sub_cap = cand_cap / kSub;
@@ -731,8 +744,8 @@ __global__ __launch_bounds__(kRescanThreads) __attribute__((amdgpu_waves_per_eu(
     // one flagged lane: the 16 results lane (nn, hh) folded are rows (j & 3) + 8 (j >> 2) + 4 hh of the 32-code tile (32x32 C/D map)
     auto evaluate = [&](uint32_t q, uint32_t off) {
         const uint64_t qv = queries[q];
-        const uint32_t tq = tau[q];
         const size_t row0 = begin + off;
+        const int tq = (int)tau[q] - (strict_rows && row0 >= strict_from ? 1 : 0);   // -1: nothing passes
         uint64_t cv[16];
         if (row0 + 28 <= end) {   // four groups of four consecutive codes: 16-byte loads (row0 is a multiple of 4)
             typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -758,7 +771,7 @@ __global__ __launch_bounds__(kRescanThreads) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const size_t row = row0 + (j & 3) + 8 * (j >> 2);
-            const uint32_t d = (uint32_t)__popcll(qv ^ cv[j]);
+            const int d = (int)__popcll(qv ^ cv[j]);
             pm |= (d <= tq && row < end) ? 1u << j : 0u;
         }
         // self-check: a flagged lane holds at least one true candidate by construction (rows past `end`
@@ -766,7 +779,7 @@ __global__ __launch_bounds__(kRescanThreads) __attribute__((amdgpu_waves_per_eu(
         // this kernel disagree about the result layout -> distrust the filter, take the robust tier
         // (the all-ones query is filtered one bit off and one distance wider -- filter_query -- so its lanes may be
         // flagged in vain)
-        if (!pm && (int)__popcll(qv) - (int)tq > 0 && qv != ~0ull) *overflow = 1;
+        if (!pm && (int)__popcll(qv) - tq > 0 && qv != ~0ull) *overflow = 1;
         while (pm) {
             const int j = __builtin_ctz(pm);
             pm &= pm - 1;
@@ -1114,7 +1127,9 @@ int launch_ids_order_update(const uint64_t* ids, size_t n, bool first, uint32_t*
 
 static bool few_queries(size_t n, uint32_t nq);
 constexpr uint32_t kBoundGroups = 256;        // workgroups of the bound pass = groups of codes whose minima bound the k-th distance
-constexpr size_t kBoundCodes = (size_t)1 << 19;   // codes the bound pass covers (measured against 2^18 and 2^20)
+// codes the bound pass covers: 2^17 / 2^18 / 2^19 / 2^20 / 2^21 measured on one box at 10 M, 12.5 M and 100 M codes x 256 and 4096
+// queries -- 2^18 is 0.5-1.5 % ahead of 2^19 everywhere, 2^17 and 2^20 1-3 % behind (stage growth 8 instead of 4: 2-5 % behind)
+constexpr size_t kBoundCodes = (size_t)1 << 18;
 
 HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     HammingPlan p;
@@ -1134,18 +1149,15 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     p.fast = n >= (size_t)1 << 18 && n - 1 <= 0xfffffff0u;
     p.robust_n = n;
     // batches on the matrix-core filter take their first bound from the filter itself (hamming_bound_mfma): the k-th
-    // smallest of 256 group minima over the first 512 k codes -- as tight as two stages of lists used to make it
+    // smallest of 256 group minima over the first 256 k codes -- as tight as two stages of lists used to make it
     p.bound = p.fast && !few_queries(n, nq) && k <= 64 && !getenv("UCFP_HAMMING_NO_BOUND");
-    size_t bcodes = kBoundCodes;
-    if (const char* e = getenv("UCFP_TUNE_BOUND_LOG2")) bcodes = (size_t)1 << atoi(e);
-    if (p.bound) p.bound_n = (n < bcodes ? n : bcodes) & ~(size_t)(128 - 1);
+    if (p.bound) p.bound_n = (n < kBoundCodes ? n : kBoundCodes) & ~(size_t)(128 - 1);
     if (p.fast) {
         size_t e = p.bound ? p.bound_n : p.sample_n;
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
         // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs; the same
         // for batches of 9 .. 256 queries, where 16x measured 5-20 % slower)
-        size_t growth = 4;
-        if (const char* e = getenv("UCFP_TUNE_GROWTH")) growth = (size_t)atoi(e);
+        constexpr size_t growth = 4;
         // (with the bound pass the first stage starts over at row 0, so there is one even when bound_n == n)
         do {
             e = e * growth < n ? e * growth : n;
@@ -1284,24 +1296,15 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         for (uint32_t sidx = 0; sidx < p.nstages; sidx++) {
             const size_t end = p.stage_end[sidx];
             const size_t supers = (end - begin + kStep - 1) / kStep;
-            // one workgroup per CU (the query image fills its LDS) of 4, 8 or 16 waves: the waves of a SIMD share its
-            // matrix pipe, so a stage costs ~ rounds x (time of one step with that many waves per SIMD); the relative
-            // step times 1 : 2 : 3.9 are tools/ubench_mfma_i8.hip's (mode 23: 62.7 / 62.8 / 64.0 T pairs/s at 1 / 2 / 4
-            // waves); more waves also cover the stalls the bare stream does not have
-            unsigned mw = kMW;
-            {
-                double best = 1e30;
-                const unsigned opt[3] = {4, 8, (unsigned)kMW};
-                const double rel[3] = {1.0, 2.0, 3.9};
-                for (int o = 0; o < 3; o++) {
-                    const double c = (double)((supers + 256 * opt[o] - 1) / (256 * opt[o])) * rel[o];
-                    if (c < best - 1e-9) best = c, mw = opt[o];
-                }
-            }
+            // one workgroup per CU (the query image fills its LDS) of 4, 8 or 16 waves -- as many as the stage has steps for:
+            // the waves of a SIMD share its matrix pipe and cover each other's stalls (a step takes 17.8 us with one wave per
+            // SIMD, 11.9 us per wave with four), and steps are dealt wave-major so that a partial round costs its share
+            unsigned mw = supers > 256 * 8 ? (unsigned)kMW : supers > 256 * 4 ? 8u : 4u;
             unsigned wgs = 256;
             if ((size_t)wgs * mw > supers) wgs = (unsigned)((supers + mw - 1) / mw);
             // suspects are dense in the short first stages (every step logs a record): more rescan blocks per slice there
             const unsigned rescan_parts = supers <= 4096 ? 4 : 1;
+            const size_t strict_from = p.bound && sidx == 0 ? p.bound_n : ~(size_t)0;   // rows behind the bound pass's range
             if (few) {
                 const size_t per_block = 256 * 8;
                 size_t blocks = (end - begin + per_block - 1) / per_block;
@@ -1314,11 +1317,12 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             // mw - 1: the rescan covers exactly those (no memset of the counters)
             hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(mw * 64), lds, stream, codes, begin, end,
                                queries, nq, (const i32x4*)qimg, (const uint32_t*)tau_cur,
-                               reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow));
+                               reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow), strict_from,
+                               ids_ascending);
             hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw, rescan_parts), dim3(kRescanThreads), 0, stream, codes, ids, begin, end, queries,
                                (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
-                               u64(w.cand_id), p.cand_cap, u32(w.overflow));
+                               u64(w.cand_id), p.cand_cap, u32(w.overflow), strict_from, ids_ascending);
             }
             if (sidx + 1 < p.nstages) {
                 hipLaunchKernelGGL(hamming_list_tau, dim3(nq), dim3(64), 0, stream, (const uint32_t*)u32(w.cand_cnt),

@@ -790,3 +790,39 @@ def test_hamming_bound_pass_edges(gpu_ctx, oracle, n):
             o_ids, o_d, o_c = oracle.hamming_topk(the_ids, codes, q, k)
             assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids), (n, flags, k)
         ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dim,nq,k", [(140_001, 512, 5, 10), (131_072, 768, 16, 1), (150_017, 1024, 11, 64),
+                                        (140_001, 256, 6, 10), (133_333, 768, 17, 10), (140_016, 256, 48, 33),
+                                        (262_147, 128, 33, 64), (131_073, 512, 16, 65)])
+def test_cosine_pruned_pass(gpu_ctx, n, dim, nq, k):
+    """5 .. 48 queries over >= 2^17 rows write no key matrix (cosine.hip CosinePrune): chunk minima -> a threshold and ~k
+    listed chunks per query -> their keys recomputed -> answer, with the dense pass as the gated fallback.  Both row-stream
+    kernels (4x4x1: dim 512 .. 1024, <= 16 queries; 16x16x4 otherwise), ragged last chunks, zero rows, duplicated rows whose
+    copies sit in different chunks (ties resolved by id), k up to the pass's limit (64) and one above it (dense path), an
+    exact-direction match; and the answer must equal the dense path's bit for bit (the list pass recomputes the same tiles
+    with the same arithmetic)."""
+    import os
+    from ucfp_amd import index
+    rng = np.random.default_rng(n + dim + nq)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[rng.integers(0, n, 9)] = 0.0
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    queries[0] = rows[n - 3] * 2.5                      # its best match sits in the ragged last chunk
+    for j in range(1, min(nq, 5)):                      # three copies of a near-match, far apart: equal scores, id order decides
+        near = (queries[j] + 0.05 * rng.standard_normal(dim)).astype(np.float32)
+        for pos in rng.integers(0, n, 3):
+            rows[pos] = near
+    ids = rng.permutation(n).astype(np.uint64) * np.uint64(5) + np.uint64(1)
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, g_key, g_c = ix.search(0, queries, k)
+    _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+    os.environ["UCFP_COSINE_NO_PRUNE"] = "1"
+    try:
+        d_ids, d_sc, d_key, d_c = ix.search(0, queries, k)
+    finally:
+        del os.environ["UCFP_COSINE_NO_PRUNE"]
+    assert np.array_equal(g_c, d_c) and np.array_equal(g_ids, d_ids) and np.array_equal(g_sc, d_sc)
+    ix.close()

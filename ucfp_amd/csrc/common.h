@@ -124,6 +124,34 @@ int launch_topk_select_lists_u32(const uint64_t* base_ids, const uint32_t* base_
                                  const uint32_t* crow, const uint32_t* ccnt, uint32_t cap, const uint64_t* ids,
                                  uint32_t nq, uint32_t k, uint64_t* out_ids, uint32_t* out_key, uint32_t* out_cnt,
                                  uint32_t* overflow, hipStream_t stream);
+// 5 .. 48 cosine queries without a key matrix (cosine.hip CosinePrune, topk.hip prune_*): chunk minima -> threshold and
+// ~k listed chunks per query -> their keys recomputed -> answer; *flag != 0 afterwards = take the dense path instead
+struct CosinePrunePlan {
+    uint32_t cs_shift = 5;   // rows per chunk = 1 << cs_shift
+    uint32_t qpad = 16;      // minima per chunk (queries padded to the keys kernel's tile): mins[chunk][qpad]
+    uint32_t nchunks = 0;
+    uint32_t waves = 0;      // waves of the minima launch: wmin[qpad][waves]
+    uint32_t capq = 32;      // listed chunks per query at most
+};
+constexpr uint32_t kPruneCand = 2048;   // chunks per query at or below the waves' bound, ranked exactly
+bool cosine_prune_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k);
+CosinePrunePlan cosine_prune_plan(const float* rows, uint32_t dim, const float* queries, size_t n, uint32_t nq_pass, uint32_t k);
+int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                            const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, uint32_t* mins, uint32_t* wmin,
+                            hipStream_t stream);
+int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                            const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, const void* list,
+                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream);
+// bound[q] = k-th smallest wave minimum -> cand[q] = (minimum, chunk) of the chunks at or below it -> tau[q] = k-th smallest chunk
+// minimum; list = (query, chunk) of every chunk whose minimum is <= tau[q]; qrange[q] = (first entry, entries); *nlist = entries
+// in all; *flag raised when a query lists more than capq chunks or has no threshold.  ws: bound[nq] ccnt[nq] cand[nq][kPruneCand] x 8 B
+size_t prune_tau_ws_bytes(uint32_t nq);
+int launch_prune_tau(const uint32_t* mins, const uint32_t* wmin, const CosinePrunePlan& p, uint32_t nq, uint32_t k, uint8_t* ws,
+                     uint32_t* tau, void* list, uint32_t* nlist, void* qrange, uint32_t* flag, hipStream_t stream);
+// best k by (key, id) of the listed chunks' keys <= tau[q]; does nothing once *flag is raised (and raises it if its own list overflows)
+int launch_prune_final(const uint32_t* ckeys, const CosinePrunePlan& p, const void* list, const void* qrange,
+                       const uint32_t* tau, const uint64_t* ids, size_t n, uint32_t nq, uint32_t k, uint64_t* out_ids,
+                       uint32_t* out_key, uint32_t* out_cnt, uint32_t* flag, hipStream_t stream);
 constexpr uint32_t kCosineListCap = 1024;   // candidates kept per query by the filtered cosine pass
 // run_flag: optional device word; when non-null the merge only runs if it is non-zero
 int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts,

@@ -128,6 +128,54 @@ __global__ __launch_bounds__(256) void cosine_keys(const float* __restrict__ row
     }
 }
 
+// ---- 5 .. 48 queries without a key matrix ---------------------------------------------------------------------------
+// Writing the nq x n key matrix costs far more than its bytes: 64 MB of keys next to 3 GB of row reads (16 queries over
+// 1 M x 768) took 140 of the keys kernel's 730 us -- the same stores aimed at a cache-resident slot cost 18 -- and the
+// selection then reads them back.  The two row-stream kernels below therefore run in one of three modes:
+//   kKeysDense  keys[q][row] (the fallback, and every other caller)
+//   kKeysMins   no keys: the smallest key of every chunk of rows (1 << cs_shift of them) per query, mins[q][chunk]
+//   kKeysList   the keys of listed (query, chunk) pairs only, ckeys[entry][row in chunk] -- the SAME arithmetic on the
+//               same tiles, so a recomputed key equals the one the minimum was taken from bit for bit
+// topk.hip's prune kernels turn the minima into a threshold per query (the k-th smallest chunk minimum: at least k keys
+// are <= it, so the k best all are, and each lies in a chunk whose minimum is <= it) and a list of about k chunks, and
+// pick the answer from the listed chunks' keys.
+enum { kKeysDense = 0, kKeysMins = 1, kKeysList = 2 };
+struct CosinePrune {
+    uint32_t* mins;          // kKeysMins: [nchunks][qpad] -- a chunk's minima leave as one contiguous run
+    uint32_t qpad;           // queries padded to the kernel's tile: 16 (4x4x1 kernel) or 16 G (16x16x4 kernel)
+    uint32_t* wmin;          // kKeysMins: [qpad][waves of the launch]: the smallest key each wave saw per query (the k-th smallest
+                             // of these bounds the k-th smallest chunk minimum: k waves hold a key at most that large)
+    uint32_t cs_shift;       // rows per chunk = 1 << cs_shift: 5 (a supertile of the 4x4x1 kernel) or 4 (a tile of the 16x16x4 one)
+    const uint2* list;       // kKeysList: (query, chunk) entries
+    const uint32_t* nlist;   // their number (device word)
+    uint32_t* ckeys;         // kKeysList: [entry][1 << cs_shift]
+};
+
+// Query image [nrows][qstride] in LDS from queries[nq_pass][dim] (16-byte aligned, dim % 4 == 0), zero-filled past dim and
+// nq_pass.  Wave w fills rows w, w + waves, ...; a row's pieces are all requested before the first is stored (the fill is a
+// few load latencies, not one per piece: it used to be ~25 us of every launch, which matters to the short list pass).
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fill_query_image(float* __restrict__ qs, const float* __restrict__ queries, uint32_t nrows,
+                                                 uint32_t nq_pass, uint32_t dim, uint32_t qstride, uint32_t nthreads) {
+    const uint32_t lane = threadIdx.x & 63, waves = nthreads >> 6;
+    for (uint32_t qt = threadIdx.x >> 6; qt < nrows; qt += waves) {
+        for (uint32_t c0 = 0; c0 < qstride; c0 += 5 * 256) {
+            f32x4q v[5];
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const uint32_t c = c0 + 256 * u + 4 * lane;
+                v[u] = f32x4q{0.f, 0.f, 0.f, 0.f};
+                if (qt < nq_pass && c < dim) v[u] = *reinterpret_cast<const f32x4q*>(queries + (size_t)qt * dim + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const uint32_t c = c0 + 256 * u + 4 * lane;
+                if (c < qstride) *reinterpret_cast<f32x4q*>(qs + (size_t)qt * qstride + c) = v[u];
+            }
+        }
+    }
+}
+
 // ---- MFMA variant: 16 rows x (16*G queries) per wave step ---------------------------------------
 // v_mfma_f32_16x16x4_f32: A = queries (M = query, lane l: Q[l&15][k]), B = rows (N = row, lane l:
 // R[l&15][k]), k = 4 consecutive dims per lane taken from ONE float4 (global for rows, LDS for
@@ -141,20 +189,26 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // FULL: dim is a multiple of 32 * U (256): every chunk load is unconditional (dead rows read row 0), so the
 // loop body is loads + LDS reads + MFMAs with no exec masking in between.
 constexpr int kCW = 8;    // waves per workgroup (one workgroup per CU: the queries fill its LDS); 12 measured the same
-template <int G, bool FULL>
+template <int G, bool FULL, int MODE>
 __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __restrict__ rows,
                                                         const float* __restrict__ norms, size_t n, uint32_t dim,
                                                         const float* __restrict__ queries,
                                                         const float* __restrict__ qnorm, uint32_t nq_pass,
-                                                        uint32_t* __restrict__ keys) {
+                                                        uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ run_flag, CosinePrune pr) {
+    if (run_flag && (MODE == kKeysList ? *run_flag != 0 : *run_flag == 0)) return;   // as in cosine_keys_blocks
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [16*G][dim16 + 4]
     const uint32_t dim16 = (dim + 15) & ~15u;
     const uint32_t qstride = dim16 + 4;
-    for (uint32_t i = threadIdx.x; i < 16u * G * qstride; i += kCW * 64) {
-        const uint32_t qt = i / qstride, c = i - qt * qstride;
-        qs[i] = (qt < nq_pass && c < dim) ? queries[(size_t)qt * dim + c] : 0.f;
+    if ((reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {   // (dim % 4 == 0: mfma_ok)
+        fill_query_image(qs, queries, 16u * G, nq_pass, dim, qstride, kCW * 64);
+    } else {
+        for (uint32_t i = threadIdx.x; i < 16u * G * qstride; i += kCW * 64) {
+            const uint32_t qt = i / qstride, c = i - qt * qstride;
+            qs[i] = (qt < nq_pass && c < dim) ? queries[(size_t)qt * dim + c] : 0.f;
+        }
     }
-    __syncthreads();
+    // (the barrier behind the fill comes after the first row loads have been requested, below)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nn = lane & 15, q4 = lane >> 4;
     const size_t tiles = (n + 15) / 16;
@@ -195,9 +249,28 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
 #pragma unroll
         for (int g = 0; g < G; g++) qv[g] = *reinterpret_cast<const float4*>(&qs[(g * 16 + nn) * qstride + c16 + 4 * q4]);
     };
-    size_t tile = (size_t)blockIdx.x * kCW + wave;
-    if (tile < tiles) load_chunks(xa, row_ptr(tile), tile * 16 + nn < n, 0);
-    for (; tile < tiles; tile += tstep) {
+    // work items: every 16-row tile, or the tiles of the listed chunks (1 << tsh of them per entry)
+    const uint32_t tsh = 0;   // a chunk is one tile (cs_shift == 4)
+    const size_t items = MODE == kKeysList ? (size_t)*pr.nlist << tsh : tiles;
+    auto tile_of = [&](size_t it) -> size_t {
+        if (MODE != kKeysList) return it;
+        const size_t t = ((size_t)pr.list[it >> tsh].y << tsh) + (it & (((size_t)1 << tsh) - 1));
+        return t < tiles ? t : tiles - 1;   // a chunk's tiles past the last row: recompute the last tile, nobody reads the keys
+    };
+    size_t it = (size_t)blockIdx.x * kCW + wave;
+    uint32_t wave_min[G][4];   // kKeysMins: smallest key per result slot over this wave's tiles
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) wave_min[g][r] = 0xffffffffu;
+    if (it < items) {
+        const size_t t0 = tile_of(it);
+        load_chunks(xa, row_ptr(t0), t0 * 16 + nn < n, 0);
+    }
+    __syncthreads();   // the query image is complete
+    for (; it < items; it += tstep) {
+        const size_t tile = tile_of(it);
+        const size_t tile_next = it + tstep < items ? tile_of(it + tstep) : tiles;
         const size_t row = tile * 16 + nn;
         const bool live = row < n;
         const float* __restrict__ v = row_ptr(tile);
@@ -235,30 +308,53 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
             consume(xa, c0);
             if (c0 + 32 * U < dim16) {
                 load_chunks(xa, v, live, c0 + 32 * U);
-            } else if (tile + tstep < tiles) {   // xa is free: the next tile's first chunks travel during the rest
-                load_chunks(xa, row_ptr(tile + tstep), (tile + tstep) * 16 + nn < n, 0);
+            } else if (tile_next < tiles) {   // xa is free: the next tile's first chunks travel during the rest
+                load_chunks(xa, row_ptr(tile_next), tile_next * 16 + nn < n, 0);
             }
             consume(xb, c0 + 16 * U);
         }
         // D: col = lane&15 = row in tile, row = 4*(lane>>4) + reg = query in group
-        if (live) {
+        const uint32_t qe = MODE == kKeysList ? pr.list[it >> tsh].x : 0u;   // wave-uniform
+        if (live || MODE == kKeysMins) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
+                uint32_t mq[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint32_t qt = g * 16 + 4 * q4 + r;
-                    if (qt < nq_pass) {
-                        const float qn = qnr[g][r];
-                        uint32_t key = 0xffffffffu;
-                        if (vn != 0.f && qn != 0.f) {
-                            const float sc = acc[g][r] / (qn * vn);
-                            if (sc == sc) key = score_to_key(sc);
-                        }
-                        keys[(size_t)qt * n + row] = key;
+                    const float qn = qnr[g][r];
+                    uint32_t key = 0xffffffffu;
+                    if (live && vn != 0.f && qn != 0.f) {
+                        const float sc = acc[g][r] / (qn * vn);
+                        if (sc == sc) key = score_to_key(sc);
+                    }
+                    if (MODE == kKeysDense) {
+                        if (qt < nq_pass) keys[(size_t)qt * n + row] = key;
+                    } else if (MODE == kKeysMins) {
+                        // minimum over the tile's 16 rows = the 16 lanes of this DPP row
+                        uint32_t m = key;
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));   // row_ror:8
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));   // row_ror:4
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));   // row_ror:2
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
+                        mq[r] = m;
+                        wave_min[g][r] = min(wave_min[g][r], m);
+                    } else if (qt == qe) {
+                        pr.ckeys[((it >> tsh) << pr.cs_shift) + ((it & (((size_t)1 << tsh) - 1)) << 4) + nn] = key;
                     }
                 }
+                // queries 16 g + 4 q4 .. + 3 of this tile: 16 bytes per lane row, 64 G contiguous bytes per tile
+                if (MODE == kKeysMins && nn == 0)
+                    *reinterpret_cast<uint4*>(pr.mins + tile * (16 * G) + g * 16 + 4 * q4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
             }
         }
+    }
+    if (MODE == kKeysMins && nn == 0) {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                pr.wmin[(size_t)(g * 16 + 4 * q4 + r) * ((size_t)gridDim.x * kCW) + (size_t)blockIdx.x * kCW + wave] = wave_min[g][r];
     }
 }
 
@@ -286,21 +382,19 @@ constexpr int kBW = 8;     // waves per workgroup (one workgroup per CU: the que
 // A wave owns SUPERTILES of 32 consecutive rows (four 8-row tiles): the keys of a supertile are collected in LDS and
 // leave as 128-byte runs per query (stored straight from the accumulator lanes they were 16-byte pieces: a fifth of
 // the kernel's time at 16 queries).
-template <int NCH>         // 64-float chunks per row: dim <= 64 NCH
+template <int NCH, int MODE>         // 64-float chunks per row: dim <= 64 NCH; MODE: see CosinePrune
 __global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __restrict__ rows,
                                                           const float* __restrict__ norms, size_t n, uint32_t dim,
                                                           const float* __restrict__ queries,
                                                           const float* __restrict__ qnorm, uint32_t nq_pass,
                                                           uint32_t qstride, uint32_t* __restrict__ keys,
-                                                          const uint32_t* __restrict__ run_flag) {
-    if (run_flag && *run_flag == 0) return;
+                                                          const uint32_t* __restrict__ run_flag, CosinePrune pr) {
+    // run_flag gates the dense fallback (runs when set) and, inverted, the list pass (pointless once the fallback is due)
+    if (run_flag && (MODE == kKeysList ? *run_flag != 0 : *run_flag == 0)) return;
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [16][qstride] query image, zero-filled past dim / nq_pass;
     uint32_t* stage = reinterpret_cast<uint32_t*>(qs + 16 * qstride) + (threadIdx.x >> 6) * (16 * 32);   // then [wave][16][32] keys
-    for (uint32_t i = threadIdx.x; i < 16u * qstride; i += kBW * 64) {
-        const uint32_t qt = i / qstride, c = i - qt * qstride;
-        qs[i] = (qt < nq_pass && c < dim) ? queries[(size_t)qt * dim + c] : 0.f;
-    }
-    __syncthreads();
+    fill_query_image(qs, queries, 16u, nq_pass, dim, qstride, kBW * 64);   // (dim % 4 == 0, queries 16-byte aligned: blocks_path)
+    // (the barrier behind the fill comes after the first row loads have been requested, below)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = lane >> 2, j = lane & 3;
     const size_t tiles = (n + 7) / 8, supers = (n + 31) / 32;
@@ -322,18 +416,30 @@ __global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __re
             h1[c] = in ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v1 + 64 * (c0 + c))) : f32x4v{0.f, 0.f, 0.f, 0.f};
         }
     };
-    size_t sup = (size_t)blockIdx.x * kBW + wave;
-    if (sup < supers) {
-        load_half(xa0, xa1, sup * 4, 0);
-        load_half(xb0, xb1, sup * 4, H);
+    // work items: every supertile (dense, minima) or the supertiles of the listed chunks (1 << tsh of them per entry)
+    const uint32_t tsh = MODE == kKeysList ? pr.cs_shift - 5 : 0;
+    const size_t items = MODE == kKeysList ? (size_t)*pr.nlist << tsh : supers;
+    auto sup_of = [&](size_t it) -> size_t {
+        if (MODE != kKeysList) return it;
+        return ((size_t)pr.list[it >> tsh].y << tsh) + (it & (((size_t)1 << tsh) - 1));   // (past the last row: clamped loads, keys nobody reads)
+    };
+    size_t it = (size_t)blockIdx.x * kBW + wave;
+    uint32_t wave_min = 0xffffffffu;   // kKeysMins: lane (q, 0) keeps query q's smallest key over this wave's supertiles
+    if (it < items) {
+        const size_t sup0 = sup_of(it);
+        load_half(xa0, xa1, sup0 * 4, 0);
+        load_half(xb0, xb1, sup0 * 4, H);
     }
-    for (; sup < supers; sup += sstep) {
+    __syncthreads();   // the query image is complete
+    for (; it < items; it += sstep) {
+        const size_t sup = sup_of(it);
+        const size_t sup_next = it + sstep < items ? sup_of(it + sstep) : supers;
 #pragma unroll 1
         for (int t = 0; t < 4; t++) {
             const size_t tile = sup * 4 + t;
             // the tile after this one: the supertile's next, or the first of the wave's next supertile (past the end
             // the loads fall on clamped rows and are dropped)
-            const size_t next = t < 3 ? tile + 1 : (sup + sstep) * 4;
+            const size_t next = t < 3 ? tile + 1 : sup_next * 4;
             const bool more = next < tiles;
             const size_t r0 = tile * 8 + j, r1 = r0 + 4;
             const float vn0 = norms[r0 < n ? r0 : n - 1], vn1 = norms[r1 < n ? r1 : n - 1];
@@ -396,17 +502,35 @@ __global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __re
                 }
             }
         }
-        // the supertile's keys: 16 queries x 32 rows, two queries (2 x 128 B) per store
         wave_lds_fence();
-        const size_t row = sup * 32 + (lane & 31);
+        if (MODE == kKeysDense) {
+            // the supertile's keys: 16 queries x 32 rows, two queries (2 x 128 B) per store
+            const size_t row = sup * 32 + (lane & 31);
 #pragma unroll
-        for (int qq = 0; qq < 16; qq += 2) {
-            const uint32_t qt = qq + (lane >> 5);
-            const uint32_t key = stage[qt * 32 + (lane & 31)];
-            if (qt < nq_pass && row < n) keys[(size_t)qt * n + row] = key;
+            for (int qq = 0; qq < 16; qq += 2) {
+                const uint32_t qt = qq + (lane >> 5);
+                const uint32_t key = stage[qt * 32 + (lane & 31)];
+                if (qt < nq_pass && row < n) keys[(size_t)qt * n + row] = key;
+            }
+        } else if (MODE == kKeysMins) {
+            // lane (q, part) = (lane >> 2, lane & 3): eight of query q's 32 keys (rows past n repeat row n - 1: the minimum
+            // does not care), then the quad's four partial minima
+            const uint4 k0 = *reinterpret_cast<const uint4*>(stage + (lane >> 2) * 32 + (lane & 3) * 8);
+            const uint4 k1 = *reinterpret_cast<const uint4*>(stage + (lane >> 2) * 32 + (lane & 3) * 8 + 4);
+            uint32_t m = min(min(min(k0.x, k0.y), min(k0.z, k0.w)), min(min(k1.x, k1.y), min(k1.z, k1.w)));
+            m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+            m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+            if ((lane & 3) == 0) pr.mins[sup * 16 + (lane >> 2)] = m;   // 64 contiguous bytes per supertile (queries past nq_pass: never read)
+            wave_min = min(wave_min, m);
+        } else {
+            const uint32_t qe = pr.list[it >> tsh].x;   // wave-uniform
+            if (lane < 32)
+                pr.ckeys[((it >> tsh) << pr.cs_shift) + ((it & (((size_t)1 << tsh) - 1)) << 5) + lane] = stage[qe * 32 + lane];
         }
         wave_lds_fence();
     }
+    if (MODE == kKeysMins && (lane & 3) == 0)
+        pr.wmin[(size_t)(lane >> 2) * ((size_t)gridDim.x * kBW) + (size_t)blockIdx.x * kBW + wave] = wave_min;
 }
 
 // ---- streaming variant for a handful of queries (the reference's own shape: one query per request) ----
@@ -765,8 +889,9 @@ bool blocks_path(const float* rows, uint32_t dim, const float* queries, uint32_t
     return mfma_ok(rows, dim) && dim >= 512 && dim <= 1024 && nq_pass > 4 && nq_pass <= 16 && n >= 4096 &&
            (reinterpret_cast<uintptr_t>(queries) & 15u) == 0;
 }
+template <int MODE>
 void launch_blocks(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
-                   uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag, hipStream_t stream) {
+                   uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag, hipStream_t stream, const CosinePrune& pr) {
     const uint32_t nch = ((dim + 63) / 64 + 1) & ~1u;      // whole chunks, an even number of them
     const uint32_t qstride = nch * 64 + 16;                // >= dim, and 16 mod 64 floats: conflict-free A reads
     const size_t lds = (size_t)16 * qstride * sizeof(float) + (size_t)kBW * 16 * 32 * sizeof(uint32_t);
@@ -777,14 +902,41 @@ void launch_blocks(const float* rows, const float* norms, size_t n, uint32_t dim
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBW * 64), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass, qstride,
-                           keys, run_flag);
+                           keys, run_flag, pr);
     };
-    if (nch <= 2) go(cosine_keys_blocks<2>);
-    else if (nch <= 4) go(cosine_keys_blocks<4>);
-    else if (nch <= 6) go(cosine_keys_blocks<6>);
-    else if (nch <= 8) go(cosine_keys_blocks<8>);
-    else if (nch <= 12) go(cosine_keys_blocks<12>);
-    else go(cosine_keys_blocks<16>);
+    if (nch <= 2) go(cosine_keys_blocks<2, MODE>);
+    else if (nch <= 4) go(cosine_keys_blocks<4, MODE>);
+    else if (nch <= 6) go(cosine_keys_blocks<6, MODE>);
+    else if (nch <= 8) go(cosine_keys_blocks<8, MODE>);
+    else if (nch <= 12) go(cosine_keys_blocks<12, MODE>);
+    else go(cosine_keys_blocks<16, MODE>);
+}
+template <int MODE>
+void launch_mfma(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
+                 uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag, hipStream_t stream, const CosinePrune& pr) {
+    const int G = (int)((nq_pass + 15) / 16);  // <= mfma_groups(dim) by construction of the pass size
+    const uint32_t dim16 = (dim + 15) & ~15u;
+    const size_t lds = (size_t)16 * G * (dim16 + 4) * sizeof(float) + 64;   // + slack for the operand prefetch past the last row
+    const size_t tiles = (n + 15) / 16;
+    unsigned grid = (unsigned)((tiles + kCW - 1) / kCW);
+    if (grid > 256 * 4) grid = 256 * 4;
+    auto go = [&](auto kern) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kCW * 64), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass,
+                           keys, run_flag, pr);
+    };
+    const bool full = dim % 256 == 0;   // 32 * U
+    if (full) {
+        if (G == 1) go(cosine_keys_mfma<1, true, MODE>);
+        else if (G == 2) go(cosine_keys_mfma<2, true, MODE>);
+        else go(cosine_keys_mfma<3, true, MODE>);
+    } else {
+        if (G == 1) go(cosine_keys_mfma<1, false, MODE>);
+        else if (G == 2) go(cosine_keys_mfma<2, false, MODE>);
+        else go(cosine_keys_mfma<3, false, MODE>);
+    }
 }
 }  // namespace
 
@@ -844,33 +996,11 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
         return 0;
     }
     if (blocks_path(rows, dim, queries, nq_pass, n)) {
-        launch_blocks(rows, norms, n, dim, queries, qnorm, nq_pass, keys, run_flag, stream);
+        launch_blocks<kKeysDense>(rows, norms, n, dim, queries, qnorm, nq_pass, keys, run_flag, stream, CosinePrune{});
         return 0;
     }
     if (mfma_ok(rows, dim)) {
-        const int G = (int)((nq_pass + 15) / 16);  // <= mfma_groups(dim) by construction of the pass size
-        const uint32_t dim16 = (dim + 15) & ~15u;
-        const size_t lds = (size_t)16 * G * (dim16 + 4) * sizeof(float) + 64;   // + slack for the operand prefetch past the last row
-        const size_t tiles = (n + 15) / 16;
-        unsigned grid = (unsigned)((tiles + kCW - 1) / kCW);
-        if (grid > 256 * 4) grid = 256 * 4;
-        auto go = [&](auto kern) {
-            if (lds > 48 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kCW * 64), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass,
-                               keys);
-        };
-        const bool full = dim % 256 == 0;   // 32 * U
-        if (full) {
-            if (G == 1) go(cosine_keys_mfma<1, true>);
-            else if (G == 2) go(cosine_keys_mfma<2, true>);
-            else go(cosine_keys_mfma<3, true>);
-        } else {
-            if (G == 1) go(cosine_keys_mfma<1, false>);
-            else if (G == 2) go(cosine_keys_mfma<2, false>);
-            else go(cosine_keys_mfma<3, false>);
-        }
+        launch_mfma<kKeysDense>(rows, norms, n, dim, queries, qnorm, nq_pass, keys, run_flag, stream, CosinePrune{});
         return 0;
     }
     const uint32_t dim4 = (dim + 3) & ~3u;
@@ -880,6 +1010,60 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(cosine_keys, dim3((unsigned)((n + 31) / 32)), dim3(256), lds, stream, rows, norms, n, dim,
                        queries, qnorm, nq_pass, keys);
+    return 0;
+}
+
+// ---- the pass without a key matrix (see CosinePrune) ----
+bool cosine_prune_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k) {
+    // the two row-stream kernels' batches (5 .. 48 queries); corpora large enough that ~k chunks are a sliver of them
+    return nq_pass > 4 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32) &&
+           (blocks_path(rows, dim, queries, nq_pass, n) ||
+            (mfma_ok(rows, dim) && nq_pass <= (uint32_t)16 * mfma_groups(dim) && !gemm_path(rows, dim, queries, nq_pass)));
+}
+CosinePrunePlan cosine_prune_plan(const float* rows, uint32_t dim, const float* queries, size_t n, uint32_t nq_pass, uint32_t k) {
+    CosinePrunePlan p;
+    const bool blocks = blocks_path(rows, dim, queries, nq_pass, n);
+    p.cs_shift = blocks ? 5 : 4;                                 // a supertile of the 4x4x1 kernel / a tile of the 16x16x4 one
+    p.qpad = blocks ? 16u : 16u * ((nq_pass + 15) / 16);
+    p.nchunks = (uint32_t)(((n - 1) >> p.cs_shift) + 1);
+    {   // waves of the minima launch (launch_blocks / launch_mfma size their grids the same way)
+        const size_t units = blocks ? (n + 31) / 32 : (n + 15) / 16;
+        const unsigned wpb = blocks ? kBW : kCW, most = blocks ? 256u : 256u * 4;
+        unsigned grid = (unsigned)((units + wpb - 1) / wpb);
+        if (grid > most) grid = most;
+        p.waves = grid * wpb;
+    }
+    p.capq = (2 * k + 31) & ~31u;                                // chunks listed per query: k of them beat the threshold, ties add a few
+    if (p.capq < 32) p.capq = 32;
+    return p;
+}
+int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                            const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, uint32_t* mins, uint32_t* wmin,
+                            hipStream_t stream) {
+    CosinePrune pr{};
+    pr.mins = mins;
+    pr.wmin = wmin;
+    pr.qpad = p.qpad;
+    pr.cs_shift = p.cs_shift;
+    if (p.cs_shift == 5)
+        launch_blocks<kKeysMins>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, nullptr, stream, pr);
+    else
+        launch_mfma<kKeysMins>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, nullptr, stream, pr);
+    return 0;
+}
+int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                            const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, const void* list,
+                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream) {
+    CosinePrune pr{};
+    pr.cs_shift = p.cs_shift;
+    pr.qpad = p.qpad;
+    pr.list = reinterpret_cast<const uint2*>(list);
+    pr.nlist = nlist;
+    pr.ckeys = ckeys;
+    if (p.cs_shift == 5)
+        launch_blocks<kKeysList>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, fallback_flag, stream, pr);
+    else
+        launch_mfma<kKeysList>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, fallback_flag, stream, pr);
     return 0;
 }
 

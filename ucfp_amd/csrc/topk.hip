@@ -500,6 +500,211 @@ __global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restr
     if (tid == 0 && out_cnt) out_cnt[q] = kept;
 }
 
+// ---- the same idea without a key matrix (cosine.hip CosinePrune): the keys kernel itself wrote the chunk minima ----
+// Three small kernels turn them into thresholds and chunk lists:
+//   prune_bound_kernel    per query: the k-th smallest of the keys kernel's per-WAVE minima -- an upper bound on the k-th
+//                         smallest chunk minimum (k waves hold a key at most that large)
+//   prune_collect_kernel  one coalesced pass over mins[chunk][qpad]: the chunks at or below their query's bound, a handful
+//                         each, to cand[q]
+//   prune_tau_kernel      per query: tau = the k-th smallest chunk minimum, ranked exactly among the candidates; the chunks
+//                         whose minimum is <= tau go to the global list as (query, chunk)
+// (A workgroup per query that reads its own column of the minima is bound by its CU's address path, one line per lane: 80 us
+// at 16 queries, 165 at 32; a radix select over all minima serialises on one histogram bin, cosine keys share their leading
+// bytes: 51 us.)
+__global__ __launch_bounds__(256) void prune_bound_kernel(const uint32_t* __restrict__ wmin, uint32_t waves, uint32_t k,
+                                                          uint32_t* __restrict__ bound, uint32_t* __restrict__ ccnt) {
+    // 256 threads (k <= 64 < 256): 1024 of them ranking 1024 minima against each other took 46 us on their one CU
+    __shared__ __attribute__((aligned(16))) uint32_t s_tmin[256];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    uint32_t m = 0xffffffffu;
+    for (uint32_t w = tid; w < waves; w += 256) m = min(m, wmin[(size_t)q * waves + w]);
+    s_tmin[tid] = m;
+    if (tid == 0) bound[q] = 0xffffffffu, ccnt[q] = 0;
+    __syncthreads();
+    // rank of this thread's minimum among the 256 (ties by thread number): the one of rank k - 1 is the bound
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u < 256; u += 4) {
+        const uint4 o = *reinterpret_cast<const uint4*>(s_tmin + u);
+        rank += (o.x < m || (o.x == m && u < tid)) ? 1u : 0u;
+        rank += (o.y < m || (o.y == m && u + 1 < tid)) ? 1u : 0u;
+        rank += (o.z < m || (o.z == m && u + 2 < tid)) ? 1u : 0u;
+        rank += (o.w < m || (o.w == m && u + 3 < tid)) ? 1u : 0u;
+    }
+    if (rank == k - 1) bound[q] = m;   // 0xffffffff: fewer than k threads saw a scored row -- no threshold
+}
+
+// thread = four consecutive queries of one chunk (a uint4 of mins[chunk][qpad]; qpad is a multiple of 16)
+__global__ __launch_bounds__(256) void prune_collect_kernel(const uint32_t* __restrict__ mins, uint32_t nchunks, uint32_t qpad,
+                                                            uint32_t nq, const uint32_t* __restrict__ bound,
+                                                            uint32_t* __restrict__ ccnt, uint2* __restrict__ cand) {
+    __shared__ uint32_t s_b[64];
+    if (threadIdx.x < 64) s_b[threadIdx.x] = threadIdx.x < nq ? bound[threadIdx.x] : 0u;
+    __syncthreads();
+    const uint32_t per = qpad / 4;
+    const size_t total = (size_t)nchunks * per;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t c = (uint32_t)(i / per), q0 = (uint32_t)(i % per) * 4;
+        const uint4 v = *reinterpret_cast<const uint4*>(mins + i * 4);
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t q = q0 + j;
+            if (q < nq && vv[j] <= s_b[q] && vv[j] != 0xffffffffu) {
+                const uint32_t pos = atomicAdd(&ccnt[q], 1u);
+                if (pos < kPruneCand) cand[(size_t)q * kPruneCand + pos] = make_uint2(vv[j], c);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void prune_tau_kernel(const uint32_t* __restrict__ bound, const uint32_t* __restrict__ ccnt,
+                                                        const uint2* __restrict__ cand, uint32_t k, uint32_t capq,
+                                                        uint32_t* __restrict__ tau_out, uint2* __restrict__ list,
+                                                        uint32_t* __restrict__ nlist, uint2* __restrict__ qrange,
+                                                        uint32_t* __restrict__ flag) {
+    __shared__ uint32_t s_ck[kPruneCand], s_cc[kPruneCand];
+    __shared__ uint32_t s_tau, s_cnt, s_put, s_base;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t cn = ccnt[q];
+    // no bound (fewer than k scored waves), ties in bulk at the bound, or -- cannot happen -- fewer than k candidates: dense path
+    if (bound[q] == 0xffffffffu || cn > kPruneCand || cn < k) {
+        if (tid == 0) {
+            *flag = 1;
+            tau_out[q] = 0xffffffffu;
+            qrange[q] = make_uint2(0, 0);
+        }
+        return;
+    }
+    for (uint32_t e = tid; e < cn; e += 256) {
+        const uint2 v = cand[(size_t)q * kPruneCand + e];
+        s_ck[e] = v.x;
+        s_cc[e] = v.y;
+    }
+    if (tid == 0) s_tau = 0xffffffffu, s_cnt = 0, s_put = 0;
+    __syncthreads();
+    for (uint32_t e = tid; e < cn; e += 256) {
+        const uint32_t v = s_ck[e];
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < cn; o++) rank += (s_ck[o] < v || (s_ck[o] == v && o < e)) ? 1u : 0u;
+        if (rank == k - 1) s_tau = v;
+    }
+    __syncthreads();
+    const uint32_t tau = s_tau;
+    for (uint32_t e = tid; e < cn; e += 256)
+        if (s_ck[e] <= tau) atomicAdd(&s_cnt, 1u);
+    __syncthreads();
+    const uint32_t total = s_cnt;
+    if (total > capq) {           // ties in bulk at the threshold: the dense path prunes them while it gathers
+        if (tid == 0) {
+            *flag = 1;
+            tau_out[q] = tau;
+            qrange[q] = make_uint2(0, 0);
+        }
+        return;
+    }
+    if (tid == 0) {
+        s_base = atomicAdd(nlist, total);
+        tau_out[q] = tau;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t e = tid; e < cn; e += 256)
+        if (s_ck[e] <= tau) list[base + atomicAdd(&s_put, 1u)] = make_uint2(q, s_cc[e]);
+    if (tid == 0) qrange[q] = make_uint2(base, total);
+}
+
+// prune_final_kernel: one workgroup per query: the listed chunks' keys <= tau with their ids, ranked by (key, id).
+constexpr uint32_t kFinalCap = 4096;
+__global__ __launch_bounds__(256) void prune_final_kernel(const uint32_t* __restrict__ ckeys, uint32_t cs_shift,
+                                                          const uint2* __restrict__ list, const uint2* __restrict__ qrange,
+                                                          const uint32_t* __restrict__ tau_in, const uint64_t* __restrict__ ids,
+                                                          size_t n, uint32_t k, uint64_t* __restrict__ out_ids,
+                                                          uint32_t* __restrict__ out_key, uint32_t* __restrict__ out_cnt,
+                                                          uint32_t* __restrict__ flag) {
+    if (*flag) return;
+    __shared__ uint32_t s_key[kFinalCap];
+    __shared__ uint64_t s_id[kFinalCap];
+    __shared__ uint32_t s_tkey[UCFP_INDEX_MAX_K];
+    __shared__ uint64_t s_tid[UCFP_INDEX_MAX_K];
+    __shared__ uint32_t s_n;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint2 rg = qrange[q];
+    const uint32_t tau = tau_in[q];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t cs = 1u << cs_shift;
+    const size_t total = (size_t)rg.y << cs_shift;
+    for (size_t i = tid; i < total; i += 256) {
+        const uint32_t e = (uint32_t)(i >> cs_shift), r = (uint32_t)i & (cs - 1);
+        const uint32_t key = ckeys[((size_t)(rg.x + e) << cs_shift) + r];
+        const size_t row = ((size_t)list[rg.x + e].y << cs_shift) + r;
+        if (row < n && key <= tau && key != 0xffffffffu) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            if (pos < kFinalCap) {
+                s_key[pos] = key;
+                s_id[pos] = ids[row];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t cn = s_n;
+    if (cn > kFinalCap) {          // more keys at or below the threshold than the list holds: the dense path (launched after this
+        if (tid == 0) *flag = 1;   // kernel, gated on the flag) answers
+        return;
+    }
+    // rank of every candidate = the number of candidates before it by (key, id, list position): a permutation even when an
+    // APPEND_ONLY shard holds the same id twice
+    for (uint32_t e = tid; e < cn; e += 256) {
+        const uint32_t dk = s_key[e];
+        const uint64_t di = s_id[e];
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < cn; o++) {
+            const uint32_t ok = s_key[o];
+            const uint64_t oi = s_id[o];
+            rank += (key_less(ok, oi, dk, di) || (ok == dk && oi == di && o < e)) ? 1u : 0u;
+        }
+        if (rank < k) {
+            s_tkey[rank] = dk;
+            s_tid[rank] = di;
+        }
+    }
+    __syncthreads();
+    const uint32_t kept = cn < k ? cn : k;
+    for (uint32_t r = tid; r < k; r += 256) {
+        out_ids[(size_t)q * k + r] = r < kept ? s_tid[r] : ~0ull;
+        out_key[(size_t)q * k + r] = r < kept ? s_tkey[r] : 0xffffffffu;
+    }
+    if (tid == 0 && out_cnt) out_cnt[q] = kept;
+}
+
+size_t prune_tau_ws_bytes(uint32_t nq) { return (size_t)nq * 8 + 256 + (size_t)nq * kPruneCand * 8; }
+int launch_prune_tau(const uint32_t* mins, const uint32_t* wmin, const CosinePrunePlan& p, uint32_t nq, uint32_t k, uint8_t* ws,
+                     uint32_t* tau, void* list, uint32_t* nlist, void* qrange, uint32_t* flag, hipStream_t stream) {
+    if (nq == 0) return 0;
+    uint32_t* bound = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* ccnt = bound + nq;
+    uint2* cand = reinterpret_cast<uint2*>(ws + (((size_t)nq * 8 + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(prune_bound_kernel, dim3(nq), dim3(256), 0, stream, wmin, p.waves, k, bound, ccnt);
+    const size_t units = (size_t)p.nchunks * (p.qpad / 4);
+    unsigned grid = (unsigned)((units + 255) / 256);
+    if (grid > 256 * 8) grid = 256 * 8;
+    hipLaunchKernelGGL(prune_collect_kernel, dim3(grid), dim3(256), 0, stream, mins, p.nchunks, p.qpad, nq,
+                       (const uint32_t*)bound, ccnt, cand);
+    hipLaunchKernelGGL(prune_tau_kernel, dim3(nq), dim3(256), 0, stream, (const uint32_t*)bound, (const uint32_t*)ccnt,
+                       (const uint2*)cand, k, p.capq, tau, reinterpret_cast<uint2*>(list), nlist,
+                       reinterpret_cast<uint2*>(qrange), flag);
+    return 0;
+}
+int launch_prune_final(const uint32_t* ckeys, const CosinePrunePlan& p, const void* list, const void* qrange,
+                       const uint32_t* tau, const uint64_t* ids, size_t n, uint32_t nq, uint32_t k, uint64_t* out_ids,
+                       uint32_t* out_key, uint32_t* out_cnt, uint32_t* flag, hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(prune_final_kernel, dim3(nq), dim3(256), 0, stream, ckeys, p.cs_shift,
+                       reinterpret_cast<const uint2*>(list), reinterpret_cast<const uint2*>(qrange), tau, ids, n, k, out_ids,
+                       out_key, out_cnt, flag);
+    return 0;
+}
+
 size_t select_pruned_chunk(size_t n) {
     size_t chunk = 1024;
     while ((n + chunk - 1) / chunk > kPruneMaxChunks) chunk *= 2;

@@ -799,10 +799,10 @@ def test_hamming_bound_pass_edges(gpu_ctx, oracle, n):
 def test_cosine_pruned_pass(gpu_ctx, n, dim, nq, k):
     """5 .. 48 queries over >= 2^17 rows write no key matrix (cosine.hip CosinePrune): chunk minima -> a threshold and ~k
     listed chunks per query -> their keys recomputed -> answer, with the dense pass as the gated fallback.  Both row-stream
-    kernels (4x4x1: dim 512 .. 1024, <= 16 queries; 16x16x4 otherwise), ragged last chunks, zero rows, duplicated rows whose
-    copies sit in different chunks (ties resolved by id), k up to the pass's limit (64) and one above it (dense path), an
-    exact-direction match; and the answer must equal the dense path's bit for bit (the list pass recomputes the same tiles
-    with the same arithmetic)."""
+    Ragged last chunks, zero rows, duplicated rows whose copies sit in different chunks (ties resolved by id), k up to the
+    pass's limit (64) and one above it (dense path), an exact-direction match; and the answer must equal, bit for bit, the one
+    of the pass's own fallback (the dense keys of the same kernel + selection; forced here by UCFP_COSINE_PRUNE_FALLBACK):
+    the list pass recomputes the same tiles with the same arithmetic."""
     import os
     from ucfp_amd import index
     rng = np.random.default_rng(n + dim + nq)
@@ -819,10 +819,10 @@ def test_cosine_pruned_pass(gpu_ctx, n, dim, nq, k):
     ix.upsert(0, ids, rows)
     g_ids, g_sc, g_key, g_c = ix.search(0, queries, k)
     _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
-    os.environ["UCFP_COSINE_NO_PRUNE"] = "1"
+    os.environ["UCFP_COSINE_PRUNE_FALLBACK"] = "1"
     try:
         d_ids, d_sc, d_key, d_c = ix.search(0, queries, k)
     finally:
-        del os.environ["UCFP_COSINE_NO_PRUNE"]
+        del os.environ["UCFP_COSINE_PRUNE_FALLBACK"]
     assert np.array_equal(g_c, d_c) and np.array_equal(g_ids, d_ids) and np.array_equal(g_sc, d_sc)
     ix.close()

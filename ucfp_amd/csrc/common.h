@@ -135,7 +135,10 @@ struct CosinePrunePlan {
 };
 constexpr uint32_t kPruneCand = 2048;   // chunks per query at or below the waves' bound, ranked exactly
 bool cosine_prune_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k);
-CosinePrunePlan cosine_prune_plan(const float* rows, uint32_t dim, const float* queries, size_t n, uint32_t nq_pass, uint32_t k);
+CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k);
+int launch_cosine_keys_dense_mfma(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                                  const float* qnorm, uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag,
+                                  hipStream_t stream);
 int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                             const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, uint32_t* mins, uint32_t* wmin,
                             hipStream_t stream);

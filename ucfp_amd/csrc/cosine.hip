@@ -23,6 +23,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void cosine_keys(const float* __restrict__ row
 // ---- 5 .. 48 queries without a key matrix ---------------------------------------------------------------------------
 // Writing the nq x n key matrix costs far more than its bytes: 64 MB of keys next to 3 GB of row reads (16 queries over
 // 1 M x 768) took 140 of the keys kernel's 730 us -- the same stores aimed at a cache-resident slot cost 18 -- and the
-// selection then reads them back.  The two row-stream kernels below therefore run in one of three modes:
+// selection then reads them back.  cosine_keys_mfma therefore runs in one of three modes:
 //   kKeysDense  keys[q][row] (the fallback, and every other caller)
 //   kKeysMins   no keys: the smallest key of every chunk of rows (1 << cs_shift of them) per query, mins[q][chunk]
 //   kKeysList   the keys of listed (query, chunk) pairs only, ckeys[entry][row in chunk] -- the SAME arithmetic on the
@@ -142,10 +143,10 @@ __global__ __launch_bounds__(256) void cosine_keys(const float* __restrict__ row
 enum { kKeysDense = 0, kKeysMins = 1, kKeysList = 2 };
 struct CosinePrune {
     uint32_t* mins;          // kKeysMins: [nchunks][qpad] -- a chunk's minima leave as one contiguous run
-    uint32_t qpad;           // queries padded to the kernel's tile: 16 (4x4x1 kernel) or 16 G (16x16x4 kernel)
+    uint32_t qpad;           // queries padded to the kernel's tile: 16 G
     uint32_t* wmin;          // kKeysMins: [qpad][waves of the launch]: the smallest key each wave saw per query (the k-th smallest
                              // of these bounds the k-th smallest chunk minimum: k waves hold a key at most that large)
-    uint32_t cs_shift;       // rows per chunk = 1 << cs_shift: 5 (a supertile of the 4x4x1 kernel) or 4 (a tile of the 16x16x4 one)
+    uint32_t cs_shift;       // rows per chunk = 1 << cs_shift = 16: a tile
     const uint2* list;       // kKeysList: (query, chunk) entries
     const uint32_t* nlist;   // their number (device word)
     uint32_t* ckeys;         // kKeysList: [entry][1 << cs_shift]
@@ -382,15 +383,14 @@ constexpr int kBW = 8;     // waves per workgroup (one workgroup per CU: the que
 // A wave owns SUPERTILES of 32 consecutive rows (four 8-row tiles): the keys of a supertile are collected in LDS and
 // leave as 128-byte runs per query (stored straight from the accumulator lanes they were 16-byte pieces: a fifth of
 // the kernel's time at 16 queries).
-template <int NCH, int MODE>         // 64-float chunks per row: dim <= 64 NCH; MODE: see CosinePrune
+template <int NCH>         // 64-float chunks per row: dim <= 64 NCH
 __global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __restrict__ rows,
                                                           const float* __restrict__ norms, size_t n, uint32_t dim,
                                                           const float* __restrict__ queries,
                                                           const float* __restrict__ qnorm, uint32_t nq_pass,
                                                           uint32_t qstride, uint32_t* __restrict__ keys,
-                                                          const uint32_t* __restrict__ run_flag, CosinePrune pr) {
-    // run_flag gates the dense fallback (runs when set) and, inverted, the list pass (pointless once the fallback is due)
-    if (run_flag && (MODE == kKeysList ? *run_flag != 0 : *run_flag == 0)) return;
+                                                          const uint32_t* __restrict__ run_flag) {
+    if (run_flag && *run_flag == 0) return;
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [16][qstride] query image, zero-filled past dim / nq_pass;
     uint32_t* stage = reinterpret_cast<uint32_t*>(qs + 16 * qstride) + (threadIdx.x >> 6) * (16 * 32);   // then [wave][16][32] keys
     fill_query_image(qs, queries, 16u, nq_pass, dim, qstride, kBW * 64);   // (dim % 4 == 0, queries 16-byte aligned: blocks_path)
@@ -416,30 +416,19 @@ __global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __re
             h1[c] = in ? __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v1 + 64 * (c0 + c))) : f32x4v{0.f, 0.f, 0.f, 0.f};
         }
     };
-    // work items: every supertile (dense, minima) or the supertiles of the listed chunks (1 << tsh of them per entry)
-    const uint32_t tsh = MODE == kKeysList ? pr.cs_shift - 5 : 0;
-    const size_t items = MODE == kKeysList ? (size_t)*pr.nlist << tsh : supers;
-    auto sup_of = [&](size_t it) -> size_t {
-        if (MODE != kKeysList) return it;
-        return ((size_t)pr.list[it >> tsh].y << tsh) + (it & (((size_t)1 << tsh) - 1));   // (past the last row: clamped loads, keys nobody reads)
-    };
-    size_t it = (size_t)blockIdx.x * kBW + wave;
-    uint32_t wave_min = 0xffffffffu;   // kKeysMins: lane (q, 0) keeps query q's smallest key over this wave's supertiles
-    if (it < items) {
-        const size_t sup0 = sup_of(it);
-        load_half(xa0, xa1, sup0 * 4, 0);
-        load_half(xb0, xb1, sup0 * 4, H);
+    size_t sup = (size_t)blockIdx.x * kBW + wave;
+    if (sup < supers) {
+        load_half(xa0, xa1, sup * 4, 0);
+        load_half(xb0, xb1, sup * 4, H);
     }
     __syncthreads();   // the query image is complete
-    for (; it < items; it += sstep) {
-        const size_t sup = sup_of(it);
-        const size_t sup_next = it + sstep < items ? sup_of(it + sstep) : supers;
+    for (; sup < supers; sup += sstep) {
 #pragma unroll 1
         for (int t = 0; t < 4; t++) {
             const size_t tile = sup * 4 + t;
             // the tile after this one: the supertile's next, or the first of the wave's next supertile (past the end
             // the loads fall on clamped rows and are dropped)
-            const size_t next = t < 3 ? tile + 1 : sup_next * 4;
+            const size_t next = t < 3 ? tile + 1 : (sup + sstep) * 4;
             const bool more = next < tiles;
             const size_t r0 = tile * 8 + j, r1 = r0 + 4;
             const float vn0 = norms[r0 < n ? r0 : n - 1], vn1 = norms[r1 < n ? r1 : n - 1];
@@ -502,35 +491,17 @@ __global__ __launch_bounds__(kBW * 64) void cosine_keys_blocks(const float* __re
                 }
             }
         }
+        // the supertile's keys: 16 queries x 32 rows, two queries (2 x 128 B) per store
         wave_lds_fence();
-        if (MODE == kKeysDense) {
-            // the supertile's keys: 16 queries x 32 rows, two queries (2 x 128 B) per store
-            const size_t row = sup * 32 + (lane & 31);
+        const size_t row = sup * 32 + (lane & 31);
 #pragma unroll
-            for (int qq = 0; qq < 16; qq += 2) {
-                const uint32_t qt = qq + (lane >> 5);
-                const uint32_t key = stage[qt * 32 + (lane & 31)];
-                if (qt < nq_pass && row < n) keys[(size_t)qt * n + row] = key;
-            }
-        } else if (MODE == kKeysMins) {
-            // lane (q, part) = (lane >> 2, lane & 3): eight of query q's 32 keys (rows past n repeat row n - 1: the minimum
-            // does not care), then the quad's four partial minima
-            const uint4 k0 = *reinterpret_cast<const uint4*>(stage + (lane >> 2) * 32 + (lane & 3) * 8);
-            const uint4 k1 = *reinterpret_cast<const uint4*>(stage + (lane >> 2) * 32 + (lane & 3) * 8 + 4);
-            uint32_t m = min(min(min(k0.x, k0.y), min(k0.z, k0.w)), min(min(k1.x, k1.y), min(k1.z, k1.w)));
-            m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-            m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-            if ((lane & 3) == 0) pr.mins[sup * 16 + (lane >> 2)] = m;   // 64 contiguous bytes per supertile (queries past nq_pass: never read)
-            wave_min = min(wave_min, m);
-        } else {
-            const uint32_t qe = pr.list[it >> tsh].x;   // wave-uniform
-            if (lane < 32)
-                pr.ckeys[((it >> tsh) << pr.cs_shift) + ((it & (((size_t)1 << tsh) - 1)) << 5) + lane] = stage[qe * 32 + lane];
+        for (int qq = 0; qq < 16; qq += 2) {
+            const uint32_t qt = qq + (lane >> 5);
+            const uint32_t key = stage[qt * 32 + (lane & 31)];
+            if (qt < nq_pass && row < n) keys[(size_t)qt * n + row] = key;
         }
         wave_lds_fence();
     }
-    if (MODE == kKeysMins && (lane & 3) == 0)
-        pr.wmin[(size_t)(lane >> 2) * ((size_t)gridDim.x * kBW) + (size_t)blockIdx.x * kBW + wave] = wave_min;
 }
 
 // ---- streaming variant for a handful of queries (the reference's own shape: one query per request) ----
@@ -889,9 +860,8 @@ bool blocks_path(const float* rows, uint32_t dim, const float* queries, uint32_t
     return mfma_ok(rows, dim) && dim >= 512 && dim <= 1024 && nq_pass > 4 && nq_pass <= 16 && n >= 4096 &&
            (reinterpret_cast<uintptr_t>(queries) & 15u) == 0;
 }
-template <int MODE>
 void launch_blocks(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
-                   uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag, hipStream_t stream, const CosinePrune& pr) {
+                   uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag, hipStream_t stream) {
     const uint32_t nch = ((dim + 63) / 64 + 1) & ~1u;      // whole chunks, an even number of them
     const uint32_t qstride = nch * 64 + 16;                // >= dim, and 16 mod 64 floats: conflict-free A reads
     const size_t lds = (size_t)16 * qstride * sizeof(float) + (size_t)kBW * 16 * 32 * sizeof(uint32_t);
@@ -902,14 +872,14 @@ void launch_blocks(const float* rows, const float* norms, size_t n, uint32_t dim
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBW * 64), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass, qstride,
-                           keys, run_flag, pr);
+                           keys, run_flag);
     };
-    if (nch <= 2) go(cosine_keys_blocks<2, MODE>);
-    else if (nch <= 4) go(cosine_keys_blocks<4, MODE>);
-    else if (nch <= 6) go(cosine_keys_blocks<6, MODE>);
-    else if (nch <= 8) go(cosine_keys_blocks<8, MODE>);
-    else if (nch <= 12) go(cosine_keys_blocks<12, MODE>);
-    else go(cosine_keys_blocks<16, MODE>);
+    if (nch <= 2) go(cosine_keys_blocks<2>);
+    else if (nch <= 4) go(cosine_keys_blocks<4>);
+    else if (nch <= 6) go(cosine_keys_blocks<6>);
+    else if (nch <= 8) go(cosine_keys_blocks<8>);
+    else if (nch <= 12) go(cosine_keys_blocks<12>);
+    else go(cosine_keys_blocks<16>);
 }
 template <int MODE>
 void launch_mfma(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
@@ -996,7 +966,7 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
         return 0;
     }
     if (blocks_path(rows, dim, queries, nq_pass, n)) {
-        launch_blocks<kKeysDense>(rows, norms, n, dim, queries, qnorm, nq_pass, keys, run_flag, stream, CosinePrune{});
+        launch_blocks(rows, norms, n, dim, queries, qnorm, nq_pass, keys, run_flag, stream);
         return 0;
     }
     if (mfma_ok(rows, dim)) {
@@ -1014,25 +984,21 @@ int launch_cosine_keys(const float* rows, const float* norms, size_t n, uint32_t
 }
 
 // ---- the pass without a key matrix (see CosinePrune) ----
+// Always the 16x16x4 kernel, also at <= 16 queries: without its key stores it is 3 % ahead of the 4x4x1 kernel there (0.62 vs
+// 0.64 ms, 16 queries over 1 M x 768) and its list pass is one tile per entry (28 vs 52 us).
 bool cosine_prune_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k) {
-    // the two row-stream kernels' batches (5 .. 48 queries); corpora large enough that ~k chunks are a sliver of them
-    return nq_pass > 4 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32) &&
-           (blocks_path(rows, dim, queries, nq_pass, n) ||
-            (mfma_ok(rows, dim) && nq_pass <= (uint32_t)16 * mfma_groups(dim) && !gemm_path(rows, dim, queries, nq_pass)));
+    // 5 .. 48 queries; corpora large enough that ~k chunks are a sliver of them; k below the 256 thread minima of prune_bound_kernel
+    return nq_pass > 4 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32) && mfma_ok(rows, dim) &&
+           nq_pass <= (uint32_t)16 * mfma_groups(dim) && !gemm_path(rows, dim, queries, nq_pass);
 }
-CosinePrunePlan cosine_prune_plan(const float* rows, uint32_t dim, const float* queries, size_t n, uint32_t nq_pass, uint32_t k) {
+CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k) {
     CosinePrunePlan p;
-    const bool blocks = blocks_path(rows, dim, queries, nq_pass, n);
-    p.cs_shift = blocks ? 5 : 4;                                 // a supertile of the 4x4x1 kernel / a tile of the 16x16x4 one
-    p.qpad = blocks ? 16u : 16u * ((nq_pass + 15) / 16);
+    p.cs_shift = 4;                                              // a chunk = a 16-row tile
+    p.qpad = 16u * ((nq_pass + 15) / 16);
     p.nchunks = (uint32_t)(((n - 1) >> p.cs_shift) + 1);
-    {   // waves of the minima launch (launch_blocks / launch_mfma size their grids the same way)
-        const size_t units = blocks ? (n + 31) / 32 : (n + 15) / 16;
-        const unsigned wpb = blocks ? kBW : kCW, most = blocks ? 256u : 256u * 4;
-        unsigned grid = (unsigned)((units + wpb - 1) / wpb);
-        if (grid > most) grid = most;
-        p.waves = grid * wpb;
-    }
+    unsigned grid = (unsigned)(((size_t)p.nchunks + kCW - 1) / kCW);   // as launch_mfma sizes it
+    if (grid > 256 * 4) grid = 256 * 4;
+    p.waves = grid * kCW;
     p.capq = (2 * k + 31) & ~31u;                                // chunks listed per query: k of them beat the threshold, ties add a few
     if (p.capq < 32) p.capq = 32;
     return p;
@@ -1045,10 +1011,7 @@ int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uin
     pr.wmin = wmin;
     pr.qpad = p.qpad;
     pr.cs_shift = p.cs_shift;
-    if (p.cs_shift == 5)
-        launch_blocks<kKeysMins>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, nullptr, stream, pr);
-    else
-        launch_mfma<kKeysMins>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, nullptr, stream, pr);
+    launch_mfma<kKeysMins>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, nullptr, stream, pr);
     return 0;
 }
 int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
@@ -1060,10 +1023,15 @@ int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uin
     pr.list = reinterpret_cast<const uint2*>(list);
     pr.nlist = nlist;
     pr.ckeys = ckeys;
-    if (p.cs_shift == 5)
-        launch_blocks<kKeysList>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, fallback_flag, stream, pr);
-    else
-        launch_mfma<kKeysList>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, fallback_flag, stream, pr);
+    launch_mfma<kKeysList>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, fallback_flag, stream, pr);
+    return 0;
+}
+// the dense keys of the same kernel (the gated fallback of the pass above: same arithmetic, so the answer does not depend on
+// which of the two produced it)
+int launch_cosine_keys_dense_mfma(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
+                                  const float* qnorm, uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag,
+                                  hipStream_t stream) {
+    launch_mfma<kKeysDense>(rows, norms, n, dim, queries, qnorm, nq_pass, keys, run_flag, stream, CosinePrune{});
     return 0;
 }
 

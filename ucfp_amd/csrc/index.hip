@@ -281,8 +281,7 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     off = align256(off + ucfp::select_pruned_ws_bytes(n, 16));
     // the pass without a key matrix (5 .. 48 queries): chunk minima, thresholds, listed chunks, their keys
     // (sized for either row-stream kernel: chunks of 16 rows, 48 padded queries)
-    const uint32_t p_capq = ucfp::cosine_prune_plan(reinterpret_cast<const float*>(s->rows), dim,
-                                                    reinterpret_cast<const float*>(d_queries), n, (uint32_t)fq, k).capq;
+    const uint32_t p_capq = ucfp::cosine_prune_plan(n, (uint32_t)fq, k).capq;
     const size_t o_pmin = off;
     off = align256(off + (n / 16 + 1) * 48 * 4 + 64);
     const size_t o_pwmin = off;
@@ -296,7 +295,7 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     const size_t o_prange = off;
     off = align256(off + fq * 8);
     const size_t o_pkeys = off;
-    off = align256(off + fq * p_capq * 32 * 4);
+    off = align256(off + fq * p_capq * 16 * 4);
     const size_t o_pflag = off;   // [0] fallback flag, [1] listed chunks
     off = align256(off + 256);
     int rc = ix->ws_slot[ix->ws_cur].ensure(off);
@@ -379,7 +378,7 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
             // one pass of 5 .. 48 queries: no key matrix (cosine.hip CosinePrune).  The dense pass and its selection follow,
             // gated on the flag the pruned pass raises when a query's ties outgrow its chunk list.
             const uint32_t np = (uint32_t)qc;
-            const ucfp::CosinePrunePlan pp = ucfp::cosine_prune_plan(rows, dim, q + q0 * dim, n, np, k);
+            const ucfp::CosinePrunePlan pp = ucfp::cosine_prune_plan(n, np, k);
             uint32_t* pflag = reinterpret_cast<uint32_t*>(w + o_pflag);
             uint32_t* pmin = reinterpret_cast<uint32_t*>(w + o_pmin);
             uint32_t* ptau = reinterpret_cast<uint32_t*>(w + o_ptau);
@@ -388,13 +387,14 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
             uint32_t* ok = okeys + q0 * k;
             uint32_t* oc = d_out_cnt + q0;
             HIP_TRY(hipMemsetAsync(pflag, 0, 8, st));
+            if (getenv("UCFP_COSINE_PRUNE_FALLBACK")) HIP_TRY(hipMemsetAsync(pflag, 1, 1, st));   // tests: the gated dense pass answers
             uint32_t* pwmin = reinterpret_cast<uint32_t*>(w + o_pwmin);
             ucfp::launch_cosine_keys_mins(rows, s->norms, n, dim, q + q0 * dim, qn + q0, np, pp, pmin, pwmin, st);
             ucfp::launch_prune_tau(pmin, pwmin, pp, np, k, w + o_ptws, ptau, w + o_plist, pflag + 1, w + o_prange, pflag, st);
             ucfp::launch_cosine_keys_list(rows, s->norms, n, dim, q + q0 * dim, qn + q0, np, pp, w + o_plist, pflag + 1, pkeys,
                                           pflag, st);
             ucfp::launch_prune_final(pkeys, pp, w + o_plist, w + o_prange, ptau, s->ids, n, np, k, oi, ok, oc, pflag, st);
-            ucfp::launch_cosine_keys(rows, s->norms, n, dim, q + q0 * dim, qn + q0, np, keymat, st, pflag);
+            ucfp::launch_cosine_keys_dense_mfma(rows, s->norms, n, dim, q + q0 * dim, qn + q0, np, keymat, pflag, st);
             select_merge(n, np, oi, ok, oc, pflag);
             continue;
         }

@@ -84,8 +84,8 @@ def main():
         else:
             n = int(rng.choice([900, 5000, 40_000, 270_000, 600_000]))
             dim = int(rng.choice([32, 64, 100, 256, 384, 512, 768, 1024]))
-            nq = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 40, 49, 130, 300]))
-            k = int(rng.choice([1, 10, 20]))
+            nq = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 17, 33, 40, 48, 49, 130, 300]))
+            k = int(rng.choice([1, 10, 20, 50, 64]))
             if n * dim > 250_000_000:
                 n = 250_000_000 // dim
             g = torch.Generator(device=dev)

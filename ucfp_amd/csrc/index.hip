@@ -281,11 +281,15 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     off = align256(off + ucfp::select_pruned_ws_bytes(n, 16));
     // the pass without a key matrix (5 .. 48 queries): chunk minima, thresholds, listed chunks, their keys
     // (sized for either row-stream kernel: chunks of 16 rows, 48 padded queries)
+    // (only when the call can take that pass: one pass of <= 48 queries; 12 bytes per row)
+    const bool may_prune = nq <= 48 && nq <= (size_t)qpp &&
+                           ucfp::cosine_prune_ok(reinterpret_cast<const float*>(s->rows), dim,
+                                                 reinterpret_cast<const float*>(d_queries), (uint32_t)nq, n, k);
     const uint32_t p_capq = ucfp::cosine_prune_plan(n, (uint32_t)fq, k).capq;
     const size_t o_pmin = off;
-    off = align256(off + (n / 16 + 1) * 48 * 4 + 64);
+    off = align256(off + (may_prune ? (n / 16 + 1) * 48 * 4 + 64 : 0));
     const size_t o_pwmin = off;
-    off = align256(off + (size_t)48 * 256 * 4 * 8 * 4);   // [qpad <= 48][waves <= 8192]
+    off = align256(off + (may_prune ? (size_t)48 * 256 * 4 * 8 * 4 : 0));   // [qpad <= 48][waves <= 8192]
     const size_t o_ptws = off;
     off = align256(off + ucfp::prune_tau_ws_bytes((uint32_t)fq));
     const size_t o_ptau = off;
@@ -373,7 +377,7 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
             }
             continue;
         }
-        if (qc <= (size_t)qpp && !getenv("UCFP_COSINE_NO_PRUNE") &&
+        if (may_prune && qc <= (size_t)qpp && !getenv("UCFP_COSINE_NO_PRUNE") &&
             ucfp::cosine_prune_ok(rows, dim, q + q0 * dim, (uint32_t)qc, n, k)) {
             // one pass of 5 .. 48 queries: no key matrix (cosine.hip CosinePrune).  The dense pass and its selection follow,
             // gated on the flag the pruned pass raises when a query's ties outgrow its chunk list.

@@ -676,6 +676,8 @@ def _bench_ann_run(args, rank, world, dev, ctx, six, queries, cpu_sample, corpus
                      "unit": "TFLOP/s per GPU (FP4 MFMA, f32 accumulate, 128 ops per code-query pair; whole search "
                              "incl. staging, rescan and selection)",
                      "frac": pairs_per_s * ops_per_pair / world / fp4_peak,
+                     # the same with ONE search in flight (ms_per_batch_one_at_a_time): what a lone batch sees
+                     "frac_one_at_a_time": nq * n_local * ops_per_pair / t_seq / fp4_peak,
                      "frac_of_int8_peak": pairs_per_s * ops_per_pair / world / i8_peak,
                      "matrix_pipe_busy_pmc": 0.80, "clock_GHz_pmc": 1.86,
                      "T_pairs_per_s_per_gpu": pairs_per_s / world / 1e12,
@@ -923,7 +925,7 @@ def bench_cosine(args, rank, world, dev, ctx):
     ix = index.DeviceIndex(index.COSINE_F32, dim, index.APPEND_ONLY, ctx)
     ix.append_dev(0, ids.data_ptr(), rows.data_ptr(), n, stream)
     out = {}
-    for nq in (1, 16, 256):
+    for nq in (1, 16, 32, 48, 256):
         q = torch.randn((nq, dim), dtype=torch.float32, device=dev, generator=g)
         o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
         o_sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
@@ -959,7 +961,7 @@ def bench_cosine(args, rank, world, dev, ctx):
         del rn
         # 1 / 16 queries read the rows once per pass: HBM-bound; the 256-query pass is one f32 GEMM: MFMA-bound
         # (157.3 TF dense f32 matrix peak, MI355X_MICROARCH.md); whole search = keys + selection
-        if nq <= 16:
+        if nq <= 48:     # one pass over the rows (5 .. 48 queries: no key matrix, cosine.hip CosinePrune)
             roof = {"bound": "hbm", "achieved": n * dim * 4 / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": n * dim * 4 / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes": "4 x dim x rows per pass (SURVEY 8d)"}

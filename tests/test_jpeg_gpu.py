@@ -178,3 +178,22 @@ def test_micro_batcher_for_jpeg_uploads(gpu_ctx, oracle):
     assert st == image.NEEDS_HOST and not any(rec)
     assert b.stats()[1] == len(files) + 1
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,n,quality,sub", [(768, 6, 92, 2), (1024, 5, 85, 0), (1024, 300, 92, 2), (512, 40, 95, 1), (640, 700, 80, 2)])
+def test_large_files_take_several_waves(gpu_ctx, side, n, quality, sub):
+    """Batches whose files average more than 24 KB run the speculative decoder with 2 or 4 waves (128 / 256 subsequences) per
+    file -- 8 for batches of at most 256 large files -- (jpeg.hip launch_jpeg_decode): block scans and the chain walk then cross waves.  Planes must equal libjpeg's."""
+    from ucfp_amd import image
+    base = picture(side, side, seed=n)
+    files, want = [], []
+    for i in range(n):
+        img = np.roll(base, (7 * i, 13 * i), axis=(0, 1)) if i % 5 else picture(side, side, seed=n + i)
+        j = jpeg_of(img, quality=quality, subsampling=sub)
+        files.append(j)
+        want.append(libjpeg_luma(j))
+    planes, status = image.decode_jpegs(files, side, side, ctx=gpu_ctx)
+    assert not status.any(), status
+    for i in range(n):
+        assert np.array_equal(planes[i], want[i]), i

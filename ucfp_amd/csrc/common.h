@@ -52,6 +52,7 @@ int launch_png_merge_status(const uint8_t* ws, const PngWs& l, size_t n, uint8_t
 // jpeg.hip
 struct JpegWs {
     size_t clean = 0, info = 0, seg = 0, qtab = 0, coef = 0, coef_stride = 0, total = 0;
+    size_t jpg_bytes = 0;   // the batch's encoded bytes (picks the decoder's waves per file)
     uint32_t bxp = 0, byp = 0, max_seg = 0;
 };
 size_t jpeg_ws_bytes(size_t n, size_t jpg_bytes, uint32_t w, uint32_t h, JpegWs* ws);

@@ -481,11 +481,20 @@ struct SpecCand {
     uint16_t b, k;
     uint32_t done;
 };
-struct SpecLds : HuffTables {
+struct SpecTables : HuffTables {
     uint8_t comp_of[8], ybi_of[8];                       // block of the MCU -> component, index among the luma blocks
-    SpecCand c0[64][kSpecMaxB];                          // round 0: a lane's exit for each guessed block phase
-    SpecCand m1[64][kSpecMaxB];                          // round 1: a lane's exit when entered with its predecessor's j-th exit
-    SpecCand tin[64];                                    // the walk: every lane's TRUE entry (done: its blocks completed)
+};
+// NW waves per file = 64 NW subsequences ("lanes" below are the workgroup's threads).  One wave for files of a few KB --
+// shorter subsequences no longer fall into step inside themselves --; 2, 4 or 8 for larger files in batches that cannot fill
+// the chip with one wave each (launch_jpeg_decode picks by the batch's mean file size): a 1024 x 1024 file is 27 ms on one
+// wave whatever the batch.
+template <int NW>
+struct SpecLds : SpecTables {
+    SpecCand c0[64 * NW][kSpecMaxB];                     // round 0: a lane's exit for each guessed block phase
+    SpecCand m1[64 * NW][kSpecMaxB];                     // round 1: a lane's exit when entered with its predecessor's j-th exit
+    SpecCand tin[64 * NW];                               // the walk: every lane's TRUE entry (done: its blocks completed)
+    uint32_t wsum[8];                                    // block scans: the waves' totals
+    uint32_t flag;                                       // block-wide "some lane failed"
 };
 
 struct SpecState {
@@ -496,7 +505,7 @@ struct SpecState {
 // One subsequence: symbols that BEGIN before end_bit, from the state st.  OUT = false: states only (the speculation
 // rounds); OUT = true: coefficients of luma blocks are stored as well.
 template <bool OUT>
-__device__ __forceinline__ void spec_run(const SpecLds& L, const uint32_t* __restrict__ cw, SpecState st, uint32_t end_bit,
+__device__ __forceinline__ void spec_run(const SpecTables& L, const uint32_t* __restrict__ cw, SpecState st, uint32_t end_bit,
                                          uint32_t data_bits, uint32_t B, uint32_t hs0, uint32_t hmax, uint32_t vmax, uint32_t mx,
                                          uint32_t bxp, uint32_t blk_abs, uint32_t blk_total, int16_t* __restrict__ cplane,
                                          SpecState& out, uint32_t& done, bool& err) {
@@ -575,21 +584,55 @@ __device__ __forceinline__ void spec_run(const SpecLds& L, const uint32_t* __res
     if (err) out.pos = 0xffffffffu;        // (a speculative parse that ran into nonsense: a state no true parse has)
 }
 
-__global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void jpeg_huff_spec_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
                                                            uint32_t width, uint32_t height, const uint8_t* __restrict__ clean,
                                                            JpgInfo* __restrict__ info, int16_t* __restrict__ coef, size_t coef_stride,
                                                            uint32_t bxp, uint16_t* __restrict__ qtab) {
-    __shared__ SpecLds L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t spec_lds[];   // (dynamic: 89 KiB at eight waves)
+    SpecLds<NW>& L = *reinterpret_cast<SpecLds<NW>*>(spec_lds);
+    constexpr int T = 64 * NW;                            // subsequences = threads
     const size_t img = blockIdx.x;
     if (img >= n) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;                         // 0 .. T - 1: the subsequence this thread owns
+    const int wlane = lane & 63, wave = lane >> 6;
+    auto block_sync = [&]() {
+        if (NW == 1) wave_lds_sync();
+        else __syncthreads();
+    };
+    // inclusive scan over the workgroup's threads; total = the sum of all
+    auto block_scan = [&](uint32_t v, uint32_t& total) -> uint32_t {
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (wlane >= off) incl += o;
+        }
+        if (NW == 1) {
+            total = (uint32_t)__shfl((int)incl, 63, 64);
+            return incl;
+        }
+        if (wlane == 63) L.wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t t = L.wsum[w];
+            before += w < wave ? t : 0u;
+            all += t;
+        }
+        __syncthreads();
+        total = all;
+        return incl + before;
+    };
     const JpgInfo J = info[img];
     if (J.status != 0 || !jpeg_takes_spec(J)) return;
     const uint8_t* p = jpg + offsets[img];
-    build_tables(L, J, p, lane, qtab + img * 64);
+    if (wave == 0) build_tables(L, J, p, wlane, qtab + img * 64);
     const uint32_t nby = J.ncomp == 1 ? 1u : (uint32_t)J.hs[0] * J.vs[0];
     const uint32_t nb1 = J.ncomp == 3 ? (uint32_t)J.hs[1] * J.vs[1] : 0u;
     const uint32_t B = jpeg_blocks_per_mcu(J);
+    if (lane == 0) L.flag = 0;
     if (lane < (int)B) {
         L.comp_of[lane] = (uint32_t)lane < nby ? 0 : (uint32_t)lane < nby + nb1 ? 1 : 2;
         L.ybi_of[lane] = (uint8_t)lane;
@@ -600,10 +643,10 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(clean + ((offsets[img] + 15) & ~(uint64_t)15));
     int16_t* cplane = coef + img * coef_stride;
     // the luma blocks' coefficients not written below are zero
-    for (size_t i = (size_t)lane * 8; i < coef_stride; i += 64 * 8) *reinterpret_cast<uint4*>(cplane + i) = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)lane * 8; i < coef_stride; i += T * 8) *reinterpret_cast<uint4*>(cplane + i) = make_uint4(0, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t data_bits = J.clean_len * 8;
-    uint32_t S = (data_bits + 63) / 64;
+    uint32_t S = (data_bits + T - 1) / T;
     S = (S + 31) & ~31u;
     const uint32_t my0 = (uint32_t)lane * S, my1 = my0 + S < data_bits ? my0 + S : data_bits;
     const bool live = my0 < data_bits;
@@ -620,7 +663,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
     auto run0 = [&](const SpecState& en) {
         spec_run<false>(L, cw, en, my1, data_bits, B, hs0, hmax, vmax, mx, bxp, 0u, ~0u, nullptr, exit_, done, err);
     };
-    wave_lds_sync();
+    block_sync();
     // ---- round 0: every block phase, over the tail of the subsequence (lane 0: its one true entry, the whole of it)
     const uint32_t tail0 = my1 - my0 > kSpecTail ? my1 - kSpecTail : my0;
     for (uint32_t h = 0; h < B; h++) {
@@ -632,7 +675,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
     }
     if (lane == 0)
         for (uint32_t h = 1; h < B; h++) L.c0[0][h] = L.c0[0][0];
-    wave_lds_sync();
+    block_sync();
     // ---- round 1: the whole subsequence from each candidate exit of the predecessor
     for (uint32_t jx = 0; jx < B; jx++) {
         if (live && lane > 0) {
@@ -646,7 +689,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
             L.m1[lane][jx] = res;
         }
     }
-    wave_lds_sync();
+    block_sync();
     // ---- the walk (every lane runs it on the same LDS words: wave-uniform)
     SpecCand t = L.c0[0][0];                                  // lane 0's true exit
     if (lane == 0) L.tin[0] = SpecCand{0u, 0, 0, t.done};
@@ -671,13 +714,13 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
             ex = L.m1[i][hit];
         } else {
             // nobody guessed lane i's true entry: that lane parses once more
-            wave_lds_sync();
+            block_sync();
             if ((uint32_t)lane == i) {
                 const SpecState en = {t.pos, t.b, t.k};
                 run0(en);
                 put(L.m1[i][0], exit_, done);
             }
-            wave_lds_sync();
+            block_sync();
             ex = L.m1[i][0];
         }
         if (lane == 0) L.tin[i] = SpecCand{t.pos, t.b, t.k, ex.done};
@@ -686,25 +729,23 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
         if (ex.pos == 0xffffffffu && cum < blk_total) bad = true;
         t = ex;                                               // ... and the true entry of lane i + 1
     }
-    wave_lds_sync();
+    block_sync();
     uint32_t blk_done = 0;
     if (!bad) {
         const SpecCand mine_in = L.tin[live ? lane : 0];
         const SpecState entry = {mine_in.pos, mine_in.b, mine_in.k};
         // ---- block numbers, then the real decode
-        uint32_t incl = live ? mine_in.done : 0u;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-            if (lane >= off) incl += o;
-        }
+        uint32_t total_done;
+        const uint32_t incl = block_scan(live ? mine_in.done : 0u, total_done);
         const uint32_t my_abs = incl - (live ? mine_in.done : 0u);
         uint32_t done2 = 0;
         bool err2 = false;
         SpecState ex2 = exit_;
         if (live) spec_run<true>(L, cw, entry, my1, data_bits, B, hs0, hmax, vmax, mx, bxp, my_abs, blk_total, cplane, ex2, done2, err2);
-        if (__ballot(live && err2)) bad = true;
-        blk_done = (uint32_t)__shfl((int)incl, 63, 64);
+        if (live && err2) L.flag = 1;
+        block_sync();
+        if (L.flag) bad = true;
+        blk_done = total_done;
     }
     if (blk_done < blk_total) bad = true;                 // the data ended before the last block
     if (bad) {
@@ -713,22 +754,17 @@ __global__ __launch_bounds__(64) void jpeg_huff_spec_kernel(const uint8_t* __res
     }
     // ---- DC differences -> DC values: prefix sum over the luma blocks in decoding order (MCU by MCU)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t ny = mx * my * nby, run = (ny + 63) / 64;
+    const uint32_t ny = mx * my * nby, run = (ny + T - 1) / T;
     auto addr_of = [&](uint32_t o) -> int16_t* {
         const uint32_t m = o / nby, bi = o % nby;
         const uint32_t bx = (m % mx) * hmax + bi % hs0, by = (m / mx) * vmax + bi / hs0;
         return cplane + ((size_t)by * bxp + bx) * 64;
     };
-    const uint32_t o0 = (uint32_t)lane * run, o1 = o0 + run < ny ? o0 + run : ny;
+    const uint32_t o0 = (uint32_t)lane * run < ny ? (uint32_t)lane * run : ny, o1 = o0 + run < ny ? o0 + run : ny;
     int sum = 0;
     for (uint32_t o = o0; o < o1; o++) sum += addr_of(o)[0];
-    int incl2 = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl2, off, 64);
-        if (lane >= off) incl2 += v;
-    }
-    int acc_dc = incl2 - sum;
+    uint32_t dc_total;
+    int acc_dc = (int)block_scan((uint32_t)sum, dc_total) - sum;      // (two's complement: the wrapping sums are the signed ones)
     for (uint32_t o = o0; o < o1; o++) {
         int16_t* a = addr_of(o);
         acc_dc += a[0];
@@ -872,6 +908,7 @@ size_t jpeg_ws_bytes(size_t n, size_t jpg_bytes, uint32_t w, uint32_t h, JpegWs*
         off += (bytes + 255) & ~(size_t)255;
         return at;
     };
+    l.jpg_bytes = jpg_bytes;
     l.clean = take(jpg_bytes + 16 + 64 + 512);
     l.info = take(n * sizeof(JpgInfo));
     l.seg = take(n * (size_t)(l.max_seg + 2) * 4);
@@ -894,8 +931,21 @@ int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, ui
                        seg, info);
     hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h, l.max_seg,
                        (const uint8_t*)(ws + l.clean), (const uint32_t*)seg, info, coef, l.coef_stride, l.bxp, qtab);
-    hipLaunchKernelGGL(jpeg_huff_spec_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h,
+    {
+        // waves per file of the speculative decoder: one for files of a few KB or batches that fill the chip anyway
+        const size_t mean = l.jpg_bytes / n;
+        const int nw = (n >= 2048 || mean < 24 * 1024) ? 1 : (n >= 1024 || mean < 64 * 1024) ? 2 : (n > 256 || mean < 128 * 1024) ? 4 : 8;
+        auto go = [&](auto kern, int threads, size_t lds) {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(threads), lds, stream, jpg, offsets, n, w, h,
                        (const uint8_t*)(ws + l.clean), info, coef, l.coef_stride, l.bxp, qtab);
+        };
+        if (nw == 1) go(jpeg_huff_spec_kernel<1>, 64, sizeof(SpecLds<1>));
+        else if (nw == 2) go(jpeg_huff_spec_kernel<2>, 128, sizeof(SpecLds<2>));
+        else if (nw == 4) go(jpeg_huff_spec_kernel<4>, 256, sizeof(SpecLds<4>));
+        else go(jpeg_huff_spec_kernel<8>, 512, sizeof(SpecLds<8>));
+    }
     const size_t blocks = n * (size_t)l.bxp * l.byp;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, stream, (const JpgInfo*)info, n, w, h,
                        (const int16_t*)coef, l.coef_stride, l.bxp, l.byp, (const uint16_t*)qtab, frames, row_stride,

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
 // find the block PHASE b by itself (which of the MCU's B blocks -- hence which Huffman tables -- comes next), and a parse in
 // the wrong phase never settles (measured: a chain that only guessed phase 0 needed one round per lane, 3 x slower than the
 // serial decode).  So:
-//   round 0   lane i parses the LAST kSpecTail bits of its subsequence B times, once per phase h, from (start, h, k = 0):
+//   round 0   lane i parses the TAIL of its subsequence (about kSpecTailBlocks blocks' worth of bits) B times, once per phase h, from (start, h, k = 0):
 //             B candidate exit states, one of which is (almost always) the state the true parse leaves the subsequence with;
 //   round 1   lane i parses its whole subsequence from EACH candidate exit of lane i - 1;
 //   walk      lane 0's entry is known; following the chain -- "my true entry is my predecessor's true exit: look up what I
@@ -467,7 +467,11 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
 // waves per CU); the bit stream fetched eight dwords ahead instead of one (-10 %: the reader does not wait for memory, the
 // extra register shuffling costs).
 constexpr uint32_t kSpecMaxB = 6;                        // blocks per MCU this path takes (4:2:0 and 4:1:1 have 6)
-constexpr uint32_t kSpecTail = 768;                      // bits of a subsequence the phase guesses of round 0 parse
+// What the phase guesses of round 0 parse: the last ~10 blocks' worth of bits of a subsequence (the file's mean bits per block
+// x 10, at least 384 bits).  A fixed 768 bits was 10 blocks of a quality-95 4:4:4 file but 16 of a config-1 file: 512 bits
+// measured +5 % on 1000 and 8000 config-1 files and -5 % on the quality-95 ones, 384 bits +9 % / +10 % and -14 % (more lanes
+// whose true entry nobody guessed: each costs a serial parse).
+constexpr uint32_t kSpecTailBlocks = 10, kSpecTailMin = 384;
 
 __device__ __forceinline__ uint32_t jpeg_blocks_per_mcu(const JpgInfo& J) {
     return J.ncomp == 1 ? 1u : (uint32_t)J.hs[0] * J.vs[0] + (uint32_t)J.hs[1] * J.vs[1] + (uint32_t)J.hs[2] * J.vs[2];
@@ -665,7 +669,9 @@ __global__ __launch_bounds__(64 * NW) void jpeg_huff_spec_kernel(const uint8_t* 
     };
     block_sync();
     // ---- round 0: every block phase, over the tail of the subsequence (lane 0: its one true entry, the whole of it)
-    const uint32_t tail0 = my1 - my0 > kSpecTail ? my1 - kSpecTail : my0;
+    uint32_t tail_bits = (uint32_t)(((uint64_t)data_bits * kSpecTailBlocks / (blk_total ? blk_total : 1u) + 31u) & ~31ull);
+    tail_bits = tail_bits < kSpecTailMin ? kSpecTailMin : tail_bits;
+    const uint32_t tail0 = my1 - my0 > tail_bits ? my1 - tail_bits : my0;
     for (uint32_t h = 0; h < B; h++) {
         if (live && (lane > 0 || h == 0)) {
             const SpecState en = {lane == 0 ? 0u : tail0, lane == 0 ? 0u : h, 0u};

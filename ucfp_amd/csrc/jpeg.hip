@@ -31,6 +31,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ucfp_hip.h"
 #include "common.h"
@@ -488,10 +489,9 @@ struct SpecCand {
 struct SpecTables : HuffTables {
     uint8_t comp_of[8], ybi_of[8];                       // block of the MCU -> component, index among the luma blocks
 };
-// NW waves per file = 64 NW subsequences ("lanes" below are the workgroup's threads).  One wave for files of a few KB --
-// shorter subsequences no longer fall into step inside themselves --; 2, 4 or 8 for larger files in batches that cannot fill
-// the chip with one wave each (launch_jpeg_decode picks by the batch's mean file size): a 1024 x 1024 file is 27 ms on one
-// wave whatever the batch.
+// NW waves per file = 64 NW subsequences ("lanes" below are the workgroup's threads): 2, 4 or 8 in batches that cannot fill
+// the chip with one wave per file, as long as a subsequence keeps >= 256 bits (launch_jpeg_decode): a 1024 x 1024 file is
+// 27 ms on one wave whatever the batch, 8.8 on eight.
 template <int NW>
 struct SpecLds : SpecTables {
     SpecCand c0[64 * NW][kSpecMaxB];                     // round 0: a lane's exit for each guessed block phase
@@ -938,9 +938,12 @@ int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, ui
     hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h, l.max_seg,
                        (const uint8_t*)(ws + l.clean), (const uint32_t*)seg, info, coef, l.coef_stride, l.bxp, qtab);
     {
-        // waves per file of the speculative decoder: one for files of a few KB or batches that fill the chip anyway
-        const size_t mean = l.jpg_bytes / n;
-        const int nw = (n >= 2048 || mean < 24 * 1024) ? 1 : (n >= 1024 || mean < 64 * 1024) ? 2 : (n > 256 || mean < 128 * 1024) ? 4 : 8;
+        // waves per file of the speculative decoder: as many as keep the batch within the chip's ~2048 wave slots and a
+        // subsequence at >= 256 bits (measured on 9 KB config-1 files, images/s at 1 | 2 | 4 waves: 1000 files 458 k | 556 k |
+        // 438 k, 500 files 252 k | 310 k | 387 k, 250 files 132 k | 172 k | 212 k)
+        const size_t mean_bits = l.jpg_bytes / n * 8;
+        int nw = 1;
+        while (nw < 8 && n * (size_t)nw * 2 <= 2048 && mean_bits / (64 * (size_t)nw * 2) >= 256) nw *= 2;
         auto go = [&](auto kern, int threads, size_t lds) {
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -436,6 +436,7 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
     try:
         setup_err = None
         codes, ids, queries = _ann_inputs(torch, dev, rank, world, n_local, start, end, nq)
+        _ann_plant(torch, codes, queries, start, end, corpus_total)
     except Exception as e:   # noqa: BLE001
         setup_err = e
     agree(setup_err, "corpus generation")
@@ -454,21 +455,46 @@ def bench_ann(args, rank, world, dev, ctx, corpus_total=None):
     return _bench_ann_run(args, rank, world, dev, ctx, six, queries, cpu_sample, corpus_total, n_local, agree)
 
 
+def ann_corpus_codes(torch, dev, start, end):
+    """code of GLOBAL row i = one xorshift64* step from the state (0x5EED, i) -- a function of the
+    global index alone, so the union of the shards is the same corpus at every world size.  int64 arithmetic wraps like
+    uint64; logical right shifts are arithmetic shifts with the sign extension masked off."""
+    out = torch.empty((end - start,), dtype=torch.int64, device=dev)
+    step = 1 << 24
+    for lo in range(start, end, step):
+        hi = min(end, lo + step)
+        x = torch.arange(lo + 1, hi + 1, dtype=torch.int64, device=dev) * -7046029254386353131     # 0x9E3779B97F4A7C15
+        x ^= 0x5EED
+        x ^= (x >> 12) & ((1 << 52) - 1)
+        x ^= x << 25
+        x ^= (x >> 27) & ((1 << 37) - 1)
+        out[lo - start:hi - start] = x * 2685821657736338717                                         # 0x2545F4914F6CDD1D
+    return out
+
+
+def ann_planted(nq, corpus_total):
+    """(query j, global row) of the planted neighbours: every second query, rows spread over the whole corpus by a
+    multiplicative hash of j -- global positions, so the same rows at every world size."""
+    return [(j, (j * 2654435761 + 12345) % corpus_total) for j in range(0, nq, 2)]
+
+
 def _ann_inputs(torch, dev, rank, world, n_local, start, end, nq):
-    g = torch.Generator(device=dev)
-    g.manual_seed(0x5EED + rank)
-    codes = torch.randint(-2**63, 2**63 - 1, (n_local,), dtype=torch.int64, device=dev, generator=g)
+    codes = ann_corpus_codes(torch, dev, start, end)
     ids = torch.arange(start, end, dtype=torch.int64, device=dev)
     gq = torch.Generator(device=dev)
     gq.manual_seed(0xC0FFEE)
     queries = torch.randint(-2**63, 2**63 - 1, (nq,), dtype=torch.int64, device=dev, generator=gq)
-    # plant a true neighbour (Hamming <= 3) for every second query, spread over the shards
-    for j in range(0, nq, 2):
-        owner = (j // 2) % world
-        if owner == rank and n_local:
-            pos = (j * 7919) % n_local
-            codes[pos] = queries[j] ^ (1 << (j % 61)) ^ (1 << ((j * 3) % 59))
+    # plant a true neighbour (two bit flips) for every second query, at GLOBAL rows: the owner of the row writes it
     return codes, ids, queries
+
+
+def _ann_plant(torch, codes, queries, start, end, corpus_total):
+    pl = [(j, pos) for j, pos in ann_planted(queries.numel(), corpus_total) if start <= pos < end]
+    if pl:
+        jj = torch.tensor([j for j, _ in pl], dtype=torch.int64, device=codes.device)
+        pp = torch.tensor([pos - start for _, pos in pl], dtype=torch.int64, device=codes.device)
+        flips = torch.tensor([(1 << (j % 61)) ^ (1 << ((j * 3) % 59)) for j, _ in pl], dtype=torch.int64, device=codes.device)
+        codes[pp] = queries[jj] ^ flips
 
 
 def _bench_ann_run(args, rank, world, dev, ctx, six, queries, cpu_sample, corpus_total, n_local, agree):
@@ -528,6 +554,20 @@ def _bench_ann_run(args, rank, world, dev, ctx, six, queries, cpu_sample, corpus
     dt, out = timed_pipeline()
     out_ids, _, out_keys, out_cnt = out
     planted_found = int((out_keys[0::2, 0] <= 3).sum().item())
+    # every rank holds the full answer after the merge: a CRC of the last batch's ids || keys, equal on every rank and --
+    # the corpus being a function of the global row -- equal at every world size for the same --ann-corpus
+    import zlib
+    answers_crc = zlib.crc32(out_keys.cpu().numpy().tobytes(), zlib.crc32(out_ids.cpu().numpy().tobytes())) & 0xffffffff
+    print(f"[bench ann] rank {rank}/{world} corpus {corpus_total} shard {n_local} answers_crc {answers_crc:08x} "
+          f"planted {planted_found}/{(nq + 1) // 2} {dt / args.ann_steps * 1e3:.3f} ms/batch", file=sys.stderr, flush=True)
+    if world > 1:
+        crcs = torch.tensor([answers_crc], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        lo, hi = crcs.clone(), crcs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        crc_same = bool(int(lo.item()) == int(hi.item()))
+    else:
+        crc_same = True
     # the exchange step alone ("all-gather time separately"): the same batches searched one at a time
     # (submit + collect back to back, so the all-gather + merge is NOT hidden under the next scan) minus the bare
     # shard scan through ucfp_index_search_dev
@@ -683,6 +723,12 @@ def _bench_ann_run(args, rank, world, dev, ctx, six, queries, cpu_sample, corpus
                      "T_pairs_per_s_per_gpu": pairs_per_s / world / 1e12,
                      "hbm_GBs_per_gpu": ((nq + 4095) // 4096) * n_local * 8 / (dt / args.ann_steps) / 1e9},
         "planted_neighbours_found": f"{planted_found}/{(nq + 1) // 2}",
+        # CRC-32 of the last batch's out_ids || out_keys; the corpus is a function of the GLOBAL row (ann_corpus_codes), so
+        # this value is the same at N = 1, 2, 4, 8 for the same --ann-corpus / --ann-queries: an N > 1 run verifies itself
+        # against the N = 1 line
+        "answers_crc": f"{answers_crc:08x}", "answers_crc_equal_on_all_ranks": crc_same,
+        "corpus": "code(i) = xorshift64*((i + 1) * 0x9E3779B97F4A7C15 ^ 0x5EED), i = global row; shard g = rows "
+                  "[g n / G, (g + 1) n / G); a neighbour two bit flips away planted for every second query at a global row",
     }
 
 
@@ -1349,13 +1395,16 @@ def main():
             ann10 = bench_ann(args, rank, world, dev, ctx, corpus_total=10_000_000)
             # one GPU: the shard a rank holds when the 100 M corpus is spread over 8 GPUs (what the 8-GPU point runs per rank)
             ann12 = bench_ann(args, rank, world, dev, ctx, corpus_total=12_500_000) if world == 1 else None
+            # ... and the shard a rank holds at "@10M corpus" on 8 GPUs (where the fixed stages of a search weigh most)
+            ann1m = bench_ann(args, rank, world, dev, ctx, corpus_total=1_250_000) if world == 1 else None
         except Exception as e:   # noqa: BLE001
-            ann = ann10 = ann12 = {"error": f"{type(e).__name__}: {e}"}
+            ann = ann10 = ann12 = ann1m = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             res["ann"] = ann
             res["ann_10m"] = ann10
             if world == 1:
                 res["ann_shard_12m5"] = ann12
+                res["ann_shard_1m25"] = ann1m
     if args.cosine_rows > 0:
         r = bench_cosine(args, rank, world, dev, ctx)
         if rank == 0:

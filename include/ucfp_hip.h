@@ -421,6 +421,12 @@ int ucfp_topk_pack_dev(ucfp_ctx* ctx, const uint64_t* d_ids, const uint32_t* d_k
 int ucfp_topk_merge_packed_dev(ucfp_ctx* ctx, int kind, const void* d_entries, uint32_t parts, size_t nq, uint32_t k,
                                uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_keys, uint32_t* d_out_counts,
                                void* stream);
+/* The same with the missing-shard mask: a shard that could not scan sends nq x k entries of 0xff bytes (id 2^64-1, key
+ * 2^32-1 like an empty list, and the pad word 0xffffffff where ucfp_topk_pack_dev writes 0); bit p of *d_missing (device
+ * u64, may be NULL; parts <= 64) is set for every such part. */
+int ucfp_topk_merge_packed_ex_dev(ucfp_ctx* ctx, int kind, const void* d_entries, uint32_t parts, size_t nq, uint32_t k,
+                                  uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_keys, uint32_t* d_out_counts,
+                                  uint64_t* d_missing, void* stream);
 
 /* ============================ SHARDED SEARCH (multi-GPU) ==============================
  * "Multi-GPU variant takes a device list; shards are internal" of IndexBackend::knn
@@ -441,9 +447,10 @@ int ucfp_topk_merge_packed_dev(ucfp_ctx* ctx, int kind, const void* d_entries, u
  * per batch on the exchange stream, the merge over the gathered buffer -- so that a single-GPU host executes, and can
  * test, exactly the code path a multi-GPU job runs.  ucfp_shard_comm_uses_rccl tells which branch a communicator takes.
  *
- * Failure of one rank: if this rank's own shard scan cannot be enqueued, ucfp_index_search_sharded_submit still joins
- * the all-gather with an empty list (so the other ranks do not block), completes the ticket and returns the scan's
- * error; the answer every rank then holds lacks that shard. */
+ * Failure of one rank: if this rank's own shard scan cannot be enqueued (or any later local step fails),
+ * ucfp_index_search_sharded_submit still joins the all-gather with an empty list (so the other ranks do not block),
+ * completes the ticket and returns the error; the answer every rank then holds lacks that shard, and every rank can tell:
+ * the list carries a mark in the entries' pad word that the merge turns into ucfp_index_search_sharded_missing's mask. */
 #define UCFP_SHARD_UID_BYTES 128
 #define UCFP_SHARD_FORCE_RCCL 1u
 typedef struct ucfp_shard_comm ucfp_shard_comm;
@@ -473,6 +480,11 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* comm, uin
                                      size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
                                      uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream, uint64_t* ticket);
 int ucfp_index_search_sharded_collect(ucfp_shard_comm* comm, uint64_t ticket, void* stream);
+/* Which shards are ABSENT from a ticket's answer: bit r of *missing_mask = rank r joined the all-gather with the empty list of
+ * a failed scan (see "Failure of one rank" above) -- the same mask on every rank, so a host can report a partial result
+ * wherever it reads the answer, not only on the rank that failed.  Waits for the batch (host synchronisation); valid while
+ * the ticket's buffer set has not been handed to a later batch (i.e. before the second submit after it). */
+int ucfp_index_search_sharded_missing(ucfp_shard_comm* comm, uint64_t ticket, uint64_t* missing_mask);
 int ucfp_index_search_sharded_dev(ucfp_index* idx, ucfp_shard_comm* comm, uint32_t tenant, const void* d_queries,
                                   size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
                                   uint32_t* d_out_keys, uint32_t* d_out_counts, void* stream);

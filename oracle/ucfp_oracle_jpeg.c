@@ -276,8 +276,20 @@ static int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 :
 #define CONST_BITS 13
 #define PASS1_BITS 2
 #define DESCALE(x, n) (((x) + ((int32_t)1 << ((n)-1))) >> (n))
-static void idct_islow(const int16_t* coef, const uint16_t* qt_natural, uint8_t* out /* 8 x 8, stride 8 */) {
+/* Range guards (J4): the 32-bit butterflies below are exact -- and every implementation of this IDCT gives the same pixels
+ * (libjpeg's C code with its wrapping range table, libjpeg-turbo's 16-bit SIMD form with saturating packs, this one) -- only
+ * while (a) every dequantised coefficient is within +-16383 (8 x 16383 x 11363 < 2^31 for the column pass; also what the
+ * SIMD form's 16-bit multiply holds), (b) every column-pass result is within +-23000 (8 x 23000 x 11363 < 2^31 for the row
+ * pass) and (c) every sample before the range limit is within -512 .. 511 of the centre.  No stream made by an encoder
+ * comes near these; a crafted one that crosses them returns 1 and the file is JPG_NEEDS_HOST (the host's decoder decides). */
+#define IDCT_MAX_COEF 16383
+#define IDCT_MAX_PASS1 23000
+static int idct_islow(const int16_t* coef, const uint16_t* qt_natural, uint8_t* out /* 8 x 8, stride 8 */) {
     int32_t ws[64];
+    for (int i = 0; i < 64; i++) {
+        const int32_t v = (int32_t)coef[i] * (int32_t)qt_natural[i];
+        if (v > IDCT_MAX_COEF || v < -IDCT_MAX_COEF) return 1;
+    }
     for (int c = 0; c < 8; c++) {
         int32_t in[8];
         for (int r = 0; r < 8; r++) in[r] = (int32_t)coef[8 * r + c] * (int32_t)qt_natural[8 * r + c];
@@ -320,6 +332,9 @@ static void idct_islow(const int16_t* coef, const uint16_t* qt_natural, uint8_t*
         ws[8 * 3 + c] = DESCALE(tmp13 + tmp0, CONST_BITS - PASS1_BITS);
         ws[8 * 4 + c] = DESCALE(tmp13 - tmp0, CONST_BITS - PASS1_BITS);
     }
+    for (int i = 0; i < 64; i++)
+        if (ws[i] > IDCT_MAX_PASS1 || ws[i] < -IDCT_MAX_PASS1) return 1;
+    int wild = 0;
     for (int r = 0; r < 8; r++) {
         const int32_t* w = ws + 8 * r;
         int32_t z2 = w[2], z3 = w[6];
@@ -354,9 +369,11 @@ static void idct_islow(const int16_t* coef, const uint16_t* qt_natural, uint8_t*
                               tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
         for (int c = 0; c < 8; c++) {
             int32_t v = DESCALE(o[c], CONST_BITS + PASS1_BITS + 3) + 128;
+            if (v < -512 + 128 || v > 511 + 128) wild = 1;
             out[8 * r + c] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
         }
     }
+    return wild;
 }
 
 /* Whole file -> luma plane (row stride w).  cap = bytes available in `luma`. */
@@ -409,7 +426,8 @@ int ucfp_oracle_jpeg_decode_luma(const uint8_t* jpg, size_t n, uint8_t* luma, si
                         const uint32_t bx = (m % mx) * (uint32_t)J.hmax + (uint32_t)(bi % J.hs[0]);
                         const uint32_t by = (m / mx) * (uint32_t)J.vmax + (uint32_t)(bi / J.hs[0]);
                         uint8_t px[64];
-                        idct_islow(coef, qn, px);
+                        if (by * 8 >= J.h || bx * 8 >= J.w) continue;     /* MCU padding: decoded, never transformed */
+                        if (idct_islow(coef, qn, px)) { rc = JPG_NEEDS_HOST; break; }
                         for (uint32_t y = 0; y < 8; y++)
                             for (uint32_t x = 0; x < 8; x++)
                                 if (by * 8 + y < J.h && bx * 8 + x < J.w)

@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 PIL = pytest.importorskip("PIL.Image")
 
-from test_oracle_jpeg import jpeg_of, libjpeg_luma, picture   # noqa: E402
+from test_oracle_jpeg import jpeg_of, libjpeg_luma, picture, with_quantiser   # noqa: E402
 
 
 @pytest.mark.parametrize("h,w", [(256, 256), (64, 64), (33, 77), (1, 1), (17, 8), (100, 300), (250, 123)])
@@ -84,6 +84,25 @@ def test_files_handed_to_the_host_and_damaged_ones(gpu_ctx, oracle):
     assert st2[0] == o_rc and (o_rc != 0 or np.array_equal(fr2[0], o_px))
     rec, st3 = image.fingerprint_jpegs([good, progressive, good], 64, 64, algo=image.MULTI, ctx=gpu_ctx)
     assert list(st3) == [0, 1, 0] and not rec[1].any() and np.array_equal(rec[0], rec[2])
+
+
+def test_out_of_range_coefficients_take_the_oracles_status(gpu_ctx, oracle):
+    """Crafted quantisers (DESIGN J4's range guards): the device hands over exactly the files the oracle hands over, and
+    decodes the others to the oracle's pixels."""
+    from ucfp_amd import image
+    img = picture(64, 64, seed=3)
+    img[::2, ::2] = 255 - img[::2, ::2]
+    files = [with_quantiser(jpeg_of(img, quality=q, subsampling=s), v) for q in (30, 60, 95) for v in (1, 16, 40, 120, 255)
+             for s in (0, 2)]
+    fr, st = image.decode_jpegs(files, 64, 64, ctx=gpu_ctx)
+    want = [oracle.jpeg_decode_luma(f) for f in files]
+    assert [int(x) for x in st] == [w[0] for w in want]
+    assert 1 in st and 0 in st
+    for i, (rc, px) in enumerate(want):
+        if rc == 0:
+            assert np.array_equal(fr[i], px), i
+    rec, st2 = image.fingerprint_jpegs(files, 64, 64, ctx=gpu_ctx)
+    assert np.array_equal(st2, st) and not rec[st != 0].any()
 
 
 def test_stray_bytes_behind_the_last_block_are_ignored(gpu_ctx, oracle):

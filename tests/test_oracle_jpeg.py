@@ -87,3 +87,42 @@ def test_what_goes_back_to_the_host(oracle):
         assert oracle.jpeg_decode_luma(b.getvalue())[0] == oracle.JPG_NEEDS_HOST
     except TypeError:
         pass
+
+
+def with_quantiser(jpg, value):
+    """The file with every entry of its 8-bit quantisation tables set to `value` (crafted: coefficients x quantiser leave the
+    range an encoder produces)."""
+    b = bytearray(jpg)
+    pos = 2
+    while pos + 4 <= len(b) and b[pos] == 0xFF:
+        m, ln = b[pos + 1], b[pos + 2] << 8 | b[pos + 3]
+        if m == 0xDB:
+            o = pos + 4
+            while o < pos + 2 + ln:
+                assert b[o] >> 4 == 0
+                b[o + 1:o + 65] = bytes([value]) * 64
+                o += 65
+        if m == 0xDA:
+            break
+        pos += 2 + ln
+    return bytes(b)
+
+
+def test_out_of_range_coefficients_go_to_the_host(oracle):
+    """DESIGN J4's guards: dequantised coefficients beyond +-16383, column-pass results beyond +-23000 or samples beyond the
+    range table -- where libjpeg's C code, its SIMD code and a 32-bit restatement part ways -- are NEEDS_HOST; files an
+    encoder made never are, whatever the quality."""
+    img = picture(64, 64, seed=3)
+    img[::2, ::2] = 255 - img[::2, ::2]                                  # strong high frequencies: large AC coefficients
+    for q in (1, 5, 30, 60, 100):
+        f = jpeg_of(img, quality=q)
+        rc, px = oracle.jpeg_decode_luma(f)
+        assert rc == 0 and np.array_equal(px, libjpeg_luma(f)), q
+    seen = set()
+    for q in (30, 60, 95):
+        for v in (40, 120, 255):
+            rc, _ = oracle.jpeg_decode_luma(with_quantiser(jpeg_of(img, quality=q), v))
+            assert rc in (0, oracle.JPG_NEEDS_HOST)
+            seen.add(rc)
+    assert oracle.JPG_NEEDS_HOST in seen
+    assert oracle.jpeg_decode_luma(with_quantiser(jpeg_of(img, quality=95), 255))[0] == oracle.JPG_NEEDS_HOST

@@ -297,3 +297,50 @@ def test_append_on_one_stream_search_on_another(gpu_ctx, oracle, torch_cuda):
     assert np.array_equal(o_ids.cpu().numpy().view(np.uint64), e_ids)
     assert np.array_equal(o_keys.cpu().numpy().view(np.uint32), e_d)
     ix.close()
+
+
+def test_a_missing_shard_is_marked_on_every_rank(gpu_ctx, oracle, torch_cuda):
+    """A rank whose scan failed joins the all-gather with 0xff bytes: an empty list whose pad word says 'missing'.  The
+    merge every rank runs reports it as a bit mask (ucfp_topk_merge_packed_ex_dev for hosts with their own transport,
+    ucfp_index_search_sharded_missing for the RCCL path), and the answer is the merge of the shards that did answer."""
+    torch = torch_cuda
+    from ucfp_amd import _lib, errors, index, sharded
+    lib = _lib.load()
+    rng = np.random.default_rng(4242)
+    nq, k, parts = 33, 7, 3
+    ids = rng.permutation(3000).astype(np.uint64).reshape(parts, 1000)
+    codes = rng.integers(0, 2**64, (parts, 1000), dtype=np.uint64)
+    q = rng.integers(0, 2**64, nq, dtype=np.uint64)
+    ent = np.zeros((parts, nq, k, 2), np.int64)
+    for p in range(parts):
+        o_ids, o_d, _ = oracle.hamming_topk(ids[p], codes[p], q, k)
+        ent[p] = sharded.pack_entries(o_ids, o_d)
+    ent[1] = -1                                                   # shard 1 could not scan: 0xff in every byte
+    d_ent = _dev(torch, ent)
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    o_keys = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    mask = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    _lib.check(lib.ucfp_topk_merge_packed_ex_dev(gpu_ctx.handle, index.HAMMING64, d_ent.data_ptr(), parts, nq, k,
+                                                 o_ids.data_ptr(), None, o_keys.data_ptr(), o_cnt.data_ptr(), mask.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream or None))
+    torch.cuda.synchronize()
+    assert int(mask.item()) == 0b010
+    keep = [0, 2]
+    w_ids, w_d, _ = oracle.hamming_topk(ids[keep].reshape(-1), codes[keep].reshape(-1), q, k)
+    assert np.array_equal(o_ids.cpu().numpy().view(np.uint64), w_ids)
+    assert np.array_equal(o_keys.cpu().numpy().view(np.uint32), w_d)
+    # the RCCL path: nothing missing after ordinary searches; a ticket whose buffers moved on is refused
+    six = sharded.ShardedIndex(index.HAMMING64, ctx=gpu_ctx, force_rccl=True)
+    six.append_local(_dev(torch, ids.reshape(-1).view(np.int64)), _dev(torch, codes.reshape(-1).view(np.int64)))
+    d_q = _dev(torch, q.view(np.int64))
+    t1 = six.submit(d_q, k)
+    assert six.missing_shards(t1) == 0
+    six.search(d_q, k, check=True)
+    t3 = six.submit(d_q, k)                                        # the buffer set of t1 again
+    assert six.missing_shards(t3) == 0
+    six._bufs[(nq, k, 0)]["ticket"], keep_t = 1, six._bufs[(nq, k, 0)]["ticket"]      # ticket 1: long overwritten
+    with pytest.raises(errors.InvalidArgument):
+        six.missing_shards((nq, k, 0))
+    six._bufs[(nq, k, 0)]["ticket"] = keep_t
+    six.close()

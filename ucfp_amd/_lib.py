@@ -98,6 +98,8 @@ SIGNATURES = {
     "ucfp_topk_pack_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
     "ucfp_topk_merge_packed_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_topk_merge_packed_ex_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_shard_unique_id": (C.c_int, [C.c_void_p]),
     "ucfp_shard_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ucfp_shard_comm_create_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32,
@@ -110,6 +112,7 @@ SIGNATURES = {
                                                    C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.POINTER(C.c_uint64)]),
     "ucfp_index_search_sharded_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ucfp_index_search_sharded_missing": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "ucfp_index_search_sharded_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_image_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,

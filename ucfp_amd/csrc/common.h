@@ -164,8 +164,9 @@ int launch_topk_merge_u32(const uint64_t* part_ids, const uint32_t* part_key, ui
                           float* hamming_scores = nullptr);   // optional: 1 - key / 64 of the final keys, written even when run_flag is 0
 // wire format of the sharded search: 16-byte entries {id u64, key u32, pad u32}
 int launch_topk_pack_entries(const uint64_t* ids, const uint32_t* keys, size_t total, void* entries, hipStream_t stream);
+// missing (optional, device): bit p set = part p's first entry carries the 0xffffffff pad word of a shard that could not scan
 int launch_topk_merge_packed(const void* entries, uint32_t parts, uint32_t nq, uint32_t k, uint64_t* out_ids,
-                             uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream);
+                             uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream, uint64_t* missing = nullptr);
 // tree merge (fan-in 64 per level); tmp_* hold 2 x topk_merge_tmp_entries(parts, nq, k) entries
 size_t topk_merge_tmp_entries(uint32_t parts, uint32_t nq, uint32_t k);
 int launch_topk_merge_tree_u32(const uint64_t* part_ids, const uint32_t* part_key, uint32_t parts, uint32_t nq,

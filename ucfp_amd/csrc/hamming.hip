@@ -825,7 +825,11 @@ __global__ __launch_bounds__(kRescanThreads) __attribute__((amdgpu_waves_per_eu(
             }
         }
         __syncthreads();
-        const uint32_t have = qn < kRescanQueue ? qn : kRescanQueue;
+        // snapshot the counter between two barriers: a wave that decides not to drain goes straight on to the next trip's
+        // atomicAdd(&qn), and a slower wave reading qn after that would decide differently and wait alone at the drain's barrier
+        const uint32_t cur = qn;
+        __syncthreads();
+        const uint32_t have = cur < kRescanQueue ? cur : kRescanQueue;
         const bool last = base + stride >= cnt;
         if (last || have + kRescanThreads * 8 > kRescanQueue) {
             for (uint32_t e = threadIdx.x; e < have; e += kRescanThreads) evaluate(queue[e].x, queue[e].y);

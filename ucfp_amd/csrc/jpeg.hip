@@ -226,6 +226,9 @@ __global__ __launch_bounds__(64) void jpeg_scan_kernel(const uint8_t* __restrict
             prev = (uint32_t)__shfl((int)b, 63, 64);
             ended = endm != 0;
         }
+        // bit positions are 32-bit (data_bits = clean_len * 8, a segment's (b1 - b0) * 8): a file with 256 MiB or more of
+        // entropy-coded data goes to the host's decoder
+        if (o >= (1u << 28)) status = UCFP_IMAGE_NEEDS_HOST;
         nseg += 1;                                              // the last segment ends where the data ends
         if (status == 0 && nseg <= max_seg + 1 && lane == 0) sg[nseg] = o;
         if (lane < 16) out[o + lane] = 0;                        // (a reader's look-ahead past the end)
@@ -821,7 +824,12 @@ __device__ __forceinline__ void islow_1d(const int32_t in0, const int32_t in1, c
     o[4] = tmp13 - tmp0;
 }
 
-__global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpgInfo* __restrict__ info, size_t n, uint32_t width, uint32_t height,
+// Range guards (DESIGN J4, the same three as the oracle's idct_islow): (a) dequantised coefficients within +-16383, (b) column-pass
+// results within +-23000, (c) samples within -512 .. 511 of the centre before the range limit.  Inside them the 32-bit
+// butterflies cannot overflow and libjpeg's C table, libjpeg-turbo's 16-bit SIMD form and this code give the same pixels; a
+// crafted stream that crosses one makes the file UCFP_IMAGE_NEEDS_HOST (its record is zeroed by the merge kernel).
+constexpr int32_t kIdctMaxCoef = 16383, kIdctMaxPass1 = 23000;
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(JpgInfo* __restrict__ info, size_t n, uint32_t width, uint32_t height,
                                                        const int16_t* __restrict__ coef, size_t coef_stride, uint32_t bxp, uint32_t byp,
                                                        const uint16_t* __restrict__ qtab, uint8_t* __restrict__ frames, size_t row_stride,
                                                        size_t frame_stride) {
@@ -846,6 +854,15 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpgInfo* __restric
             ws[8 * r + 2 * i + 1] = (int32_t)(int16_t)(cw[i] >> 16) * (int32_t)(qw[i] >> 16);
         }
     }
+    {
+        int32_t big = 0;
+#pragma unroll
+        for (int i = 0; i < 64; i++) big = max(big, ws[i] < 0 ? -ws[i] : ws[i]);
+        if (big > kIdctMaxCoef) {
+            info[img].status = UCFP_IMAGE_NEEDS_HOST;
+            return;
+        }
+    }
     // pass 1: columns
 #pragma unroll
     for (int col = 0; col < 8; col++) {
@@ -854,6 +871,16 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpgInfo* __restric
 #pragma unroll
         for (int r = 0; r < 8; r++) ws[8 * r + col] = JD(o[r], 13 - 2);
     }
+    {
+        int32_t big = 0;
+#pragma unroll
+        for (int i = 0; i < 64; i++) big = max(big, ws[i] < 0 ? -ws[i] : ws[i]);
+        if (big > kIdctMaxPass1) {
+            info[img].status = UCFP_IMAGE_NEEDS_HOST;
+            return;
+        }
+    }
+    bool wild = false;
     // pass 2: rows, range limit, store
     uint8_t* dst = frames + img * frame_stride + (size_t)(by * 8) * row_stride + (size_t)bx * 8;
     const bool whole = bx * 8 + 8 <= width && ((reinterpret_cast<uintptr_t>(dst) | row_stride) & 7u) == 0;
@@ -865,6 +892,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpgInfo* __restric
 #pragma unroll
         for (int x = 0; x < 8; x++) {
             const int32_t v = JD(o[x], 13 + 2 + 3) + 128;
+            wild = wild || v < -512 + 128 || v > 511 + 128;
             px[x] = (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
         }
         if (by * 8 + r < height) {
@@ -879,6 +907,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpgInfo* __restric
             }
         }
     }
+    if (wild) info[img].status = UCFP_IMAGE_NEEDS_HOST;
 }
 
 __global__ void jpeg_status_kernel(const JpgInfo* __restrict__ info, size_t n, int32_t* __restrict__ status) {
@@ -956,7 +985,7 @@ int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, ui
         else go(jpeg_huff_spec_kernel<8>, 512, sizeof(SpecLds<8>));
     }
     const size_t blocks = n * (size_t)l.bxp * l.byp;
-    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, stream, (const JpgInfo*)info, n, w, h,
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, stream, info, n, w, h,
                        (const int16_t*)coef, l.coef_stride, l.bxp, l.byp, (const uint16_t*)qtab, frames, row_stride,
                        frame_stride);
     if (status)

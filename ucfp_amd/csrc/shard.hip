@@ -99,6 +99,8 @@ struct ucfp_shard_comm {
         size_t cap = 0;
         hipEvent_t queued = nullptr, searched = nullptr, done = nullptr;
         uint64_t ticket = 0;
+        bool has_mask = false;          // the merge of this set's batch wrote the missing-shard mask at buf + missing_off
+        size_t missing_off = 0;
     } sets[2];
     uint64_t next_ticket = 1;
     uint64_t exchanges = 0;         // all-gathers issued (stats / tests)
@@ -229,6 +231,13 @@ int ucfp_topk_pack_dev(ucfp_ctx* ctx, const uint64_t* d_ids, const uint32_t* d_k
 int ucfp_topk_merge_packed_dev(ucfp_ctx* ctx, int kind, const void* d_entries, uint32_t parts, size_t nq, uint32_t k,
                                uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_keys, uint32_t* d_out_counts,
                                void* stream) {
+    return ucfp_topk_merge_packed_ex_dev(ctx, kind, d_entries, parts, nq, k, d_out_ids, d_out_scores, d_out_keys, d_out_counts,
+                                         nullptr, stream);
+}
+
+int ucfp_topk_merge_packed_ex_dev(ucfp_ctx* ctx, int kind, const void* d_entries, uint32_t parts, size_t nq, uint32_t k,
+                                  uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_keys, uint32_t* d_out_counts,
+                                  uint64_t* d_missing, void* stream) {
     if (!ctx) return capi_fail(UCFP_E_INVALID, "ctx is NULL");
     if (kind != UCFP_INDEX_HAMMING64 && kind != UCFP_INDEX_COSINE_F32)
         return capi_fail(UCFP_E_UNSUPPORTED, "unknown index kind %d", kind);
@@ -238,7 +247,8 @@ int ucfp_topk_merge_packed_dev(ucfp_ctx* ctx, int kind, const void* d_entries, u
     if (k > UCFP_INDEX_MAX_K) return capi_fail(UCFP_E_INVALID, "k too large");
     if ((size_t)parts * k > 2048 && parts > 64) return capi_fail(UCFP_E_UNSUPPORTED, "more than 64 shards");
     hipStream_t st = (hipStream_t)stream;
-    ucfp::launch_topk_merge_packed(d_entries, parts, (uint32_t)nq, k, d_out_ids, d_out_keys, d_out_counts, st);
+    if (d_missing && parts > 64) return capi_fail(UCFP_E_UNSUPPORTED, "the missing-shard mask holds 64 parts");
+    ucfp::launch_topk_merge_packed(d_entries, parts, (uint32_t)nq, k, d_out_ids, d_out_keys, d_out_counts, st, d_missing);
     if (d_out_scores) {
         if (kind == UCFP_INDEX_HAMMING64) ucfp::launch_hamming_scores(d_out_keys, nq * k, d_out_scores, st);
         else ucfp::launch_cosine_scores_from_keys(d_out_keys, nq * k, d_out_scores, st);
@@ -266,6 +276,7 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* c, uint32
     ucfp_shard_comm::Set& S = c->sets[t & 1];
     S.ticket = t;
     *ticket = t;
+    S.has_mask = false;
     if (nq == 0 || k == 0) {
         // every rank still takes part in nothing: an empty batch is empty everywhere (queries are replicated)
         HIP_TRY(hipStreamWaitEvent(st, S.done, 0));
@@ -283,7 +294,8 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* c, uint32
     const size_t e = nq * k;
     const size_t o_ids = 0, o_keys = align256(e * 8), o_cnt = align256(o_keys + e * 4), o_send = align256(o_cnt + nq * 4);
     const size_t o_recv = align256(o_send + e * 16), o_okeys = align256(o_recv + (size_t)c->world * e * 16);
-    const size_t need = align256(o_okeys + e * 4);
+    const size_t o_missing = align256(o_okeys + e * 4);
+    const size_t need = align256(o_missing + 8);
     if (S.cap < need) {
         HIP_TRY(hipStreamSynchronize(c->xs));
         HIP_TRY(hipStreamSynchronize(ls));
@@ -301,35 +313,58 @@ int ucfp_index_search_sharded_submit(ucfp_index* idx, ucfp_shard_comm* c, uint32
     uint8_t* recv = exchange ? S.buf + o_recv : send;
     uint32_t* okeys = d_out_keys ? d_out_keys : reinterpret_cast<uint32_t*>(S.buf + o_okeys);
     // 1. this rank's shard, on the set's scan stream
-    const int rc = ucfp_index_search_dev(idx, tenant, d_queries, nq, k, l_ids, nullptr, l_keys, l_cnt, ls);
+    int rc = ucfp_index_search_dev(idx, tenant, d_queries, nq, k, l_ids, nullptr, l_keys, l_cnt, ls);
     if (rc && !exchange) return rc;
-    if (rc) {
-        // This rank's scan could not be enqueued (workspace allocation, say) but the other ranks are about to enter the
-        // all-gather: join it with an all-invalid list (id 2^64-1, key 2^32-1 in every place: what a shard with no
-        // hit sends) so nobody blocks, and report the error after the collective has been issued.
-        HIP_TRY(hipMemsetAsync(send, 0xff, e * 16, ls));
-    } else {
+    // From here to the all-gather NOTHING returns on this rank alone: the other ranks are about to enter the collective
+    // and would wait in it for ever.  A local failure (the scan could not be enqueued, a stream call failed) is kept in
+    // `rc`, the rank joins the all-gather with an all-0xff list -- id 2^64-1 and key 2^32-1 in every place like a shard
+    // with no hit, and the PAD word 0xffffffff where a packed entry has 0: the mark of a missing shard, which the merge
+    // on every rank turns into the ticket's `missing` mask (ucfp_index_search_sharded_missing) -- and the error is
+    // reported after the collective has been issued.
+    auto keep = [&](hipError_t e_, const char* what) {
+        if (e_ != hipSuccess && rc == UCFP_OK) rc = capi_fail(UCFP_E_INDEX, "%s failed: %s", what, hipGetErrorString(e_));
+    };
+    if (rc == UCFP_OK) {
         ucfp::launch_topk_pack_entries(l_ids, l_keys, e, send, ls);
-        HIP_TRY(hipGetLastError());
+        keep(hipGetLastError(), "pack kernel");
     }
+    if (rc) (void)hipMemsetAsync(send, 0xff, e * 16, ls);
     // 2. exchange + merge, on the side stream (the scan stream when there is nothing to exchange)
     hipStream_t xs = exchange ? c->xs : ls;
     if (exchange) {
-        HIP_TRY(hipEventRecord(S.searched, ls));
-        HIP_TRY(hipStreamWaitEvent(xs, S.searched, 0));
+        keep(hipEventRecord(S.searched, ls), "hipEventRecord");
+        // (if the event calls failed the all-gather may read a stale send buffer: the rank still JOINS, its error is returned)
+        keep(hipStreamWaitEvent(xs, S.searched, 0), "hipStreamWaitEvent");
         RcclApi* api = rccl();
         ncclResult_t r = api->all_gather(send, recv, e * 2, ncclUint64, c->comm, xs);   // 16-byte entries as 2 x u64
         if (r != ncclSuccess) return capi_fail(UCFP_E_INDEX, "ncclAllGather: %s", api->error_string(r));
         c->exchanges++;
     }
-    ucfp::launch_topk_merge_packed(recv, (uint32_t)c->world, (uint32_t)nq, k, d_out_ids, okeys, d_out_counts, xs);
+    ucfp::launch_topk_merge_packed(recv, (uint32_t)c->world, (uint32_t)nq, k, d_out_ids, okeys, d_out_counts, xs,
+                                   reinterpret_cast<uint64_t*>(S.buf + o_missing));
     if (d_out_scores) {
         if (kind == UCFP_INDEX_HAMMING64) ucfp::launch_hamming_scores(okeys, e, d_out_scores, xs);
         else ucfp::launch_cosine_scores_from_keys(okeys, e, d_out_scores, xs);
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(S.done, xs));
+    keep(hipGetLastError(), "merge kernels");
+    keep(hipEventRecord(S.done, xs), "hipEventRecord");
+    S.has_mask = true;
+    S.missing_off = o_missing;
     return rc;   // non-zero: this rank's shard is missing from the answer every rank now holds (ucfp_last_error says why)
+}
+
+int ucfp_index_search_sharded_missing(ucfp_shard_comm* c, uint64_t ticket, uint64_t* missing_mask) {
+    if (!c || !missing_mask) return capi_fail(UCFP_E_INVALID, "comm/mask is NULL");
+    *missing_mask = 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (ticket == 0 || ticket >= c->next_ticket) return capi_fail(UCFP_E_INVALID, "unknown ticket %llu", (unsigned long long)ticket);
+    ucfp_shard_comm::Set& S = c->sets[ticket & 1];
+    if (S.ticket != ticket) return capi_fail(UCFP_E_INVALID, "ticket %llu: its buffers hold a later batch", (unsigned long long)ticket);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(S.done));
+    if (!S.has_mask) return UCFP_OK;          // an empty batch: nothing was exchanged
+    HIP_TRY(hipMemcpy(missing_mask, S.buf + S.missing_off, 8, hipMemcpyDeviceToHost));
+    return UCFP_OK;
 }
 
 int ucfp_index_search_sharded_collect(ucfp_shard_comm* c, uint64_t ticket, void* stream) {

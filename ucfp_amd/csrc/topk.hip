@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
                                                      uint32_t* __restrict__ out_key,
                                                      uint32_t* __restrict__ out_cnt,
                                                      const uint32_t* __restrict__ run_flag, uint32_t group_parts,
-                                                     float* __restrict__ hscores) {
+                                                     float* __restrict__ hscores, uint64_t* __restrict__ missing = nullptr) {
     // hscores (optional; only with one group): Hamming similarity 1 - d / 64 of the FINAL keys of this query, written
     // whether or not the merge runs -- the gated fallback of the Hamming search ends with it, so that the distances another
     // kernel selected get their scores without a launch of their own
@@ -207,6 +207,13 @@ __global__ __launch_bounds__(64) void topk_merge_u32(const uint64_t* __restrict_
     }
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
+    if (PACKED && missing && blockIdx.x == 0 && blockIdx.y == 0) {
+        // a shard whose rank could not scan joins the all-gather with 0xff bytes (shard.hip): the pad word of its first entry
+        // is 0xffffffff where a packed entry carries 0.  Bit p of *missing = part p is absent from this answer (parts <= 64).
+        const bool gone = (uint32_t)lane < parts && reinterpret_cast<const uint4*>(part_ids)[(size_t)lane * nq * k].w == 0xffffffffu;
+        const uint64_t m = __ballot(gone);
+        if (lane == 0) *missing = m;
+    }
     // blockIdx.y = group of `group_parts` consecutive parts (tree merge: one output list per group and query)
     const uint32_t p_lo = blockIdx.y * group_parts;
     const uint32_t p_n = parts - p_lo < group_parts ? parts - p_lo : group_parts;
@@ -850,10 +857,11 @@ int launch_topk_pack_entries(const uint64_t* ids, const uint32_t* keys, size_t t
 
 // merge `parts` packed lists ([parts][nq][k] entries, as all-gathered) into the final (ids, keys, counts)
 int launch_topk_merge_packed(const void* entries, uint32_t parts, uint32_t nq, uint32_t k, uint64_t* out_ids,
-                             uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream) {
+                             uint32_t* out_key, uint32_t* out_cnt, hipStream_t stream, uint64_t* missing) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(topk_merge_u32<true>, dim3(nq), dim3(64), 0, stream, reinterpret_cast<const uint64_t*>(entries),
-                       (const uint32_t*)nullptr, parts, nq, k, out_ids, out_key, out_cnt, (const uint32_t*)nullptr, parts, (float*)nullptr);
+                       (const uint32_t*)nullptr, parts, nq, k, out_ids, out_key, out_cnt, (const uint32_t*)nullptr, parts, (float*)nullptr,
+                       missing);
     return 0;
 }
 

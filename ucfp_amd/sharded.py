@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import errors as _errors
 from . import index as _index
 
 ENTRY_BYTES = 16
@@ -193,11 +194,29 @@ class ShardedIndex:
             cur.wait_event(b["done"])
         return b["out_ids"], b["out_scores"], b["out_keys"], b["out_cnt"]
 
-    def search(self, queries: torch.Tensor, k: int):
+    def missing_shards(self, ticket: Tuple[int, int, int]) -> int:
+        """Bit mask of the ranks whose shard is ABSENT from the ticket's answer (their scan failed; they joined the
+        all-gather with the marked empty list) -- the same on every rank.  Synchronises with the batch."""
+        nq, k, slot = ticket
+        b = self._bufs[(nq, k, slot)]
+        if b["ticket"] is None:
+            return 0                      # host transport (gloo): a failing rank raises in its own all-gather
+        m = C.c_uint64(0)
+        _lib.check(self._lib.ucfp_index_search_sharded_missing(self.comm.handle, b["ticket"], C.byref(m)))
+        return int(m.value)
+
+    def search(self, queries: torch.Tensor, k: int, check: bool = False):
         """queries: device tensor, [nq] int64 (u64 hashes) or [nq, dim] float32, identical on
         every rank. Returns (ids int64 [nq,k], scores f32 [nq,k], keys int32 [nq,k], counts [nq]).
-        The returned tensors belong to the index and are overwritten two searches later."""
-        return self.collect(self.submit(queries, k))
+        The returned tensors belong to the index and are overwritten two searches later.
+        check: wait for the batch and raise on EVERY rank if some rank's shard is missing from the answer."""
+        t = self.submit(queries, k)
+        out = self.collect(t)
+        if check:
+            m = self.missing_shards(t)
+            if m:
+                raise _errors.IndexError_(f"partial result: shards {[r for r in range(64) if m >> r & 1]} missing")
+        return out
 
     def close(self):
         self.comm.close()

@@ -97,3 +97,43 @@ def test_wire_format_is_16_little_endian_bytes():
     assert raw[16:] == b"\xff" * 12 + b"\0" * 4
     i2, k2 = sharded.unpack_entries(sharded.pack_entries(ids, keys))
     assert np.array_equal(i2, ids) and np.array_equal(k2, keys)
+
+
+def test_bench_corpus_is_a_function_of_the_global_row():
+    """bench.py's config-5 corpus (xorshift64*(0x5EED, index)): the union of the shards is the same corpus at
+    every world size, so an N > 1 line's answers_crc can be compared with the N = 1 line's."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from ucfp_amd import sharded
+    m = (1 << 64) - 1
+
+    def ref(i):
+        x = ((i + 1) * 0x9E3779B97F4A7C15) & m
+        x ^= 0x5EED
+        x ^= x >> 12
+        x ^= (x << 25) & m
+        x ^= x >> 27
+        return (x * 0x2545F4914F6CDD1D) & m
+
+    n = 5003
+    whole = bench.ann_corpus_codes(torch, "cpu", 0, n)
+    assert [int(v) & m for v in whole[:50].tolist()] == [ref(i) for i in range(50)]
+    for world in (2, 3, 8):
+        parts = [bench.ann_corpus_codes(torch, "cpu", *sharded.shard_range(n, r, world)) for r in range(world)]
+        assert torch.equal(torch.cat(parts), whole)
+    # planted rows are global positions: the shards' plants together are the plants of the whole
+    q = torch.arange(64, dtype=torch.int64) * 7919
+    a = whole.clone()
+    bench._ann_plant(torch, a, q, 0, n, n)
+    for world in (2, 8):
+        got = []
+        for r in range(world):
+            s, e = sharded.shard_range(n, r, world)
+            c = whole[s:e].clone()
+            bench._ann_plant(torch, c, q, s, e, n)
+            got.append(c)
+        assert torch.equal(torch.cat(got), a)
+    assert int((a != whole).sum()) == 32

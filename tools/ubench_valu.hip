@@ -27,6 +27,20 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t s0, uint32_t s1
                 unsigned long long t = ((unsigned long long)acc[(j + 1) & 7] << 32) | acc[j];
                 t = (unsigned long long)(q0 + j) * q1 + t;
                 acc[j] = (uint32_t)t ^ (uint32_t)(t >> 32);
+            } else if (MODE == 6) {  // v_mul_lo_u32 (32 x 32 -> low 32)
+                acc[j] = acc[j] * (q0 | 1u) + j;
+            } else if (MODE == 7) {  // v_mul_hi_u32
+                acc[j] = __umulhi(acc[j] + q1, q0 | 0x80000001u);
+            } else if (MODE == 8) {  // v_mad_u32_u24
+                acc[j] = __umul24(acc[j], q0) + q1;
+            } else if (MODE == 9) {  // DPP row_shr:1 add (what a wave prefix scan is made of)
+                acc[j] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[j], 0x111, 0xf, 0xf, true);
+            } else if (MODE == 10) {  // ds_bpermute shuffle + add (what __shfl_up compiles to)
+                acc[j] += (uint32_t)__shfl_up((int)acc[j], 1, 64);
+            } else if (MODE == 11) {  // u32 -> f32, multiply, f32 -> u32 (the rounding division's estimate)
+                acc[j] = (uint32_t)((float)(acc[j] | 1u) * __uint_as_float(0x3c000000u | (q0 & 0xffffu))) + j;
+            } else if (MODE == 12) {  // v_bfe_u32 + v_mad_u32_u24: byte extract and multiply-add
+                acc[j] = __umul24((q0 >> (8 * (j & 3))) & 255u, q1 & 0x1ffu) + acc[j];
             } else {  // fma f32 reference: 1 op
                 float f = __uint_as_float(acc[j]);
                 f = fmaf(f, 1.0001f, 0.5f);
@@ -72,5 +86,12 @@ int main() {
     run<3>("dot4_u32_u8 (acc chain x8)", 1, 16000);
     run<4>("alignbyte + add", 2, 8000);
     run<5>("mad_u64_u32 + xor", 2, 8000);
+    run<6>("mul_lo_u32 + add", 2, 8000);
+    run<7>("add + mul_hi_u32", 2, 8000);
+    run<8>("mad_u32_u24", 1, 16000);
+    run<9>("dpp row_shr:1 + add", 1, 16000);
+    run<10>("shfl_up (ds_bpermute) + add", 3, 4000);
+    run<11>("or, cvt_f32_u32, mul_f32, cvt_u32_f32, add", 5, 4000);
+    run<12>("bfe + mad_u32_u24", 2, 8000);
     return 0;
 }

@@ -29,6 +29,16 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
                       uint8_t* norm_ws, size_t norm_ws_frames, hipStream_t stream);
 bool image_hash_needs_ws(const uint8_t* frames, uint32_t w, uint32_t h, size_t row_stride, size_t frame_stride,
                          int pixfmt, uint32_t min_dim, uint32_t max_dim);
+// the fused any-geometry kernel (ragged batches; uniform ones of a geometry the square kernels do not take)
+bool image_any_plan(const uint8_t* base, uint64_t src, uint32_t w, uint32_t h, size_t row_stride, int pixfmt, uint32_t* cls,
+                    uint32_t* parts);
+size_t image_any_item_bytes();
+void image_any_item_write(void* dst, size_t i, uint64_t src, uint32_t w, uint32_t h, uint32_t row_stride, uint32_t slot, uint32_t cls,
+                          uint32_t parts);
+int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, bool any_prefix, uint32_t proto_w,
+                          uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_parts, size_t frame_stride,
+                          const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t stream);
+int launch_image_reject_list(const uint32_t* d_slots, size_t n, uint8_t* out, uint32_t rec, int32_t* status, hipStream_t stream);
 int launch_image_record_codes(const uint8_t* records, size_t n, uint32_t rec_bytes, uint32_t offset, uint64_t* codes,
                               hipStream_t stream);
 int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,

@@ -120,6 +120,28 @@ int ucfp_image_hash_batch(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, s
                           size_t frame_stride, int pixfmt, const ucfp_image_preprocess* pre,
                           const uint8_t* exact, uint8_t* out, int32_t* status);
 
+/* RAGGED batch of decoded frames: every frame has its own geometry -- the reference's image route takes any upload
+ * (src/server/handlers.rs:232-302 -> src/modality/image.rs:54-88: "PNG / JPEG / WebP / GIF / BMP", any size), so what a
+ * server hands over after decode is a mix of sizes.  Frame i is described by items[i] (a HOST array; the library plans
+ * the launch from it): its first pixel sits `offset` bytes into `frames`, rows `row_stride` bytes apart, `pixfmt` pixels.
+ * One launch per form of row (up to / beyond 512 pixels) hashes the whole batch: a workgroup takes a frame from source
+ * bytes to record with the 256 x 256 normalised plane kept in registers and LDS, never in memory.  Outputs as
+ * ucfp_image_hash_batch_dev, indexed like `items`; a frame outside the guards of `pre` (or of zero size) gets
+ * status[i] = UCFP_E_MODALITY and a zero record, the others are unaffected.  frames_bytes: the readable bytes behind
+ * `frames` (the unaligned loader reads whole dwords, never outside them). */
+typedef struct ucfp_image_item {
+    uint64_t offset;     /* first pixel of the frame, bytes from `frames`                 */
+    uint32_t width, height;
+    uint32_t row_stride; /* bytes; >= width x bytes per pixel                              */
+    int32_t pixfmt;      /* ucfp_pixfmt                                                    */
+} ucfp_image_item;
+int ucfp_image_hash_ragged_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_frames, size_t frames_bytes,
+                               const ucfp_image_item* items, size_t n, const ucfp_image_preprocess* pre, const uint8_t* d_exact,
+                               uint8_t* d_out, int32_t* d_status, void* stream);
+/* Host-pointer variant: frames / exact / out / status in host memory; blocks until the records are in `out`. */
+int ucfp_image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t frames_bytes, const ucfp_image_item* items,
+                           size_t n, const ucfp_image_preprocess* pre, const uint8_t* exact, uint8_t* out, int32_t* status);
+
 /* ---- PNG front end ----
  * The reference decodes the upload inside the SDK call (src/modality/image.rs:68-70, :176-179: imgfprint ->
  * image::load_from_memory); BASELINE config 1 (1 k 256x256 PNGs) is decode-bound on the CPU.  These entry points take

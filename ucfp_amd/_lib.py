@@ -27,6 +27,12 @@ class HaitsmaConfig(C.Structure):
     _fields_ = [("fmin", C.c_float), ("fmax", C.c_float)]
 
 
+class ImageItem(C.Structure):
+    """ucfp_image_item: one decoded frame of a ragged batch."""
+    _fields_ = [("offset", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("row_stride", C.c_uint32),
+                ("pixfmt", C.c_int32)]
+
+
 class ImagePreprocess(C.Structure):
     """ucfp_image_preprocess (imgfprint::PreprocessConfig guards)."""
     _fields_ = [("max_dimension", C.c_uint32), ("min_dimension", C.c_uint32)]
@@ -47,6 +53,10 @@ SIGNATURES = {
     "ucfp_image_hash_batch": (C.c_int, [
         C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
         C.c_size_t, C.c_int, C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_image_hash_ragged_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(ImageItem), C.c_size_t,
+                                             C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_image_hash_ragged": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(ImageItem), C.c_size_t,
+                                         C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_audio_wang_max_hashes": (C.c_size_t, [C.c_size_t, C.POINTER(WangConfig)]),
     "ucfp_audio_wang": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(WangConfig), C.c_void_p,
                                   C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -67,6 +68,15 @@ struct ucfp_ctx {
     // BLAKE3 chaining values of the last batch (+ the digests when the PNG call computes `exact` itself); ordered by png_done
     uint8_t* b3_ws = nullptr;
     size_t b3_ws_cap = 0;
+    // per-frame tables of ragged image batches (ImgItem rows, rejected slots): two pinned + device buffer pairs used in
+    // turn; `used[i]` is recorded behind the kernels that read pair i and waited for before the host rewrites it
+    std::mutex item_mu;
+    uint8_t* item_h[2] = {nullptr, nullptr};
+    uint8_t* item_d[2] = {nullptr, nullptr};
+    size_t item_cap[2] = {0, 0};
+    hipEvent_t item_used[2] = {nullptr, nullptr};
+    int item_next = 0;
+    size_t any_max_pixels = (size_t)1 << 20;   // uniform batches: frames up to this size take the fused any-geometry kernel
 };
 
 namespace {
@@ -85,6 +95,7 @@ int grow(uint8_t** p, size_t* cap, size_t need) {
 }  // namespace
 
 namespace ucfp {
+int capi_fail(int code, const char* fmt, ...);
 int ctx_device(const ucfp_ctx* ctx) { return ctx->device; }
 // Every image launch of the library goes through here.  The fused kernels touch no shared state; a geometry that
 // normalises into ctx->norm_ws first waits (on `stream`) for the previous user of that workspace -- whatever stream
@@ -97,6 +108,16 @@ int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size
                           ctx->norm_ws, kNormWsFrames, stream);
         return (int)hipGetLastError();
     }
+    // a geometry the square kernels do not take: up to any_max_pixels per frame the fused any-geometry kernel (one
+    // workgroup per frame, no workspace); larger frames are normalised by many waves each into the shared workspace
+    uint32_t cls = 0, parts = 0;
+    if (n && (size_t)w * h <= ctx->any_max_pixels && image_any_plan(frames, 0, w, h, row_stride, pixfmt, &cls, &parts)) {
+        const size_t bpp = pixfmt == 0 ? 1 : pixfmt == 1 ? 3 : 4;
+        const uint8_t* hi = frames + (n - 1) * frame_stride + (size_t)(h - 1) * row_stride + (size_t)w * bpp;
+        launch_image_hash_any(algo, frames, nullptr, n, image_any_is_prefix(cls), w, h, (uint32_t)row_stride, cls, parts, frame_stride,
+                              frames, hi, exact, out, status, stream);
+        return (int)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lk(ctx->norm_mu);
     hipError_t e = hipStreamWaitEvent(stream, ctx->norm_done, 0);
     if (e != hipSuccess) return (int)e;
@@ -105,6 +126,84 @@ int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     return (int)hipEventRecord(ctx->norm_done, stream);
+}
+
+// Ragged batch of decoded frames: every frame has its own geometry.  items: HOST array.  Frames inside the fused kernel's
+// range take ONE launch per form group (rows up to / beyond 512 pixels); the rest (more than any_max_pixels) go one by
+// one down the many-waves-per-frame path.  Returns a ucfp_status (message set), not a hipError_t.
+int image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* base, size_t frames_bytes, const ucfp_image_item* items, size_t n,
+                      uint32_t min_dim, uint32_t max_dim, const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t st) {
+    const size_t rec = algo == 7u ? 536 : 168, isz = image_any_item_bytes();
+    // plan on the host: form group, class and parts of every frame
+    std::vector<uint32_t> reject, big;
+    std::vector<uint8_t> tab[2];          // ImgItem rows of the TAPS and of the PREFIX launch
+    size_t cnt[2] = {0, 0};
+    for (size_t i = 0; i < n; i++) {
+        const ucfp_image_item& it = items[i];
+        if (it.pixfmt < UCFP_PIX_GRAY8 || it.pixfmt > UCFP_PIX_RGBA8) return capi_fail(UCFP_E_INVALID, "item %zu: unknown pixfmt %d", i, it.pixfmt);
+        const size_t bpp = it.pixfmt == UCFP_PIX_GRAY8 ? 1 : it.pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
+        if (it.width == 0 || it.height == 0 || it.width < min_dim || it.height < min_dim || it.width > max_dim || it.height > max_dim) {
+            reject.push_back((uint32_t)i);            // Error::Modality for this frame (image.rs:70), the others go on
+            continue;
+        }
+        if (it.row_stride < (size_t)it.width * bpp) return capi_fail(UCFP_E_INVALID, "item %zu: row_stride %u < width * bpp", i, it.row_stride);
+        const uint64_t end = it.offset + (uint64_t)(it.height - 1) * it.row_stride + (uint64_t)it.width * bpp;
+        if (end > frames_bytes || end < it.offset) return capi_fail(UCFP_E_INVALID, "item %zu reaches beyond the %zu bytes of frames", i, frames_bytes);
+        uint32_t cls = 0, parts = 0;
+        if ((size_t)it.width * it.height > ctx->any_max_pixels ||
+            !image_any_plan(base, it.offset, it.width, it.height, it.row_stride, it.pixfmt, &cls, &parts)) {
+            big.push_back((uint32_t)i);
+            continue;
+        }
+        const int g = image_any_is_prefix(cls) ? 1 : 0;
+        tab[g].resize((cnt[g] + 1) * isz);
+        image_any_item_write(tab[g].data(), cnt[g]++, it.offset, it.width, it.height, it.row_stride, (uint32_t)i, cls, parts);
+    }
+    // tables -> device through one of the two pinned / device pairs
+    const size_t o1 = (tab[0].size() + 255) & ~(size_t)255, o2 = o1 + ((tab[1].size() + 255) & ~(size_t)255);
+    const size_t bytes = o2 + reject.size() * 4;
+    const uint8_t* d_tab = nullptr;
+    int pair = -1;
+    if (bytes) {
+        std::lock_guard<std::mutex> lk(ctx->item_mu);
+        pair = ctx->item_next;
+        ctx->item_next ^= 1;
+        hipError_t e = hipEventSynchronize(ctx->item_used[pair]);          // the launches that read this pair last are done
+        if (e == hipSuccess && ctx->item_cap[pair] < bytes) {
+            if (ctx->item_h[pair]) (void)hipHostFree(ctx->item_h[pair]);
+            if (ctx->item_d[pair]) (void)hipFree(ctx->item_d[pair]);
+            ctx->item_h[pair] = ctx->item_d[pair] = nullptr;
+            ctx->item_cap[pair] = 0;
+            const size_t want = bytes + bytes / 2 + 4096;
+            e = hipHostMalloc((void**)&ctx->item_h[pair], want, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void**)&ctx->item_d[pair], want);
+            if (e == hipSuccess) ctx->item_cap[pair] = want;
+        }
+        if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "item table staging failed: %s", hipGetErrorString(e));
+        if (!tab[0].empty()) memcpy(ctx->item_h[pair], tab[0].data(), tab[0].size());
+        if (!tab[1].empty()) memcpy(ctx->item_h[pair] + o1, tab[1].data(), tab[1].size());
+        if (!reject.empty()) memcpy(ctx->item_h[pair] + o2, reject.data(), reject.size() * 4);
+        e = hipMemcpyAsync(ctx->item_d[pair], ctx->item_h[pair], bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "item table copy failed: %s", hipGetErrorString(e));
+        d_tab = ctx->item_d[pair];
+    }
+    const uint8_t* hi = base + frames_bytes;
+    for (int g = 0; g < 2; g++)
+        if (cnt[g])
+            launch_image_hash_any(algo, base, d_tab + (g ? o1 : 0), cnt[g], g == 1, 0, 0, 0, 0, 0, 0, base, hi, exact, out, status, st);
+    if (!reject.empty())
+        launch_image_reject_list(reinterpret_cast<const uint32_t*>(d_tab + o2), reject.size(), out, (uint32_t)rec, status, st);
+    hipError_t e = hipGetLastError();
+    if (pair >= 0 && e == hipSuccess) e = hipEventRecord(ctx->item_used[pair], st);
+    if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "ragged image launch failed: %s", hipGetErrorString(e));
+    for (uint32_t i : big) {
+        const ucfp_image_item& it = items[i];
+        e = (hipError_t)image_hash_ordered(ctx, algo, base + it.offset, 1, it.width, it.height, it.row_stride,
+                                           (size_t)it.row_stride * it.height, it.pixfmt, min_dim, max_dim,
+                                           exact ? exact + 32 * (size_t)i : nullptr, out + (size_t)i * rec, status ? status + i : nullptr, st);
+        if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "image launch failed: %s", hipGetErrorString(e));
+    }
+    return UCFP_OK;
 }
 }  // namespace ucfp
 
@@ -138,6 +237,8 @@ int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->audio_done, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->png_done, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->norm_done, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e2 == hipSuccess; i++) e2 = hipEventCreateWithFlags(&c->item_used[i], hipEventDisableTiming);
+    if (const char* v = getenv("UCFP_IMAGE_ANY_MAX_PIXELS")) c->any_max_pixels = (size_t)strtoull(v, nullptr, 10);   // (tuning)
     if (e2 != hipSuccess) {
         ucfp_ctx_destroy(c);
         return fail(UCFP_E_INDEX, "context allocation failed: %s", hipGetErrorString(e2));
@@ -159,6 +260,11 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->png_ws) (void)hipFree(c->png_ws);
     if (c->b3_ws) (void)hipFree(c->b3_ws);
     if (c->norm_done) (void)hipEventDestroy(c->norm_done);
+    for (int i = 0; i < 2; i++) {
+        if (c->item_h[i]) (void)hipHostFree(c->item_h[i]);
+        if (c->item_d[i]) (void)hipFree(c->item_d[i]);
+        if (c->item_used[i]) (void)hipEventDestroy(c->item_used[i]);
+    }
     delete c;
 }
 
@@ -198,6 +304,55 @@ int ucfp_image_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frame
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY((hipError_t)ucfp::image_hash_ordered(ctx, algo, frames, n, width, height, row_stride, frame_stride, pixfmt,
                                                  min_dim, max_dim, exact, out, status, (hipStream_t)stream));
+    return UCFP_OK;
+}
+
+int ucfp_image_hash_ragged_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_frames, size_t frames_bytes,
+                               const ucfp_image_item* items, size_t n, const ucfp_image_preprocess* pre, const uint8_t* d_exact,
+                               uint8_t* d_out, int32_t* d_status, void* stream) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    if (ucfp_image_record_bytes(algo) == 0)
+        return fail(UCFP_E_UNSUPPORTED, "image algo mask %u is not one of ahash|phash|dhash|multi", algo);
+    if (n == 0) return UCFP_OK;
+    if (!items || !d_frames || !d_out) return fail(UCFP_E_INVALID, "items/frames/out is NULL");
+    if (n > 0x7fffffffu) return fail(UCFP_E_INVALID, "batch of %zu frames exceeds one launch", n);
+    const uint32_t min_dim = pre ? pre->min_dimension : 32u, max_dim = pre ? pre->max_dimension : 8192u;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ucfp::image_hash_ragged(ctx, algo, d_frames, frames_bytes, items, n, min_dim, max_dim, d_exact, d_out, d_status,
+                                   (hipStream_t)stream);
+}
+
+int ucfp_image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t frames_bytes, const ucfp_image_item* items,
+                           size_t n, const ucfp_image_preprocess* pre, const uint8_t* exact, uint8_t* out, int32_t* status) {
+    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
+    const size_t rec = ucfp_image_record_bytes(algo);
+    if (rec == 0) return fail(UCFP_E_UNSUPPORTED, "image algo mask %u is not one of ahash|phash|dhash|multi", algo);
+    if (n == 0) return UCFP_OK;
+    if (!items || !frames || !out) return fail(UCFP_E_INVALID, "items/frames/out is NULL");
+    if (n > 0x7fffffffu) return fail(UCFP_E_INVALID, "batch of %zu frames exceeds one launch", n);
+    const uint32_t min_dim = pre ? pre->min_dimension : 32u, max_dim = pre ? pre->max_dimension : 8192u;
+    const size_t in_bytes = (frames_bytes + 64 + 255) & ~(size_t)255;
+    const size_t o_ex = (n * rec + 255) & ~(size_t)255, o_st = o_ex + ((n * 32 + 255) & ~(size_t)255);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = grow(&ctx->stage_in, &ctx->stage_in_cap, in_bytes);
+    if (rc) return rc;
+    rc = grow(&ctx->stage_out, &ctx->stage_out_cap, o_st + n * 4);
+    if (rc) return rc;
+    hipStream_t st = ctx->host_stream;
+    HIP_TRY(hipMemcpyAsync(ctx->stage_in, frames, frames_bytes, hipMemcpyHostToDevice, st));
+    uint8_t* d_exact = ctx->stage_out + o_ex;
+    int32_t* d_status = reinterpret_cast<int32_t*>(ctx->stage_out + o_st);
+    if (exact) HIP_TRY(hipMemcpyAsync(d_exact, exact, n * 32, hipMemcpyHostToDevice, st));
+    rc = ucfp::image_hash_ragged(ctx, algo, ctx->stage_in, frames_bytes, items, n, min_dim, max_dim, exact ? d_exact : nullptr,
+                                 ctx->stage_out, d_status, st);
+    if (rc) {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(out, ctx->stage_out, n * rec, hipMemcpyDeviceToHost, st));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return UCFP_OK;
 }
 

@@ -32,10 +32,11 @@ bool image_hash_needs_ws(const uint8_t* frames, uint32_t w, uint32_t h, size_t r
 // the fused any-geometry kernel (ragged batches; uniform ones of a geometry the square kernels do not take)
 bool image_any_plan(const uint8_t* base, uint64_t src, uint32_t w, uint32_t h, size_t row_stride, int pixfmt, uint32_t* cls,
                     uint32_t* parts);
+bool image_any_is_prefix(uint32_t cls);      // which of the two kernels (launches) a frame of this class belongs to
 size_t image_any_item_bytes();
 void image_any_item_write(void* dst, size_t i, uint64_t src, uint32_t w, uint32_t h, uint32_t row_stride, uint32_t slot, uint32_t cls,
                           uint32_t parts);
-int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, bool any_prefix, uint32_t proto_w,
+int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, bool prefix, uint32_t proto_w,
                           uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_parts, size_t frame_stride,
                           const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t stream);
 int launch_image_reject_list(const uint32_t* d_slots, size_t n, uint8_t* out, uint32_t rec, int32_t* status, hipStream_t stream);
@@ -48,6 +49,33 @@ int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t
 size_t blake3_ws_bytes(size_t n, size_t blob_bytes);
 int launch_blake3_batch(const uint8_t* blob, const uint64_t* offsets, size_t n, uint8_t* ws, uint8_t* out, hipStream_t stream);
 
+// ---- encoded uploads (png.hip, jpeg.hip): one file of a decode batch as the kernels see it ----
+// A RAGGED batch carries a device table of these, built by the host from the per-file probe results (every upload its own
+// geometry: the reference's route takes any image, src/server/handlers.rs:232-302); a UNIFORM batch -- ONE announced
+// geometry, the round-2/3 entry points -- passes no table and the kernels derive entry k from the launch's parameters.
+struct UpItem {
+    uint32_t file;        // index into the caller's offsets / status / records
+    uint32_t w, h;        // announced geometry: the file's own header must agree
+    int32_t pixfmt;       // announced decoded format (PNG; a JPEG's luma plane is GRAY8)
+    uint32_t row_stride;  // rows of the decoded frame, bytes
+    uint32_t bxp, byp;    // JPEG: the coefficient plane in blocks
+    uint32_t max_seg;     // JPEG: restart segments the file's table holds
+    uint64_t frame_off;   // decoded frame: bytes from the launch's frame base
+    uint64_t aux_off;     // PNG: filtered scanlines, bytes into the raw area; JPEG: coefficient plane, int16 units into the coefficient area
+    uint64_t seg_off;     // JPEG: segment table, words into the segment area
+};
+struct UpUniform {        // the same for entry k of a uniform batch: file = k, offsets k x stride
+    uint32_t w = 0, h = 0;
+    int32_t pixfmt = 0;
+    uint32_t row_stride = 0, bxp = 0, byp = 0, max_seg = 0;
+    uint64_t frame_stride = 0, aux_stride = 0;
+};
+__device__ __forceinline__ UpItem up_item(const UpItem* __restrict__ items, const UpUniform& u, size_t k) {
+    if (items) return items[k];
+    return UpItem{(uint32_t)k, u.w, u.h, u.pixfmt, u.row_stride, u.bxp, u.byp, u.max_seg, k * u.frame_stride, k * u.aux_stride,
+                  k * (uint64_t)(u.max_seg + 2)};
+}
+
 // png.hip
 struct PngWs {
     size_t zbuf = 0, info = 0, raw = 0, raw_stride = 0, raw_n = 0, total = 0;
@@ -57,7 +85,13 @@ int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uin
                       const PngWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
                       hipStream_t stream);
 int launch_png_merge_status(const uint8_t* ws, const PngWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
-                            hipStream_t stream);
+                            hipStream_t stream, const UpItem* d_items = nullptr);
+// ragged: n files listed in d_items (device); raw_total = bytes of the raw area (sum of the files' aligned scanline sizes),
+// max_row[f] = widest decoded row in bytes among the files announced as pixel format f (0: none; sizes the unfilter's LDS)
+size_t png_ragged_ws_bytes(size_t n, size_t png_bytes, size_t raw_total, PngWs* ws);
+size_t png_raw_bytes(uint32_t w, uint32_t h, int pixfmt);      // aligned bytes of one file's filtered scanlines in the raw area
+int launch_png_decode_ragged(const uint8_t* png, const uint64_t* offsets, const UpItem* d_items, size_t n, const uint32_t max_w[3],
+                             uint8_t* ws, const PngWs& l, uint8_t* frames, int32_t* status, hipStream_t stream);
 
 // jpeg.hip
 struct JpegWs {

@@ -1148,9 +1148,11 @@ __device__ __forceinline__ void any_phase_a(ImageLds& L, uint32_t* __restrict__ 
 __host__ __device__ constexpr uint32_t any_class(int bppc, bool aligned, int form) { return (uint32_t)bppc | (aligned ? 4u : 0u) | (uint32_t)form << 3; }
 
 // items == nullptr: a UNIFORM batch -- every frame is `proto` moved by blockIdx.x * frame_stride, slot = blockIdx.x (no table).
-// row_words: words of each wave's row buffer (kAnyRowWordsTaps when no frame of the launch takes the PREFIX form).
+// Two kernels, so that each gets the registers ITS forms need: TAPS frames (rows of up to 512 pixels; <= 106 VGPRs and a
+// 2 KiB row buffer per wave: two workgroups per CU) and PREFIX frames (wider rows; up to 163 VGPRs, 4 KiB row buffers: one).
+template <bool PREFIX>
 __global__ __launch_bounds__(kNT) void image_hash_any_kernel(const uint8_t* __restrict__ base, const ImgItem* __restrict__ items,
-                                                             ImgItem proto, size_t frame_stride, uint32_t n_items, uint32_t row_words,
+                                                             ImgItem proto, size_t frame_stride, uint32_t n_items,
                                                              uint32_t algo, const uint8_t* __restrict__ exact,
                                                              uint8_t* __restrict__ out, int32_t* __restrict__ status,
                                                              const uint8_t* lo, const uint8_t* hi) {
@@ -1164,12 +1166,13 @@ __global__ __launch_bounds__(kNT) void image_hash_any_kernel(const uint8_t* __re
         it.src += (uint64_t)blockIdx.x * frame_stride;
         it.slot = blockIdx.x;
     }
-    uint32_t* rowbuf = reinterpret_cast<uint32_t*>(any_lds + ((sizeof(ImageLds) + 15) & ~(size_t)15)) + (threadIdx.x >> 6) * row_words;
+    uint32_t* rowbuf = reinterpret_cast<uint32_t*>(any_lds + ((sizeof(ImageLds) + 15) & ~(size_t)15)) +
+                       (threadIdx.x >> 6) * (PREFIX ? kAnyRowWords : kAnyRowWordsTaps);
     switch (it.cls) {
-#define UCFP_ANY_CASE(BC, BPP, AL)                                                                         \
-    case any_class(BC, AL, 0): any_phase_a<BPP, 1, AL, true>(L, rowbuf, it, base, lo, hi); break;        \
-    case any_class(BC, AL, 1): any_phase_a<BPP, 2, AL, true>(L, rowbuf, it, base, lo, hi); break;        \
-    case any_class(BC, AL, 2): any_phase_a<BPP, 4, AL, false>(L, rowbuf, it, base, lo, hi); break;
+#define UCFP_ANY_CASE(BC, BPP, AL)                                                                                     \
+    case any_class(BC, AL, 0): if (!PREFIX) any_phase_a<BPP, 1, AL, true>(L, rowbuf, it, base, lo, hi); break;        \
+    case any_class(BC, AL, 1): if (!PREFIX) any_phase_a<BPP, 2, AL, true>(L, rowbuf, it, base, lo, hi); break;        \
+    case any_class(BC, AL, 2): if (PREFIX) any_phase_a<BPP, 4, AL, false>(L, rowbuf, it, base, lo, hi); break;
         UCFP_ANY_CASE(0, 1, true)
         UCFP_ANY_CASE(0, 1, false)
         UCFP_ANY_CASE(1, 3, true)
@@ -1390,6 +1393,7 @@ bool image_any_plan(const uint8_t* base, uint64_t src, uint32_t w, uint32_t h, s
     *parts = np;
     return true;
 }
+bool image_any_is_prefix(uint32_t cls) { return (cls >> 3) == 2; }
 
 size_t image_any_item_bytes() { return sizeof(ImgItem); }
 void image_any_item_write(void* dst, size_t i, uint64_t src, uint32_t w, uint32_t h, uint32_t row_stride, uint32_t slot, uint32_t cls,
@@ -1397,22 +1401,28 @@ void image_any_item_write(void* dst, size_t i, uint64_t src, uint32_t w, uint32_
     reinterpret_cast<ImgItem*>(dst)[i] = ImgItem{src, w, h, row_stride, slot, cls, parts};
 }
 
+// One launch over frames of ONE form group (prefix: the PREFIX kernel, rows of more than 512 pixels; else the TAPS kernel).
 // d_items == nullptr: uniform batch of n frames described by (proto_*) and frame_stride.
-int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, bool any_prefix, uint32_t proto_w,
+int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, bool prefix, uint32_t proto_w,
                           uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_parts, size_t frame_stride,
                           const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t stream) {
     if (n == 0) return 0;
-    const uint32_t row_words = any_prefix ? kAnyRowWords : kAnyRowWordsTaps;
-    const size_t lds = ((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * row_words * 4;
+    const size_t lds = ((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * (prefix ? kAnyRowWords : kAnyRowWordsTaps) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * kAnyRowWords * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * kAnyRowWordsTaps * 4));
         attr_set = true;
     }
     const ImgItem proto{0, proto_w, proto_h, proto_row_stride, 0, proto_cls, proto_parts};
-    hipLaunchKernelGGL(image_hash_any_kernel, dim3((unsigned)n), dim3(kNT), lds, stream, base, reinterpret_cast<const ImgItem*>(d_items),
-                       proto, frame_stride, (uint32_t)n, row_words, algo, exact, out, status, lo, hi);
+    if (prefix)
+        hipLaunchKernelGGL(image_hash_any_kernel<true>, dim3((unsigned)n), dim3(kNT), lds, stream, base, reinterpret_cast<const ImgItem*>(d_items),
+                           proto, frame_stride, (uint32_t)n, algo, exact, out, status, lo, hi);
+    else
+        hipLaunchKernelGGL(image_hash_any_kernel<false>, dim3((unsigned)n), dim3(kNT), lds, stream, base, reinterpret_cast<const ImgItem*>(d_items),
+                           proto, frame_stride, (uint32_t)n, algo, exact, out, status, lo, hi);
     return 0;
 }
 

@@ -413,13 +413,14 @@ struct PngInfo {
     uint32_t zlen;      // bytes of the gathered zlib stream
     int32_t status;
     uint32_t raw_n;     // filtered bytes the stream must inflate to: height x (1 + width x bytes per pixel IN THE FILE)
-    uint16_t layout;    // kLayoutPlain: the file's pixels are the announced format; kLayoutPalette: 8-bit indices into
+    uint8_t layout;     // kLayoutPlain: the file's pixels are the announced format; kLayoutPalette: 8-bit indices into
                         // PLTE -> RGB8; kLayoutGreyAlpha: 8-bit grey + alpha -> GRAY8 (the alpha byte is dropped, as the
                         // host path does: luma takes no alpha, DESIGN I1)
+    uint8_t fbpp;       // bytes per pixel IN THE FILE (1, 2, 3, 4)
     uint16_t plte_n;    // palette entries
     uint32_t plte_off;  // offset of the PLTE data inside the file
 };
-constexpr uint16_t kLayoutPlain = 0, kLayoutPalette = 1, kLayoutGreyAlpha = 2;
+constexpr uint8_t kLayoutPlain = 0, kLayoutPalette = 1, kLayoutGreyAlpha = 2;
 
 __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
     return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3];
@@ -472,12 +473,16 @@ __device__ uint32_t chunk_crc(const uint8_t* base, uint32_t total, const uint32_
 
 // One wave per file: validate, gather IDAT payloads to zbuf + align16(offsets[i]).
 __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict__ png, const uint64_t* __restrict__ offsets,
-                                                     size_t n, uint32_t width, uint32_t height, int pixfmt,
+                                                     size_t n, const UpItem* __restrict__ items, UpUniform uni,
                                                      uint8_t* __restrict__ zbuf, PngInfo* __restrict__ info) {
     __shared__ uint32_t crc_tab[1024];
     __shared__ uint32_t x2n[32];
-    const size_t img = blockIdx.x;
-    if (img >= n) return;
+    const size_t k = blockIdx.x;
+    if (k >= n) return;
+    const UpItem item = up_item(items, uni, k);
+    const size_t img = item.file;                    // (the gather area is addressed by the FILE's offset, info by the entry)
+    const uint32_t width = item.w, height = item.h;
+    const int pixfmt = item.pixfmt;
     const int lane = threadIdx.x;
     for (uint32_t i = lane; i < 256; i += 64) {
         uint32_t c = i;
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
     uint8_t* z = zbuf + ((offsets[img] + 15) & ~(uint64_t)15);
     int32_t status = 0;
     uint32_t zn = 0, fbpp = 1, plte_off = 0, plte_n = 0;
-    uint16_t layout = kLayoutPlain;
+    uint8_t layout = kLayoutPlain;
     if (len < 8 + 25 + 12 || p[0] != 137 || p[1] != 80 || p[2] != 78 || p[3] != 71 || p[4] != 13 || p[5] != 10 || p[6] != 26 ||
         p[7] != 10 || be32(p + 8) != 13 || p[12] != 'I' || p[13] != 'H' || p[14] != 'D' || p[15] != 'R') {
         status = UCFP_E_MODALITY;
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
     // writing its zlib header there in this same launch (a valid file's zn + 4 stays inside its own byte range).
     if (status == 0 && lane < 4) z[zn + lane] = 0;
     if (lane == 0)
-        info[img] = PngInfo{zn, status, height * (1u + width * fbpp), layout, (uint16_t)plte_n, plte_off};
+        info[k] = PngInfo{zn, status, height * (1u + width * fbpp), layout, (uint8_t)fbpp, (uint16_t)plte_n, plte_off};
 }
 
 #ifdef PNG_PROF
@@ -593,18 +598,19 @@ __device__ unsigned long long g_png_prof[16];
 // One wave per image: zlib stream -> filtered scanlines (raw_n bytes expected).
 template <class C>
 __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets,
-                                                        size_t n, PngInfo* __restrict__ info, uint8_t* __restrict__ raw,
-                                                        size_t raw_stride) {
+                                                        size_t n, const UpItem* __restrict__ items, UpUniform uni,
+                                                        PngInfo* __restrict__ info, uint8_t* __restrict__ raw) {
     __shared__ InflateLds<C> L;
-    const size_t img = blockIdx.x;
+    const size_t img = blockIdx.x;                   // entry of the batch: info[img]
     if (img >= n) return;
     const int lane = threadIdx.x;
     if (info[img].status != 0) return;
+    const UpItem item = up_item(items, uni, img);
     const uint32_t raw_n = info[img].raw_n;
-    const uint8_t* z = zbuf + ((offsets[img] + 15) & ~(uint64_t)15);
+    const uint8_t* z = zbuf + ((offsets[item.file] + 15) & ~(uint64_t)15);
     const uint32_t zlen = info[img].zlen;
     const uint32_t zwords = (zlen + 3) / 4, total_bits = zlen * 8;
-    uint8_t* out = raw + img * raw_stride;
+    uint8_t* out = raw + item.aux_off;
     bool bad = zlen < 6;
     if (!bad) {
         const uint32_t cmf = z[0], flg = z[1];
@@ -935,33 +941,38 @@ struct UnfilterCfg {
 // bytes per index through the file's PLTE, kLayoutGreyAlpha (BPP 2) the grey byte.  One launch per layout a batch may
 // hold; a launch skips the files of the other layouts (and only the plain launch reports the status of rejected files).
 template <int BPP, int LAYOUT>
-__global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restrict__ raw, size_t raw_stride,
-                                                         PngInfo* __restrict__ info, size_t n, uint32_t w, uint32_t h,
-                                                         uint8_t* __restrict__ frames, size_t row_stride, size_t frame_stride,
+__global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restrict__ raw, const UpItem* __restrict__ items,
+                                                         UpUniform uni, uint32_t uprow_bytes /* widest row of the launch, 16-byte rounded */,
+                                                         PngInfo* __restrict__ info, size_t n, uint8_t* __restrict__ frames,
                                                          int32_t* __restrict__ status, const uint8_t* __restrict__ png,
                                                          const uint64_t* __restrict__ offsets) {
     using Cfg = UnfilterCfg<BPP>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint8_t* slots = lds_raw;                               // [2][64 lanes][kSlot]; byte 3 = the byte before the block, byte 4.. = its pixels
     uint8_t* uprow = lds_raw + 2 * 64 * Cfg::kSlot;         // w * BPP bytes: the last row lane 63 finished
-    uint8_t* plte = uprow + (((size_t)w * BPP + 15) & ~(size_t)15);   // kLayoutPalette: 256 x 3 bytes, black beyond the file's entries
-    const size_t img = blockIdx.x;
-    if (img >= n) return;
+    uint8_t* plte = uprow + uprow_bytes;                    // kLayoutPalette: 256 x 3 bytes, black beyond the file's entries
+    const size_t ent = blockIdx.x;
+    if (ent >= n) return;
     const int lane = threadIdx.x;
-    const int32_t st = info[img].status;
+    const UpItem item = up_item(items, uni, ent);
+    const size_t img = item.file;
+    const uint32_t w = item.w, h = item.h;
+    const size_t row_stride = item.row_stride;
+    const int32_t st = info[ent].status;
     if (st != 0) {
         if (LAYOUT == kLayoutPlain && lane == 0 && status) status[img] = st;
         return;
     }
-    if (info[img].layout != LAYOUT) return;
+    // a launch takes the files of its own layout and bytes per pixel (a ragged batch holds every kind)
+    if (info[ent].layout != LAYOUT || info[ent].fbpp != BPP) return;
     if (LAYOUT == kLayoutPalette) {
-        const uint8_t* pp = png + offsets[img] + info[img].plte_off;
-        const uint32_t pn = (uint32_t)info[img].plte_n * 3;
+        const uint8_t* pp = png + offsets[img] + info[ent].plte_off;
+        const uint32_t pn = (uint32_t)info[ent].plte_n * 3;
         for (uint32_t i = lane; i < 768; i += 64) plte[i] = i < pn ? pp[i] : 0;
         wave_lds_fence();
     }
-    const uint8_t* src = raw + img * raw_stride;
-    uint8_t* dst = frames + img * frame_stride;
+    const uint8_t* src = raw + item.aux_off;
+    uint8_t* dst = frames + item.frame_off;
     const uint32_t rowb = w * BPP;
     const uint32_t W = ((w > 64 ? w : 64) + 63) & ~63u;       // steps per row: whole blocks, and lane 63 is done with x before lane 0 needs it
     const uint32_t bpr = W / 64;                              // blocks per row
@@ -1107,18 +1118,19 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restr
     if (nblocks >= 1) flush_block(nblocks - 1);               // the loop flushed blocks 0 .. nblocks - 2
     const bool any_bad = __ballot(bad) != 0;
     if (lane == 0) {
-        if (any_bad) info[img].status = UCFP_E_MODALITY;
+        if (any_bad) info[ent].status = UCFP_E_MODALITY;
         if (status) status[img] = any_bad ? UCFP_E_MODALITY : 0;
     }
 }
 
 // Records of files that did not decode are zeroed and carry the decoder's status.
-__global__ void png_merge_status_kernel(const PngInfo* __restrict__ info, size_t n, uint8_t* __restrict__ out, uint32_t rec,
-                                        int32_t* __restrict__ status) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x / 64 + threadIdx.x / 64;
-    if (i >= n) return;
-    const int32_t st = info[i].status;
+__global__ void png_merge_status_kernel(const PngInfo* __restrict__ info, const UpItem* __restrict__ items, size_t n,
+                                        uint8_t* __restrict__ out, uint32_t rec, int32_t* __restrict__ status) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x / 64 + threadIdx.x / 64;
+    if (e >= n) return;
+    const int32_t st = info[e].status;
     if (st == 0) return;
+    const size_t i = items ? items[e].file : e;
     const int lane = threadIdx.x & 63;
     for (uint32_t b = lane * 4; b < rec; b += 256) *reinterpret_cast<uint32_t*>(out + i * rec + b) = 0;
     if (lane == 0 && status) status[i] = st;
@@ -1127,10 +1139,10 @@ __global__ void png_merge_status_kernel(const PngInfo* __restrict__ info, size_t
 }  // namespace
 
 int launch_png_merge_status(const uint8_t* ws, const PngWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
-                            hipStream_t stream) {
+                            hipStream_t stream, const UpItem* d_items) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(png_merge_status_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
-                       reinterpret_cast<const PngInfo*>(ws + l.info), n, out, rec, status);
+                       reinterpret_cast<const PngInfo*>(ws + l.info), d_items, n, out, rec, status);
     return 0;
 }
 
@@ -1145,61 +1157,99 @@ extern "C" int ucfp_debug_png_prof(unsigned long long* out16, int reset) {
 }
 #endif
 
-size_t png_ws_bytes(size_t n, size_t png_bytes, uint32_t w, uint32_t h, int pixfmt, PngWs* ws) {
+size_t png_raw_bytes(uint32_t w, uint32_t h, int pixfmt) {
     const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 2 /* a grey + alpha file */ : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
     const size_t raw_n = (size_t)h * ((size_t)w * bpp + 1);
-    PngWs l;
-    l.raw_n = raw_n;
-    l.raw_stride = (raw_n + 15 + 64) & ~(size_t)15;
+    return (raw_n + 15 + 64) & ~(size_t)15;
+}
+
+static size_t png_ws_layout(size_t n, size_t png_bytes, size_t raw_total, PngWs* l) {
     size_t off = 0;
-    l.zbuf = off;
+    l->zbuf = off;
     off += (png_bytes + 16 + 64 + 255) & ~(size_t)255;
-    l.info = off;
+    l->info = off;
     off += (n * sizeof(PngInfo) + 255) & ~(size_t)255;
-    l.raw = off;
-    off += n * l.raw_stride;
-    l.total = off;
+    l->raw = off;
+    off += raw_total;
+    l->total = off;
+    return off;
+}
+
+size_t png_ws_bytes(size_t n, size_t png_bytes, uint32_t w, uint32_t h, int pixfmt, PngWs* ws) {
+    PngWs l;
+    l.raw_stride = png_raw_bytes(w, h, pixfmt);
+    l.raw_n = l.raw_stride;
+    const size_t off = png_ws_layout(n, png_bytes, n * l.raw_stride, &l);
     if (ws) *ws = l;
     return off;
+}
+
+size_t png_ragged_ws_bytes(size_t n, size_t png_bytes, size_t raw_total, PngWs* ws) {
+    PngWs l;
+    const size_t off = png_ws_layout(n, png_bytes, raw_total, &l);
+    if (ws) *ws = l;
+    return off;
+}
+
+// max_w[f]: widest frame (pixels) announced as pixel format f among the launch's files (0: no such file)
+static int png_decode_launches(const uint8_t* png, const uint64_t* offsets, const UpItem* d_items, const UpUniform& uni, size_t n,
+                               const uint32_t max_w[3], uint8_t* ws, const PngWs& l, uint8_t* frames, int32_t* status,
+                               hipStream_t stream) {
+    PngInfo* info = reinterpret_cast<PngInfo*>(ws + l.info);
+    hipLaunchKernelGGL(png_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, png, offsets, n, d_items, uni, ws + l.zbuf, info);
+    // wide rounds while the batch leaves most of the chip's wave slots empty anyway (RoundCfg)
+    // measured (files/s, narrow | wide): 600: 83 k | 98 k, 1000: 130 k | 157 k, 1400: 162 k | 118 k, 2000: 141 k | 160 k,
+    // 3000: 189 k | 164 k -- the chip holds about 1024 wide or 1536 narrow waves at a time
+    if (n <= 512)           // two waves per CU hold such a batch: 512-bit rounds, 10 % less latency than 256-bit ones
+        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<512>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, d_items, uni,
+                           info, ws + l.raw);
+    else if (n <= 1024 || (n > 1536 && n <= 2048))
+        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<256>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, d_items, uni,
+                           info, ws + l.raw);
+    else
+        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<128>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, d_items, uni,
+                           info, ws + l.raw);
+    // one unfilter launch per file layout the announced formats admit: GRAY8 <- grey | grey + alpha, RGB8 <- RGB | palette
+    auto go = [&](auto kern, size_t fbpp, bool palette, uint32_t wmax) {
+        const uint32_t uprow = (uint32_t)(((size_t)wmax * fbpp + 15) & ~(size_t)15);
+        const size_t lds = uprow + (palette ? 768 : 0) + 2 * 64 * (size_t)((3 + 1 + 64 * fbpp + 15 + 15) / 16) * 16;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, stream, ws + l.raw, d_items, uni, uprow, info, n, frames, status, png,
+                           offsets);
+    };
+    if (max_w[UCFP_PIX_GRAY8]) {
+        go(png_unfilter_kernel<1, kLayoutPlain>, 1, false, max_w[UCFP_PIX_GRAY8]);
+        go(png_unfilter_kernel<2, kLayoutGreyAlpha>, 2, false, max_w[UCFP_PIX_GRAY8]);
+    }
+    if (max_w[UCFP_PIX_RGB8]) {
+        go(png_unfilter_kernel<3, kLayoutPlain>, 3, false, max_w[UCFP_PIX_RGB8]);
+        go(png_unfilter_kernel<1, kLayoutPalette>, 1, true, max_w[UCFP_PIX_RGB8]);
+    }
+    if (max_w[UCFP_PIX_RGBA8]) go(png_unfilter_kernel<4, kLayoutPlain>, 4, false, max_w[UCFP_PIX_RGBA8]);
+    return 0;
 }
 
 int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, int pixfmt, uint8_t* ws,
                       const PngWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
                       hipStream_t stream) {
     if (n == 0) return 0;
-    PngInfo* info = reinterpret_cast<PngInfo*>(ws + l.info);
-    hipLaunchKernelGGL(png_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, png, offsets, n, w, h, pixfmt, ws + l.zbuf, info);
-    // wide rounds while the batch leaves most of the chip's wave slots empty anyway (RoundCfg)
-    // measured (files/s, narrow | wide): 600: 83 k | 98 k, 1000: 130 k | 157 k, 1400: 162 k | 118 k, 2000: 141 k | 160 k,
-    // 3000: 189 k | 164 k -- the chip holds about 1024 wide or 1536 narrow waves at a time
-    if (n <= 512)           // two waves per CU hold such a batch: 512-bit rounds, 10 % less latency than 256-bit ones
-        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<512>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
-                           ws + l.raw, l.raw_stride);
-    else if (n <= 1024 || (n > 1536 && n <= 2048))
-        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<256>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
-                           ws + l.raw, l.raw_stride);
-    else
-        hipLaunchKernelGGL(png_inflate_kernel<RoundCfg<128>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, info,
-                           ws + l.raw, l.raw_stride);
-    // one unfilter launch per file layout the announced format admits: GRAY8 <- grey | grey + alpha, RGB8 <- RGB | palette
-    auto go = [&](auto kern, size_t fbpp, bool palette) {
-        const size_t lds = (((size_t)w * fbpp + 15) & ~(size_t)15) + (palette ? 768 : 0) +
-                           2 * 64 * (size_t)((3 + 1 + 64 * fbpp + 15 + 15) / 16) * 16;
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, stream, ws + l.raw, l.raw_stride, info, n, w, h, frames,
-                           row_stride, frame_stride, status, png, offsets);
-    };
-    if (pixfmt == UCFP_PIX_GRAY8) {
-        go(png_unfilter_kernel<1, kLayoutPlain>, 1, false);
-        go(png_unfilter_kernel<2, kLayoutGreyAlpha>, 2, false);
-    } else if (pixfmt == UCFP_PIX_RGB8) {
-        go(png_unfilter_kernel<3, kLayoutPlain>, 3, false);
-        go(png_unfilter_kernel<1, kLayoutPalette>, 1, true);
-    } else {
-        go(png_unfilter_kernel<4, kLayoutPlain>, 4, false);
-    }
-    return 0;
+    UpUniform uni;
+    uni.w = w;
+    uni.h = h;
+    uni.pixfmt = pixfmt;
+    uni.row_stride = (uint32_t)row_stride;
+    uni.frame_stride = frame_stride;
+    uni.aux_stride = l.raw_stride;
+    uint32_t max_w[3] = {0, 0, 0};
+    max_w[pixfmt] = w;
+    return png_decode_launches(png, offsets, nullptr, uni, n, max_w, ws, l, frames, status, stream);
+}
+
+int launch_png_decode_ragged(const uint8_t* png, const uint64_t* offsets, const UpItem* d_items, size_t n, const uint32_t max_w[3],
+                             uint8_t* ws, const PngWs& l, uint8_t* frames, int32_t* status, hipStream_t stream) {
+    if (n == 0) return 0;
+    return png_decode_launches(png, offsets, d_items, UpUniform{}, n, max_w, ws, l, frames, status, stream);
 }
 
 }  // namespace ucfp

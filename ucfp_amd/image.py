@@ -113,6 +113,61 @@ def fingerprint_frames(frames: np.ndarray, *, algo: int = MULTI, pixfmt: int = P
 
 
 # ------------------------------------------------------------------------------------------
+# ragged batches: every frame its own geometry (the reference's route takes any upload, handlers.rs:232-302)
+# ------------------------------------------------------------------------------------------
+
+def make_items(geoms) -> "C.Array":
+    """[(offset, width, height, row_stride, pixfmt), ...] -> ucfp_image_item array."""
+    arr = (_lib.ImageItem * max(len(geoms), 1))()
+    for i, (off, w, h, rs, fmt) in enumerate(geoms):
+        arr[i] = _lib.ImageItem(int(off), int(w), int(h), int(rs), int(fmt))
+    return arr
+
+
+def fingerprint_frames_ragged_dev(frames_ptr: int, frames_bytes: int, geoms, *, algo: int = MULTI, exact_ptr: int = 0,
+                                  out_ptr: int, status_ptr: int = 0, stream: int = 0,
+                                  preprocess: Optional[PreprocessConfig] = None, ctx=None) -> None:
+    """Enqueue hashing of device-resident frames of ANY mix of geometries: geoms[i] = (byte offset into the buffer at
+    frames_ptr, width, height, row_stride, pixfmt).  One launch per form of row; no sync (ucfp_image_hash_ragged_dev)."""
+    ctx = ctx or _lib.current_context()
+    pre = (preprocess or PreprocessConfig())._c()
+    items = geoms if not isinstance(geoms, (list, tuple)) else make_items(geoms)
+    n = len(geoms)
+    _lib.check(_lib.load().ucfp_image_hash_ragged_dev(ctx.handle, algo, frames_ptr, frames_bytes, items, n, C.byref(pre),
+                                                      exact_ptr or None, out_ptr, status_ptr or None, stream or None))
+
+
+def fingerprint_frames_ragged(frames: Sequence[np.ndarray], pixfmts: Sequence[int], *, algo: int = MULTI,
+                              exact: Optional[np.ndarray] = None, preprocess: Optional[PreprocessConfig] = None, ctx=None):
+    """Hash host-resident decoded frames of different sizes ([h, w] or [h, w, c] uint8 each) in one call through the
+    host-pointer ABI (ucfp_image_hash_ragged).  Returns (records uint8 [n, record_bytes], status int32 [n])."""
+    ctx = ctx or _lib.current_context()
+    n = len(frames)
+    rec = record_bytes(algo)
+    geoms, parts, off = [], [], 0
+    for f, fmt in zip(frames, pixfmts):
+        f = np.ascontiguousarray(f, dtype=np.uint8)
+        h, w = f.shape[:2]
+        if f.size != h * w * _BPP[fmt]:
+            raise ModalityError(f"frame shape {f.shape} does not match pixfmt {fmt}")
+        geoms.append((off, w, h, w * _BPP[fmt], fmt))
+        parts.append(f.reshape(-1))
+        off += f.size
+    blob = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    out = np.zeros((max(n, 1), rec), np.uint8)
+    status = np.zeros(max(n, 1), np.int32)
+    ex = None
+    if exact is not None:
+        ex = np.ascontiguousarray(exact, dtype=np.uint8)
+        if ex.shape != (n, 32):
+            raise ModalityError("exact must be [n, 32] bytes")
+    pre = (preprocess or PreprocessConfig())._c()
+    _lib.check(_lib.load().ucfp_image_hash_ragged(ctx.handle, algo, blob.ctypes.data, blob.size, make_items(geoms), n, C.byref(pre),
+                                                  ex.ctypes.data if ex is not None else None, out.ctypes.data, status.ctypes.data))
+    return out[:n], status[:n]
+
+
+# ------------------------------------------------------------------------------------------
 # encoded PNG files in (SURVEY 8f N4): chunk walk, inflate and filter reconstruction on the GPU
 # ------------------------------------------------------------------------------------------
 NEEDS_HOST = 1

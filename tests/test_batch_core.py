@@ -32,3 +32,15 @@ def test_batch_core_many_more_threads_than_slots(tmp_path):
     exe = _build(tmp_path, "-O2")
     r = subprocess.run([exe, "200", "100", "50"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_rounding_division_magic_numbers(tmp_path):
+    """The fused image kernel's floor((2 acc + D) / 2 D) is one multiply-high with a per-frame magic number
+    (ucfp_amd/csrc/any_magic.h): exact at every quotient boundary for a grid of geometries and random divisors."""
+    cxx = shutil.which("g++")
+    if not cxx:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "any_magic_check")
+    subprocess.run([cxx, "-std=c++17", "-O2", os.path.join(HERE, "native", "any_magic_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr

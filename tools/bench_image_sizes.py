@@ -21,9 +21,14 @@ def main():
              (301, 200, image.PIX_RGB8), (641, 481, image.PIX_GRAY8), (1023, 767, image.PIX_RGB8), (1366, 768, image.PIX_RGB8),
              (300, 200, image.PIX_GRAY8), (640, 480, image.PIX_GRAY8)]
     bpp = {image.PIX_GRAY8: 1, image.PIX_RGB8: 3, image.PIX_RGBA8: 4}
+    if len(sys.argv) >= 4:            # one case: w h bytes-per-pixel [frames]  (profiling runs)
+        fmt = {1: image.PIX_GRAY8, 3: image.PIX_RGB8, 4: image.PIX_RGBA8}[int(sys.argv[3])]
+        cases = [(int(sys.argv[1]), int(sys.argv[2]), fmt)]
     for w, h, fmt in cases:
         fb = w * h * bpp[fmt]
         n = max(8, min(20000, int(4e9 // fb)))
+        if len(sys.argv) >= 5:
+            n = int(sys.argv[4])
         frames = torch.randint(0, 256, (n, fb), dtype=torch.uint8, device=dev)
         out = torch.empty((n, 536), dtype=torch.uint8, device=dev)
 

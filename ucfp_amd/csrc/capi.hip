@@ -110,11 +110,11 @@ int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size
     }
     // a geometry the square kernels do not take: up to any_max_pixels per frame the fused any-geometry kernel (one
     // workgroup per frame, no workspace); larger frames are normalised by many waves each into the shared workspace
-    uint32_t cls = 0, parts = 0;
-    if (n && (size_t)w * h <= ctx->any_max_pixels && image_any_plan(frames, 0, w, h, row_stride, pixfmt, &cls, &parts)) {
+    uint32_t cls = 0, magic = 0, shift = 0;
+    if (n && (size_t)w * h <= ctx->any_max_pixels && image_any_plan(frames, 0, w, h, row_stride, pixfmt, &cls, &magic, &shift)) {
         const size_t bpp = pixfmt == 0 ? 1 : pixfmt == 1 ? 3 : 4;
         const uint8_t* hi = frames + (n - 1) * frame_stride + (size_t)(h - 1) * row_stride + (size_t)w * bpp;
-        launch_image_hash_any(algo, frames, nullptr, n, image_any_is_prefix(cls), w, h, (uint32_t)row_stride, cls, parts, frame_stride,
+        launch_image_hash_any(algo, frames, nullptr, n, image_any_group(cls), w, h, (uint32_t)row_stride, cls, magic, shift, frame_stride,
                               frames, hi, exact, out, status, stream);
         return (int)hipGetLastError();
     }
@@ -136,8 +136,8 @@ int image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* base, size_t 
     const size_t rec = algo == 7u ? 536 : 168, isz = image_any_item_bytes();
     // plan on the host: form group, class and parts of every frame
     std::vector<uint32_t> reject, big;
-    std::vector<uint8_t> tab[2];          // ImgItem rows of the TAPS and of the PREFIX launch
-    size_t cnt[2] = {0, 0};
+    std::vector<uint8_t> tab[3];          // ImgItem rows of the three width groups (rows up to 512 / 1024 / 2048 pixels): a launch each
+    size_t cnt[3] = {0, 0, 0};
     for (size_t i = 0; i < n; i++) {
         const ucfp_image_item& it = items[i];
         if (it.pixfmt < UCFP_PIX_GRAY8 || it.pixfmt > UCFP_PIX_RGBA8) return capi_fail(UCFP_E_INVALID, "item %zu: unknown pixfmt %d", i, it.pixfmt);
@@ -149,18 +149,21 @@ int image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* base, size_t 
         if (it.row_stride < (size_t)it.width * bpp) return capi_fail(UCFP_E_INVALID, "item %zu: row_stride %u < width * bpp", i, it.row_stride);
         const uint64_t end = it.offset + (uint64_t)(it.height - 1) * it.row_stride + (uint64_t)it.width * bpp;
         if (end > frames_bytes || end < it.offset) return capi_fail(UCFP_E_INVALID, "item %zu reaches beyond the %zu bytes of frames", i, frames_bytes);
-        uint32_t cls = 0, parts = 0;
+        uint32_t cls = 0, magic = 0, shift = 0;
         if ((size_t)it.width * it.height > ctx->any_max_pixels ||
-            !image_any_plan(base, it.offset, it.width, it.height, it.row_stride, it.pixfmt, &cls, &parts)) {
+            !image_any_plan(base, it.offset, it.width, it.height, it.row_stride, it.pixfmt, &cls, &magic, &shift)) {
             big.push_back((uint32_t)i);
             continue;
         }
-        const int g = image_any_is_prefix(cls) ? 1 : 0;
+        const int g = image_any_group(cls);
         tab[g].resize((cnt[g] + 1) * isz);
-        image_any_item_write(tab[g].data(), cnt[g]++, it.offset, it.width, it.height, it.row_stride, (uint32_t)i, cls, parts);
+        image_any_item_write(tab[g].data(), cnt[g]++, it.offset, it.width, it.height, it.row_stride, (uint32_t)i, cls, magic, shift);
     }
     // tables -> device through one of the two pinned / device pairs
-    const size_t o1 = (tab[0].size() + 255) & ~(size_t)255, o2 = o1 + ((tab[1].size() + 255) & ~(size_t)255);
+    size_t o[4];
+    o[0] = 0;
+    for (int g = 0; g < 3; g++) o[g + 1] = o[g] + ((tab[g].size() + 255) & ~(size_t)255);
+    const size_t o2 = o[3];
     const size_t bytes = o2 + reject.size() * 4;
     const uint8_t* d_tab = nullptr;
     int pair = -1;
@@ -180,17 +183,17 @@ int image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* base, size_t 
             if (e == hipSuccess) ctx->item_cap[pair] = want;
         }
         if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "item table staging failed: %s", hipGetErrorString(e));
-        if (!tab[0].empty()) memcpy(ctx->item_h[pair], tab[0].data(), tab[0].size());
-        if (!tab[1].empty()) memcpy(ctx->item_h[pair] + o1, tab[1].data(), tab[1].size());
+        for (int g = 0; g < 3; g++)
+            if (!tab[g].empty()) memcpy(ctx->item_h[pair] + o[g], tab[g].data(), tab[g].size());
         if (!reject.empty()) memcpy(ctx->item_h[pair] + o2, reject.data(), reject.size() * 4);
         e = hipMemcpyAsync(ctx->item_d[pair], ctx->item_h[pair], bytes, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "item table copy failed: %s", hipGetErrorString(e));
         d_tab = ctx->item_d[pair];
     }
     const uint8_t* hi = base + frames_bytes;
-    for (int g = 0; g < 2; g++)
+    for (int g = 0; g < 3; g++)
         if (cnt[g])
-            launch_image_hash_any(algo, base, d_tab + (g ? o1 : 0), cnt[g], g == 1, 0, 0, 0, 0, 0, 0, base, hi, exact, out, status, st);
+            launch_image_hash_any(algo, base, d_tab + o[g], cnt[g], g, 0, 0, 0, 0, 0, 0, 0, base, hi, exact, out, status, st);
     if (!reject.empty())
         launch_image_reject_list(reinterpret_cast<const uint32_t*>(d_tab + o2), reject.size(), out, (uint32_t)rec, status, st);
     hipError_t e = hipGetLastError();

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "../../include/ucfp_dct32.h"
+#include "any_magic.h"
 #include "common.h"
 
 namespace ucfp {
@@ -903,51 +904,58 @@ __global__ __launch_bounds__(64) void image_normalize_stream_kernel(
 // The streaming normaliser above writes a 64 KiB plane per frame that the hash kernel reads back: for the frames uploads
 // are made of (a few hundred pixels a side) that plane is as large as the frame itself, and two launches' fixed costs
 // land on every frame.  Here ONE workgroup takes a frame from source bytes to record: wave v owns destination rows
-// [32 v, 32 v + 32) -- four whole 8-row tile bands, so everything phase B needs from them is wave-local -- streams its
-// source rows exactly as the streaming kernel does (vertical pass first, exact integers) and, when a destination row is
-// complete, turns it into its four normalised pixels per lane IN REGISTERS and folds them straight into the LDS planes of
-// ImageLds (s2 2x2 means, v8 column sums, gsum / g32 tile totals).  The 256 x 256 plane is never stored anywhere.
-// Every frame carries its own geometry (ImgItem), so one launch hashes a batch of frames of any mix of sizes, strides and
-// pixel formats: the kernel dispatches on the frame's class (bytes per pixel, strips per lane, alignment, horizontal form).
-// Horizontal pass, two forms (same integers, spec I3):
-//   TAPS    w <= 512: a destination column overlaps at most three source pixels; the accumulated row T goes to LDS as it
-//           is and a pixel is three reads and three multiply-adds with weights fixed per lane for the whole frame;
-//   PREFIX  wider rows: the wrapping prefix sums of the streaming kernel, scanned with DPP row shifts (no LDS round trips).
-// The rounding division floor((2 R + D) / 2 D) is a float estimate plus ONE exact correction step (|error| < 1: the
-// quotient is at most 255); 2 D < 2^24 keeps every product in v_mul_u32_u24 range (frames of up to 8.3 M pixels; larger
-// ones take the two-launch path).
+// [32 v, 32 v + 32) -- four whole 8-row tile bands, so everything phase B needs from them is wave-local -- and streams the
+// source rows that overlap them, HORIZONTAL PASS FIRST (the area resample is separable and exact in integers, spec I3, so
+// the order of the passes is free):
+//   1. a source row arrives as strips of four pixels per lane (64 lanes read 256 / 768 / 1024 contiguous bytes); its lumas
+//      go to the wave's LDS row buffer as BYTES, four per strip;
+//   2. a lane owns four destination columns.  A column's source window is a run of bytes: 256-weight pixels inside, one
+//      partly covered pixel at either end.  The window is fetched as aligned dwords + v_alignbyte, and
+//          H = (dot4(window, inside mask) << 8) + dot4(window, edge weights)
+//      -- two v_dot4_u32_u8 per four source pixels, masks and weights fixed per lane for the whole frame;
+//   3. vertical: acc += overlap(y, j) * H for the destination row(s) j the source row falls into; when row j is complete
+//      its four pixels per lane are floor((2 acc + D) / 2 D) by ONE multiply-high with a per-frame magic number (exact
+//      for this numerator range, any_magic) and are folded straight into the LDS planes of ImageLds (RowFold).
+// The 256 x 256 plane is never stored anywhere.  Every frame carries its own geometry (ImgItem), so one launch hashes a
+// batch of frames of any mix of sizes, strides and pixel formats: the kernel dispatches on the frame's class (bytes per
+// pixel, strips per lane, alignment).  Rows of up to 2048 pixels and frames of up to 2^22 pixels; beyond, the two-launch path.
 struct ImgItem {
     uint64_t src;         // byte offset of the frame's first pixel from the launch's base pointer
     uint32_t w, h;
     uint32_t row_stride;  // bytes
     uint32_t slot;        // which record / status / exact entry the frame fills
     uint32_t cls;         // kernel variant, see any_class()
-    uint32_t parts;       // column parts a wave walks one after the other (rows of more than 1024 pixels)
+    uint32_t magic;       // floor(num / 2 w h) = mulhi(num, magic) >> shift for num < 512 w h
+    uint32_t shift;
+    uint32_t pad;
 };
-static_assert(sizeof(ImgItem) == 32, "ImgItem is uploaded as raw bytes");
+static_assert(sizeof(ImgItem) == 40, "ImgItem is uploaded as raw bytes");
 
-constexpr uint32_t kAnyRowWords = 4 * 64 * 4 + 8;      // per-wave row buffer: prefix sums of up to 1024 pixels (PREFIX form)
-constexpr uint32_t kAnyRowWordsTaps = 4 * 64 * 2 + 8;  // ... the accumulated row of up to 512 pixels (TAPS form)
-constexpr uint32_t kAnyMaxPixels = (1u << 23) - 1;     // 2 w h < 2^24: the 24-bit multiplies of the rounding division
+constexpr uint32_t kAnyMaxWidth = 2048;                // the wave's row buffer: one byte per source pixel
+__host__ __device__ constexpr uint32_t any_row_bytes(int group) { return (512u << group) + 32u; }   // (+ the windows' look-ahead)
+constexpr uint32_t kAnyMaxPixels = (1u << 22) - 1;     // 2 w h < 2^23: the magic number fits 32 bits (any_magic)
 
-// inclusive scan over the wave by DPP: shifts inside rows of 16 lanes, then the row totals passed on (row_bcast 15 / 31)
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-// floor(num / den) for num < 256 den, den < 2^24 (rden = 1 / den rounded): float estimate, one exact step either way
-__device__ __forceinline__ uint32_t div_q8(uint32_t num, uint32_t den, float rden) {
-    uint32_t q = (uint32_t)((float)num * rden);
-    const int32_t rem = (int32_t)(num - __umul24(q, den));       // in (-den, 2 den)
-    q += rem >= (int32_t)den ? 1u : 0u;
-    q -= rem < 0 ? 1u : 0u;
-    return q;
+// Four pixels of a strip -> their lumas as four bytes (spec I1), straight from the raw dwords: a luma is byte 1 of
+// 77 R + 150 G + 29 B + 128 < 2^16, so v_perm_b32 gathers them without shifts.
+template <int BPP>
+__device__ __forceinline__ uint32_t strip_luma_bytes(const RawStrip<BPP>& r) {
+    constexpr uint32_t W = 0x001D964Du;  // bytes: R*77, G*150, B*29, (4th)*0
+    if (BPP == 1) return r.w[0];
+    uint32_t x0, x1, x2, x3;
+    if (BPP == 4) {
+        x0 = __builtin_amdgcn_udot4(r.w[0], W, 128u, false);
+        x1 = __builtin_amdgcn_udot4(r.w[1], W, 128u, false);
+        x2 = __builtin_amdgcn_udot4(r.w[2], W, 128u, false);
+        x3 = __builtin_amdgcn_udot4(r.w[BPP - 1], W, 128u, false);
+    } else {
+        // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+        x0 = __builtin_amdgcn_udot4(r.w[0], W, 128u, false);
+        x1 = __builtin_amdgcn_udot4(r.w[1], W >> 8, __builtin_amdgcn_udot4(r.w[0], W << 24, 128u, false), false);
+        x2 = __builtin_amdgcn_udot4(r.w[2], W >> 16, __builtin_amdgcn_udot4(r.w[1], W << 16, 128u, false), false);
+        x3 = __builtin_amdgcn_udot4(r.w[2], W << 8, 128u, false);
+    }
+    // v_perm_b32(s0, s1, sel): selector 0-3 = bytes of s1, 4-7 = bytes of s0, 0x0c = the constant 0
+    return __builtin_amdgcn_perm(x1, x0, 0x0c0c0501u) | __builtin_amdgcn_perm(x3, x2, 0x05010c0cu);
 }
 
 // Folds destination row j (the lane's four pixels q[0..3] of columns col4 .. col4 + 3) into the LDS planes.  Rows arrive in
@@ -956,7 +964,7 @@ struct RowFold {
     uint32_t col[4];      // column sums over the current group of eight rows
     uint32_t prev;        // the even row of the current pair, four bytes
     __device__ __forceinline__ void init() { col[0] = col[1] = col[2] = col[3] = prev = 0; }
-    __device__ __forceinline__ void push(ImageLds& L, uint32_t j, uint32_t col4, bool live, const uint32_t (&q)[4]) {
+    __device__ __forceinline__ void push(ImageLds& L, uint32_t j, uint32_t col4, const uint32_t (&q)[4]) {
         const uint32_t q4 = q[0] | q[1] << 8 | q[2] << 16 | q[3] << 24;
 #pragma unroll
         for (int c = 0; c < 4; c++) col[c] += q[c];
@@ -964,16 +972,16 @@ struct RowFold {
             // 2x2 means of this row pair: two per lane
             const uint32_t s01 = __builtin_amdgcn_udot4(prev, 0x00000101u, __builtin_amdgcn_udot4(q4, 0x00000101u, 2u, false), false) >> 2;
             const uint32_t s23 = __builtin_amdgcn_udot4(prev, 0x01010000u, __builtin_amdgcn_udot4(q4, 0x01010000u, 2u, false), false) >> 2;
-            if (live) *reinterpret_cast<uint16_t*>(&L.s2[(j >> 1) * 128 + (col4 >> 1)]) = (uint16_t)(s01 | s23 << 8);
+            *reinterpret_cast<uint16_t*>(&L.s2[(j >> 1) * 128 + (col4 >> 1)]) = (uint16_t)(s01 | s23 << 8);
         } else {
             prev = q4;
         }
         if ((j & 7u) == 7u) {
             const uint32_t ty = j >> 3;
-            if (live) *reinterpret_cast<uint2*>(&L.v8[ty * 256 + col4]) = make_uint2(col[0] | col[1] << 16, col[2] | col[3] << 16);
+            *reinterpret_cast<uint2*>(&L.v8[ty * 256 + col4]) = make_uint2(col[0] | col[1] << 16, col[2] | col[3] << 16);
             uint32_t tot = col[0] + col[1] + col[2] + col[3];
             tot += (uint32_t)__builtin_amdgcn_mov_dpp((int)tot, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]: the tile's other half
-            if (live && !(col4 & 4u)) {
+            if (!(col4 & 4u)) {
                 L.gsum[ty * 32 + (col4 >> 3)] = (uint16_t)tot;
                 L.g32[ty * 32 + (col4 >> 3)] = (uint8_t)((tot + 32u) >> 6);
             }
@@ -982,175 +990,135 @@ struct RowFold {
     }
 };
 
-template <int BPP, int SP, bool ALIGNED, bool TAPS>
-__device__ __forceinline__ void any_phase_a(ImageLds& L, uint32_t* __restrict__ rowbuf, const ImgItem& it,
+// SP = strips per lane (1, 2, 4, 8: w <= 256 SP); NT = dwords a destination column's window of luma bytes spans at most
+template <int BPP, int SP, bool ALIGNED>
+__device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ lrow, const ImgItem& it,
                                             const uint8_t* __restrict__ base, const uint8_t* lo, const uint8_t* hi) {
+    constexpr int NT = SP <= 2 ? 1 : SP <= 4 ? 2 : 3;      // windows of <= 4 / 6 / 10 pixels at any byte phase
     const uint32_t t = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t w = it.w, h = it.h;
     const size_t row_stride = it.row_stride;
     const uint8_t* __restrict__ f = base + it.src;
     const uint32_t j0 = (256u / kNW) * wave, j1 = j0 + 256u / kNW;
     const uint32_t ys = (h * j0) >> 8;
-    const uint32_t D = w * h, den = 2u * D;
-    const float rden = 1.0f / (float)den;
-    constexpr int PF = SP <= 1 ? 6 : SP <= 2 ? 4 : 2;     // source rows in flight ahead of the one being consumed
-    const uint32_t parts = TAPS ? 1u : it.parts;
-#pragma unroll 1
-    for (uint32_t z = 0; z < parts; z++) {
-        // destination columns [c0, c1) of this part (multiples of 8: a tile never straddles two parts) and the source strips
-        // [blk0, blk0 + nblk) that overlap them; nblk <= 64 SP by the planner's choice of `parts`
-        const uint32_t c0 = parts == 1 ? 0u : (256u * z / parts) & ~7u;
-        const uint32_t c1 = z + 1 == parts ? 256u : (256u * (z + 1) / parts) & ~7u;
-        const uint32_t blk0 = ((w * c0) >> 8) / 4;
-        const uint32_t nblk = ((w * c1 - 1) >> 8) / 4 + 1 - blk0;
-        const uint32_t wl = w - 4 * blk0;               // source pixels from this part's first strip to the row's end
-        const uint32_t col4 = c0 + 4 * t;               // this lane's four destination columns
-        const bool live = col4 < c1;
-        // horizontal geometry of the lane's columns, fixed for the frame
-        uint32_t gx[4], g0[4], g1[4], g2[4];            // TAPS: first source pixel, doubled weights of the three taps
-                                                        // PREFIX: first / last source pixel (gx, g0), edge overlaps (g1, g2)
+    const uint32_t D = w * h, magic = it.magic, shift = it.shift;
+    const uint32_t nblk = (w + 3) / 4;
+    constexpr int PF = SP <= 1 ? 6 : SP <= 2 ? 4 : SP <= 4 ? 2 : 1;     // source rows in flight ahead of the one being consumed
+    const uint32_t col4 = 4 * t;                          // this lane's four destination columns
+    // horizontal geometry of the lane's columns, fixed for the frame: first dword and byte phase of the window, which of its
+    // bytes are whole pixels (weight 256: `inside`) and the weights of the partly covered ones (`edge`, < 256)
+    uint32_t gw[4], gs[4], inside[4][NT], edge[4][NT];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const uint32_t i = live ? col4 + c : c1 - 1;
-            const uint32_t di0 = w * i, di1 = di0 + w;
-            const uint32_t xa = di0 >> 8, xb = (di1 - 1) >> 8;
-            if (TAPS) {
-                gx[c] = xa;
-                const uint32_t nt = xb - xa;            // taps - 1
-                g0[c] = 2u * (nt == 0 ? w : 256u * (xa + 1) - di0);
-                g1[c] = 2u * (nt == 0 ? 0u : nt == 1 ? di1 - 256u * xb : 256u);
-                g2[c] = 2u * (nt == 2 ? di1 - 256u * xb : 0u);
-            } else {
-                gx[c] = xa - 4 * blk0;
-                g0[c] = xb - 4 * blk0;
-                g1[c] = xa == xb ? w : 256u * (xa + 1) - di0;
-                g2[c] = xa == xb ? 0u : di1 - 256u * xb;
+    for (int c = 0; c < 4; c++) {
+        const uint32_t i = col4 + c;
+        const uint32_t di0 = w * i, di1 = di0 + w;
+        const uint32_t xa = di0 >> 8, xb = (di1 - 1) >> 8;
+        gw[c] = xa >> 2;
+        gs[c] = xa & 3u;
+#pragma unroll
+        for (int k = 0; k < NT; k++) inside[c][k] = edge[c][k] = 0;
+        // byte b of the window is source pixel xa + b; its weight = overlap of [256 x, 256 x + 256) with [di0, di1)
+        for (uint32_t x = xa; x <= xb; x++) {
+            const uint32_t a = 256u * x > di0 ? 256u * x : di0, b = 256u * x + 256u < di1 ? 256u * x + 256u : di1;
+            const uint32_t ov = b - a, pos = x - xa;
+#pragma unroll
+            for (int k = 0; k < NT; k++)
+                if ((pos >> 2) == (uint32_t)k) {
+                    if (ov == 256u) inside[c][k] |= 1u << (8 * (pos & 3u));
+                    else edge[c][k] |= ov << (8 * (pos & 3u));
+                }
+        }
+    }
+    uint32_t acc[4] = {0, 0, 0, 0};
+    RowFold fold;
+    fold.init();
+    RawStrip<BPP> cur[SP], nxt[PF][SP];
+    auto load_row = [&](RawStrip<BPP> (&dst)[SP], uint32_t y) {
+        const uint8_t* __restrict__ row = f + (size_t)y * row_stride;
+#pragma unroll
+        for (int s = 0; s < SP; s++) {
+            if (s == 0 || (uint32_t)(64 * s) < nblk) {       // (wave-uniform: a narrow frame skips the idle strip slots)
+                const uint32_t blk = s * 64 + t;
+                // strips past the row's end re-read its last strip: they are never stored
+                dst[s] = load_raw_strip<BPP, ALIGNED>(row + (size_t)(blk < nblk ? blk : nblk - 1) * 4 * BPP, lo, hi);
             }
         }
-        uint32_t acc[SP][4];
+    };
+    // ---- stream the source rows of this band ----
+    uint32_t j = j0, y = ys;
+    load_row(cur, y);
 #pragma unroll
-        for (int s = 0; s < SP; s++) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
-        RowFold fold;
-        fold.init();
-        RawStrip<BPP> cur[SP], nxt[PF][SP];
-        auto load_row = [&](RawStrip<BPP> (&dst)[SP], uint32_t y) {
-            const uint8_t* __restrict__ row = f + (size_t)y * row_stride;
+    for (int p = 0; p < PF - 1; p++) load_row(nxt[p], y + 1 + p < h ? y + 1 + p : h - 1);
+    while (j < j1 && y < h) {
+        load_row(nxt[PF - 1], y + PF < h ? y + PF : h - 1);
+        // 1. the row's lumas, as bytes, into the wave's row buffer
 #pragma unroll
-            for (int s = 0; s < SP; s++) {
-                if (s == 0 || (uint32_t)(64 * s) < nblk) {       // (wave-uniform: a narrow frame skips the idle strip slots)
-                    const uint32_t blk = s * 64 + t;
-                    // strips past the part's end re-read its last strip: their accumulators are never used
-                    dst[s] = load_raw_strip<BPP, ALIGNED>(row + (size_t)(blk0 + (blk < nblk ? blk : nblk - 1)) * 4 * BPP, lo, hi);
-                }
+        for (int s = 0; s < SP; s++) {
+            if (s == 0 || (uint32_t)(64 * s) < nblk) {
+                const uint32_t blk = s * 64 + t;
+                if (blk < nblk) *reinterpret_cast<uint32_t*>(lrow + 4 * blk) = strip_luma_bytes<BPP>(cur[s]);
             }
-        };
-        auto emit = [&](uint32_t j) {
-            uint32_t q[4];
-            if (TAPS) {
-                // the accumulated row as it is: T[x] at rowbuf[x]
+        }
+        wave_lds_fence();
+        // 2. horizontal pass: H[c] = sum over the column's window of weight x luma (pixels past the row's end have weight 0)
+        uint32_t H[4];
 #pragma unroll
-                for (int s = 0; s < SP; s++) {
-                    if (s == 0 || (uint32_t)(64 * s) < nblk) {
-                        const uint32_t blk = s * 64 + t;
-                        if (blk < nblk) *reinterpret_cast<uint4*>(rowbuf + 4 * blk) = make_uint4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
-                        acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
-                    }
-                }
-                wave_lds_fence();
+        for (int c = 0; c < 4; c++) {
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(lrow) + gw[c];
+            uint32_t d[NT + 1];
+#pragma unroll
+            for (int k = 0; k <= NT; k++) d[k] = wp[k];
+            uint32_t in = 0, ed = 0;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const uint32_t win = __builtin_amdgcn_alignbyte(d[k + 1], d[k], gs[c]);
+                in = __builtin_amdgcn_udot4(win, inside[c][k], in, false);
+                ed = __builtin_amdgcn_udot4(win, edge[c][k], ed, false);
+            }
+            H[c] = (in << 8) + ed;
+        }
+        wave_lds_fence();       // (the next row's stores stay behind these reads)
+        // 3. vertical pass: source row y spans [256 y, 256 y + 256), destination row j [h j, h j + h)
+        const uint32_t s0 = 256u * y, s1 = s0 + 256u;
+        while (j < j1) {
+            const uint32_t d0 = h * j, d1 = d0 + h;
+            const uint32_t a = s0 > d0 ? s0 : d0, b = s1 < d1 ? s1 : d1;
+            if (b > a) {
+                const uint32_t ov = b - a;
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] += __umul24(ov, H[c]);       // ov <= 256, H <= 255 w < 2^24
+            }
+            if (s1 >= d1) {   // destination row j is complete: round, fold into the planes
+                uint32_t q[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const uint32_t t0 = rowbuf[gx[c]], t1 = rowbuf[gx[c] + 1], t2 = rowbuf[gx[c] + 2];
-                    // T < 2^21, doubled weights <= 1024: 24-bit multiplies (a tap of weight 0 may read anything)
-                    const uint32_t num = D + __umul24(g0[c], t0) + __umul24(g1[c], t1) + __umul24(g2[c], t2 & 0xffffffu);
-                    q[c] = div_q8(num, den, rden);
+                    q[c] = __umulhi(2u * acc[c] + D, magic) >> shift;
+                    acc[c] = 0;
                 }
-                wave_lds_fence();       // (the next emit's stores stay behind these reads)
+                fold.push(L, j, col4, q);
+                j++;
+                if (s1 == d1) break;   // the source row ends exactly there
             } else {
-                uint32_t basev = 0;     // wave-uniform running total
-#pragma unroll
-                for (int s = 0; s < SP; s++) {
-                    if (s == 0 || (uint32_t)(64 * s) < nblk) {
-                        const uint32_t blk = s * 64 + t;
-                        const bool in_row = blk < nblk;   // strips past the part's end accumulated a re-read: drop them, and the
-                        // pixels of the row's last strip that lie past the row's end (w % 4 != 0)
-                        const uint32_t p1 = (in_row && 4 * blk + 0 < wl) ? acc[s][0] : 0u, p2 = p1 + ((in_row && 4 * blk + 1 < wl) ? acc[s][1] : 0u),
-                                       p3 = p2 + ((in_row && 4 * blk + 2 < wl) ? acc[s][2] : 0u),
-                                       tot = p3 + ((in_row && 4 * blk + 3 < wl) ? acc[s][3] : 0u);
-                        const uint32_t inc = wave_incl_scan_dpp(tot);
-                        const uint32_t b = basev + inc - tot;
-                        if (in_row) *reinterpret_cast<uint4*>(rowbuf + 4 * blk) = make_uint4(b, b + p1, b + p2, b + p3);
-                        basev += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                        acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
-                    }
-                }
-                if (t == 0) rowbuf[4 * nblk] = basev;
-                wave_lds_fence();
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t pa0 = rowbuf[gx[c]], pa1 = rowbuf[gx[c] + 1], pb0 = rowbuf[g0[c]], pb1 = rowbuf[g0[c] + 1];
-                    // one source pixel (gx == g0): R = w T[xa] (g1 = w, g2 = 0 and the middle run pb0 - pa1 = -T[xa] must not
-                    // count: its weight is dropped with the select below)
-                    const uint32_t mid = gx[c] == g0[c] ? 0u : (pb0 - pa1) << 8;
-                    const uint32_t R = __umul24(g1[c], pa1 - pa0) + mid + __umul24(g2[c], pb1 - pb0);
-                    q[c] = div_q8(2u * R + D, den, rden);
-                }
-                wave_lds_fence();
+                break;                 // the source row is used up, row j continues below
             }
-            fold.push(L, j, col4, live, q);
-        };
-        // ---- stream the source rows of this band ----
-        uint32_t j = j0, y = ys;
-        load_row(cur, y);
+        }
+        y++;
 #pragma unroll
-        for (int p = 0; p < PF - 1; p++) load_row(nxt[p], y + 1 + p < h ? y + 1 + p : h - 1);
-        while (j < j1 && y < h) {
-            load_row(nxt[PF - 1], y + PF < h ? y + PF : h - 1);
-            // lumas of the row in hand, once; source row y spans [256 y, 256 y + 256), destination row j [h j, h j + h)
-            uint32_t lum[SP][4];
+        for (int s = 0; s < SP; s++) {
+            cur[s] = nxt[0][s];
 #pragma unroll
-            for (int s = 0; s < SP; s++)
-                if (s == 0 || (uint32_t)(64 * s) < nblk) strip_luma4<BPP>(cur[s], lum[s]);
-            const uint32_t s0 = 256u * y, s1 = s0 + 256u;
-            while (j < j1) {
-                const uint32_t d0 = h * j, d1 = d0 + h;
-                const uint32_t a = s0 > d0 ? s0 : d0, b = s1 < d1 ? s1 : d1;
-                if (b > a) {
-                    const uint32_t ov = b - a;
-#pragma unroll
-                    for (int s = 0; s < SP; s++) {
-                        if (s == 0 || (uint32_t)(64 * s) < nblk) {
-#pragma unroll
-                            for (int c = 0; c < 4; c++) acc[s][c] += __umul24(ov, lum[s][c]);
-                        }
-                    }
-                }
-                if (s1 >= d1) {   // destination row j is complete
-                    emit(j);
-                    j++;
-                    if (s1 == d1) break;   // the source row ends exactly there
-                } else {
-                    break;                 // the source row is used up, row j continues below
-                }
-            }
-            y++;
-#pragma unroll
-            for (int s = 0; s < SP; s++) {
-                cur[s] = nxt[0][s];
-#pragma unroll
-                for (int p = 0; p + 1 < PF; p++) nxt[p][s] = nxt[p + 1][s];
-            }
+            for (int p = 0; p + 1 < PF; p++) nxt[p][s] = nxt[p + 1][s];
         }
     }
 }
 
-// class of a frame: bits 0-1 bytes per pixel (0: 1, 1: 3, 2: 4), bit 2 aligned strips, bits 3-4 row form
-// (0: TAPS with <= 64 strips, 1: TAPS with <= 128, 2: PREFIX with <= 256 strips per part)
-__host__ __device__ constexpr uint32_t any_class(int bppc, bool aligned, int form) { return (uint32_t)bppc | (aligned ? 4u : 0u) | (uint32_t)form << 3; }
+// class of a frame: bits 0-1 bytes per pixel (0: 1, 1: 3, 2: 4), bit 2 aligned strips, bits 3-4 strips per lane (0: 1, 1: 2, 2: 4, 3: 8)
+__host__ __device__ constexpr uint32_t any_class(int bppc, bool aligned, int spc) { return (uint32_t)bppc | (aligned ? 4u : 0u) | (uint32_t)spc << 3; }
 
 // items == nullptr: a UNIFORM batch -- every frame is `proto` moved by blockIdx.x * frame_stride, slot = blockIdx.x (no table).
-// Two kernels, so that each gets the registers ITS forms need: TAPS frames (rows of up to 512 pixels; <= 106 VGPRs and a
-// 2 KiB row buffer per wave: two workgroups per CU) and PREFIX frames (wider rows; up to 163 VGPRs, 4 KiB row buffers: one).
-template <bool PREFIX>
+// Three kernels, so that each gets the registers and the LDS ITS frames need: GROUP 0 = rows of up to 512 pixels (<= 99
+// VGPRs, 0.5 KiB row buffers), 1 = up to 1024 (<= 121 VGPRs, 1 KiB: still two workgroups per CU), 2 = up to 2048 (one).
+template <int GROUP>
 __global__ __launch_bounds__(kNT) void image_hash_any_kernel(const uint8_t* __restrict__ base, const ImgItem* __restrict__ items,
                                                              ImgItem proto, size_t frame_stride, uint32_t n_items,
                                                              uint32_t algo, const uint8_t* __restrict__ exact,
@@ -1166,13 +1134,13 @@ __global__ __launch_bounds__(kNT) void image_hash_any_kernel(const uint8_t* __re
         it.src += (uint64_t)blockIdx.x * frame_stride;
         it.slot = blockIdx.x;
     }
-    uint32_t* rowbuf = reinterpret_cast<uint32_t*>(any_lds + ((sizeof(ImageLds) + 15) & ~(size_t)15)) +
-                       (threadIdx.x >> 6) * (PREFIX ? kAnyRowWords : kAnyRowWordsTaps);
+    uint8_t* lrow = any_lds + ((sizeof(ImageLds) + 15) & ~(size_t)15) + (threadIdx.x >> 6) * any_row_bytes(GROUP);
     switch (it.cls) {
 #define UCFP_ANY_CASE(BC, BPP, AL)                                                                                     \
-    case any_class(BC, AL, 0): if (!PREFIX) any_phase_a<BPP, 1, AL, true>(L, rowbuf, it, base, lo, hi); break;        \
-    case any_class(BC, AL, 1): if (!PREFIX) any_phase_a<BPP, 2, AL, true>(L, rowbuf, it, base, lo, hi); break;        \
-    case any_class(BC, AL, 2): if (PREFIX) any_phase_a<BPP, 4, AL, false>(L, rowbuf, it, base, lo, hi); break;
+    case any_class(BC, AL, 0): if (GROUP == 0) any_phase_a<BPP, 1, AL>(L, lrow, it, base, lo, hi); break;             \
+    case any_class(BC, AL, 1): if (GROUP == 0) any_phase_a<BPP, 2, AL>(L, lrow, it, base, lo, hi); break;             \
+    case any_class(BC, AL, 2): if (GROUP == 1) any_phase_a<BPP, 4, AL>(L, lrow, it, base, lo, hi); break;             \
+    case any_class(BC, AL, 3): if (GROUP == 2) any_phase_a<BPP, 8, AL>(L, lrow, it, base, lo, hi); break;
         UCFP_ANY_CASE(0, 1, true)
         UCFP_ANY_CASE(0, 1, false)
         UCFP_ANY_CASE(1, 3, true)
@@ -1361,68 +1329,53 @@ __global__ void image_reject_list_kernel(const uint32_t* __restrict__ slots, uin
     if (lane == 0 && status) status[slot] = -1;
 }
 
-// Class, column parts and validity of one frame for image_hash_any_kernel.  false: the fused kernel does not take it (more
-// than kAnyMaxPixels pixels): the caller sends it down the two-launch path.
+// Class, magic number and validity of one frame for image_hash_any_kernel.  false: the fused kernel does not take it (rows
+// of more than kAnyMaxWidth pixels, more than kAnyMaxPixels pixels): the caller sends it down the two-launch path.
 bool image_any_plan(const uint8_t* base, uint64_t src, uint32_t w, uint32_t h, size_t row_stride, int pixfmt, uint32_t* cls,
-                    uint32_t* parts) {
-    if ((uint64_t)w * h > kAnyMaxPixels || row_stride > 0xffffffffull) return false;
-    const uint32_t bppc = (uint32_t)pixfmt;                                  // 0, 1, 2 -> 1, 3, 4 bytes per pixel
+                    uint32_t* magic, uint32_t* shift) {
+    if (w > kAnyMaxWidth || (uint64_t)w * h > kAnyMaxPixels || row_stride > 0xffffffffull) return false;
+    if (!any_magic(2u * w * h, magic, shift)) return false;
     const uintptr_t need = pixfmt == 2 ? 15u : 3u;
     const bool aligned = w % 4 == 0 && (((uintptr_t)base + src) & need) == 0 && (row_stride & need) == 0;
     const uint32_t strips = (w + 3) / 4;
-    uint32_t form = strips <= 64 ? 0u : strips <= 128 ? 1u : 2u, np = 1;
-    if (form == 2) {
-        // the smallest number of column parts (boundaries on multiples of 8 destination columns, as the kernel cuts them)
-        // whose widest part is at most 256 strips
-        for (np = (strips + 255) / 256;; np++) {
-            uint32_t widest = 0;
-            for (uint32_t z = 0; z < np; z++) {
-                const uint32_t c0 = np == 1 ? 0u : (256u * z / np) & ~7u, c1 = z + 1 == np ? 256u : (256u * (z + 1) / np) & ~7u;
-                if (c1 <= c0) {
-                    widest = 0xffffffffu;
-                    break;
-                }
-                const uint32_t b0 = ((w * c0) >> 8) / 4, b1 = ((w * c1 - 1) >> 8) / 4 + 1;
-                widest = b1 - b0 > widest ? b1 - b0 : widest;
-            }
-            if (widest <= 256) break;
-            if (np >= 32) return false;       // (w <= 8192: 2048 strips, 9 parts at most)
-        }
-    }
-    *cls = any_class((int)bppc, aligned, (int)form);
-    *parts = np;
+    const int spc = strips <= 64 ? 0 : strips <= 128 ? 1 : strips <= 256 ? 2 : 3;
+    *cls = any_class(pixfmt, aligned, spc);
     return true;
 }
-bool image_any_is_prefix(uint32_t cls) { return (cls >> 3) == 2; }
+int image_any_group(uint32_t cls) { return (cls >> 3) <= 1 ? 0 : (int)(cls >> 3) - 1; }
 
 size_t image_any_item_bytes() { return sizeof(ImgItem); }
 void image_any_item_write(void* dst, size_t i, uint64_t src, uint32_t w, uint32_t h, uint32_t row_stride, uint32_t slot, uint32_t cls,
-                          uint32_t parts) {
-    reinterpret_cast<ImgItem*>(dst)[i] = ImgItem{src, w, h, row_stride, slot, cls, parts};
+                          uint32_t magic, uint32_t shift) {
+    reinterpret_cast<ImgItem*>(dst)[i] = ImgItem{src, w, h, row_stride, slot, cls, magic, shift, 0};
 }
 
-// One launch over frames of ONE form group (prefix: the PREFIX kernel, rows of more than 512 pixels; else the TAPS kernel).
+// One launch over frames of ONE width group (image_any_group).
 // d_items == nullptr: uniform batch of n frames described by (proto_*) and frame_stride.
-int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, bool prefix, uint32_t proto_w,
-                          uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_parts, size_t frame_stride,
-                          const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t stream) {
+int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, int group, uint32_t proto_w,
+                          uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_magic, uint32_t proto_shift,
+                          size_t frame_stride, const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out,
+                          int32_t* status, hipStream_t stream) {
     if (n == 0) return 0;
-    const size_t lds = ((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * (prefix ? kAnyRowWords : kAnyRowWordsTaps) * 4;
+    auto lds_of = [](int g) { return ((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * any_row_bytes(g); };
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * kAnyRowWords * 4));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * kAnyRowWordsTaps * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(0));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(2));
         attr_set = true;
     }
-    const ImgItem proto{0, proto_w, proto_h, proto_row_stride, 0, proto_cls, proto_parts};
-    if (prefix)
-        hipLaunchKernelGGL(image_hash_any_kernel<true>, dim3((unsigned)n), dim3(kNT), lds, stream, base, reinterpret_cast<const ImgItem*>(d_items),
-                           proto, frame_stride, (uint32_t)n, algo, exact, out, status, lo, hi);
+    const ImgItem proto{0, proto_w, proto_h, proto_row_stride, 0, proto_cls, proto_magic, proto_shift, 0};
+    const ImgItem* items = reinterpret_cast<const ImgItem*>(d_items);
+    if (group == 0)
+        hipLaunchKernelGGL(image_hash_any_kernel<0>, dim3((unsigned)n), dim3(kNT), lds_of(0), stream, base, items, proto, frame_stride,
+                           (uint32_t)n, algo, exact, out, status, lo, hi);
+    else if (group == 1)
+        hipLaunchKernelGGL(image_hash_any_kernel<1>, dim3((unsigned)n), dim3(kNT), lds_of(1), stream, base, items, proto, frame_stride,
+                           (uint32_t)n, algo, exact, out, status, lo, hi);
     else
-        hipLaunchKernelGGL(image_hash_any_kernel<false>, dim3((unsigned)n), dim3(kNT), lds, stream, base, reinterpret_cast<const ImgItem*>(d_items),
-                           proto, frame_stride, (uint32_t)n, algo, exact, out, status, lo, hi);
+        hipLaunchKernelGGL(image_hash_any_kernel<2>, dim3((unsigned)n), dim3(kNT), lds_of(2), stream, base, items, proto, frame_stride,
+                           (uint32_t)n, algo, exact, out, status, lo, hi);
     return 0;
 }
 

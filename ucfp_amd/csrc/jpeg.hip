@@ -174,11 +174,14 @@ __device__ int jpeg_parse(const uint8_t* p, size_t n, uint32_t width, uint32_t h
 // One wave per file.  clean: the file's unstuffed entropy-coded bytes (at the 16-byte rounded file offset of a buffer as
 // large as the batch); seg: (max_seg + 2) offsets per file.
 __global__ __launch_bounds__(64) void jpeg_scan_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
-                                                      uint32_t width, uint32_t height, uint32_t max_seg,
+                                                      const UpItem* __restrict__ items, UpUniform uni,
                                                       uint8_t* __restrict__ clean, uint32_t* __restrict__ seg,
                                                       JpgInfo* __restrict__ info) {
-    const size_t img = blockIdx.x;
-    if (img >= n) return;
+    const size_t ent = blockIdx.x;                    // entry of the batch: info[ent]; the bytes are FILE item.file's
+    if (ent >= n) return;
+    const UpItem item = up_item(items, uni, ent);
+    const size_t img = item.file;
+    const uint32_t width = item.w, height = item.h, max_seg = item.max_seg;
     const int lane = threadIdx.x;
     const uint8_t* p = jpg + offsets[img];
     const size_t len = (size_t)(offsets[img + 1] - offsets[img]);
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64) void jpeg_scan_kernel(const uint8_t* __restrict
     wave_lds_sync();
     int32_t status = J.status;
     uint8_t* out = clean + ((offsets[img] + 15) & ~(uint64_t)15);
-    uint32_t* sg = seg + img * (size_t)(max_seg + 2);
+    uint32_t* sg = seg + item.seg_off;
     uint32_t o = 0, nseg = 0;       // wave-uniform: clean bytes written, RSTn markers seen
     if (status == 0) {
         if (lane == 0) sg[0] = 0;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(64) void jpeg_scan_kernel(const uint8_t* __restrict
         J.status = status;
         J.clean_len = o;
         J.nseg = nseg;
-        info[img] = J;
+        info[ent] = J;
     }
 }
 
@@ -313,19 +316,21 @@ __device__ void build_tables(HuffTables& L, const JpgInfo& J, const uint8_t* __r
 
 // One wave per file: lane = restart interval (in rounds of 64).
 __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
-                                                      uint32_t width, uint32_t height, uint32_t max_seg,
+                                                      const UpItem* __restrict__ items, UpUniform uni,
                                                       const uint8_t* __restrict__ clean, const uint32_t* __restrict__ seg,
                                                       JpgInfo* __restrict__ info, int16_t* __restrict__ coef,
-                                                      size_t coef_stride /* int16 per file */, uint32_t bxp /* luma blocks per row of the plane */,
                                                       uint16_t* __restrict__ qtab) {
     __shared__ HuffLds L;
-    const size_t img = blockIdx.x;
-    if (img >= n) return;
+    const size_t ent = blockIdx.x;
+    if (ent >= n) return;
     const int lane = threadIdx.x;
-    const JpgInfo J = info[img];
+    const JpgInfo J = info[ent];
     if (J.status != 0 || jpeg_takes_spec(J)) return;          // (single-segment files: jpeg_huff_spec_kernel)
+    const UpItem item = up_item(items, uni, ent);
+    const size_t img = item.file;
+    const uint32_t width = item.w, height = item.h, bxp = item.bxp /* luma blocks per row of the plane */;
     const uint8_t* p = jpg + offsets[img];
-    build_tables(L, J, p, lane, qtab + img * 64);
+    build_tables(L, J, p, lane, qtab + ent * 64);
     const uint32_t mcu_w = 8u * J.hmax, mcu_h = 8u * J.vmax;
     const uint32_t mx = (width + mcu_w - 1) / mcu_w, my = (height + mcu_h - 1) / mcu_h, total_mcu = mx * my;
     const uint32_t per = J.restart ? J.restart : total_mcu;
@@ -333,8 +338,8 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
     bool bad = J.nseg != need;                     // one segment per restart interval, no more, no fewer
     const uint8_t* cl = clean + ((offsets[img] + 15) & ~(uint64_t)15);
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(cl);
-    const uint32_t* sg = seg + img * (size_t)(max_seg + 2);
-    int16_t* cplane = coef + img * coef_stride;
+    const uint32_t* sg = seg + item.seg_off;
+    int16_t* cplane = coef + item.aux_off;
     int16_t* myblk = L.blk[lane];
     for (int i = 0; i < 64; i += 8) *reinterpret_cast<uint4*>(myblk + i) = make_uint4(0, 0, 0, 0);
     const uint32_t nb_c[3] = {(uint32_t)(J.ncomp == 1 ? 1 : J.hs[0] * J.vs[0]), (uint32_t)(J.ncomp == 3 ? J.hs[1] * J.vs[1] : 0),
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
         }
         if (__ballot(err)) bad = true;
     }
-    if (bad && lane == 0) info[img].status = UCFP_IMAGE_NEEDS_HOST;
+    if (bad && lane == 0) info[ent].status = UCFP_IMAGE_NEEDS_HOST;
 }
 
 
@@ -593,14 +598,14 @@ __device__ __forceinline__ void spec_run(const SpecTables& L, const uint32_t* __
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void jpeg_huff_spec_kernel(const uint8_t* __restrict__ jpg, const uint64_t* __restrict__ offsets, size_t n,
-                                                           uint32_t width, uint32_t height, const uint8_t* __restrict__ clean,
-                                                           JpgInfo* __restrict__ info, int16_t* __restrict__ coef, size_t coef_stride,
-                                                           uint32_t bxp, uint16_t* __restrict__ qtab) {
+                                                           const UpItem* __restrict__ items, UpUniform uni, const uint8_t* __restrict__ clean,
+                                                           JpgInfo* __restrict__ info, int16_t* __restrict__ coef,
+                                                           uint16_t* __restrict__ qtab) {
     extern __shared__ __attribute__((aligned(16))) uint8_t spec_lds[];   // (dynamic: 89 KiB at eight waves)
     SpecLds<NW>& L = *reinterpret_cast<SpecLds<NW>*>(spec_lds);
     constexpr int T = 64 * NW;                            // subsequences = threads
-    const size_t img = blockIdx.x;
-    if (img >= n) return;
+    const size_t ent = blockIdx.x;
+    if (ent >= n) return;
     const int lane = threadIdx.x;                         // 0 .. T - 1: the subsequence this thread owns
     const int wlane = lane & 63, wave = lane >> 6;
     auto block_sync = [&]() {
@@ -632,10 +637,14 @@ __global__ __launch_bounds__(64 * NW) void jpeg_huff_spec_kernel(const uint8_t* 
         total = all;
         return incl + before;
     };
-    const JpgInfo J = info[img];
+    const JpgInfo J = info[ent];
     if (J.status != 0 || !jpeg_takes_spec(J)) return;
+    const UpItem item = up_item(items, uni, ent);
+    const size_t img = item.file;
+    const uint32_t width = item.w, height = item.h, bxp = item.bxp;
+    const size_t coef_stride = (size_t)item.bxp * item.byp * 64;      // the file's coefficient plane, int16
     const uint8_t* p = jpg + offsets[img];
-    if (wave == 0) build_tables(L, J, p, wlane, qtab + img * 64);
+    if (wave == 0) build_tables(L, J, p, wlane, qtab + ent * 64);
     const uint32_t nby = J.ncomp == 1 ? 1u : (uint32_t)J.hs[0] * J.vs[0];
     const uint32_t nb1 = J.ncomp == 3 ? (uint32_t)J.hs[1] * J.vs[1] : 0u;
     const uint32_t B = jpeg_blocks_per_mcu(J);
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(64 * NW) void jpeg_huff_spec_kernel(const uint8_t* 
     const uint32_t mx = (width + 8u * hmax - 1) / (8u * hmax), my = (height + 8u * vmax - 1) / (8u * vmax);
     const uint32_t blk_total = mx * my * B;               // (<= 2048 x 2048 MCUs x 6 blocks)
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(clean + ((offsets[img] + 15) & ~(uint64_t)15));
-    int16_t* cplane = coef + img * coef_stride;
+    int16_t* cplane = coef + item.aux_off;
     // the luma blocks' coefficients not written below are zero
     for (size_t i = (size_t)lane * 8; i < coef_stride; i += T * 8) *reinterpret_cast<uint4*>(cplane + i) = make_uint4(0, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(64 * NW) void jpeg_huff_spec_kernel(const uint8_t* 
     }
     if (blk_done < blk_total) bad = true;                 // the data ended before the last block
     if (bad) {
-        if (lane == 0) info[img].status = UCFP_IMAGE_NEEDS_HOST;
+        if (lane == 0) info[ent].status = UCFP_IMAGE_NEEDS_HOST;
         return;
     }
     // ---- DC differences -> DC values: prefix sum over the luma blocks in decoding order (MCU by MCU)
@@ -829,18 +838,37 @@ __device__ __forceinline__ void islow_1d(const int32_t in0, const int32_t in1, c
 // butterflies cannot overflow and libjpeg's C table, libjpeg-turbo's 16-bit SIMD form and this code give the same pixels; a
 // crafted stream that crosses one makes the file UCFP_IMAGE_NEEDS_HOST (its record is zeroed by the merge kernel).
 constexpr int32_t kIdctMaxCoef = 16383, kIdctMaxPass1 = 23000;
-__global__ __launch_bounds__(256) void jpeg_idct_kernel(JpgInfo* __restrict__ info, size_t n, uint32_t width, uint32_t height,
-                                                       const int16_t* __restrict__ coef, size_t coef_stride, uint32_t bxp, uint32_t byp,
-                                                       const uint16_t* __restrict__ qtab, uint8_t* __restrict__ frames, size_t row_stride,
-                                                       size_t frame_stride) {
-    const size_t per = (size_t)bxp * byp;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n * per) return;
-    const size_t img = t / per;
-    const uint32_t b = (uint32_t)(t % per), bx = b % bxp, by = b / bxp;
+// first[e] = the first workgroup of entry e (ceil(blocks of its plane / 256) workgroups each), first[n] = the grid
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(JpgInfo* __restrict__ info, size_t n, const UpItem* __restrict__ items, UpUniform uni,
+                                                       const uint32_t* __restrict__ first, uint32_t uni_groups,
+                                                       const int16_t* __restrict__ coef, const uint16_t* __restrict__ qtab,
+                                                       uint8_t* __restrict__ frames) {
+    // which entry this workgroup belongs to (wave-uniform)
+    size_t img;
+    uint32_t g0;
+    if (first) {
+        size_t lo = 0, hi = n;                       // first[lo] <= blockIdx.x < first[hi]
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) >> 1;
+            if (first[mid] <= blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        img = lo;
+        g0 = first[lo];
+    } else {
+        img = blockIdx.x / uni_groups;
+        g0 = (uint32_t)img * uni_groups;
+    }
+    if (img >= n) return;
+    const UpItem item = up_item(items, uni, img);
+    const uint32_t width = item.w, height = item.h, bxp = item.bxp, byp = item.byp;
+    const size_t row_stride = item.row_stride;
+    const uint32_t b = (blockIdx.x - g0) * 256 + threadIdx.x;
+    if (b >= bxp * byp) return;
+    const uint32_t bx = b % bxp, by = b / bxp;
     if (info[img].status != 0) return;
     if (bx * 8 >= width || by * 8 >= height) return;                 // MCU padding
-    const int16_t* c = coef + img * coef_stride + (size_t)b * 64;
+    const int16_t* c = coef + item.aux_off + (size_t)b * 64;
     const uint16_t* q = qtab + img * 64;
     int32_t ws[64];
 #pragma unroll
@@ -882,7 +910,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpgInfo* __restrict__ in
     }
     bool wild = false;
     // pass 2: rows, range limit, store
-    uint8_t* dst = frames + img * frame_stride + (size_t)(by * 8) * row_stride + (size_t)bx * 8;
+    uint8_t* dst = frames + item.frame_off + (size_t)(by * 8) * row_stride + (size_t)bx * 8;
     const bool whole = bx * 8 + 8 <= width && ((reinterpret_cast<uintptr_t>(dst) | row_stride) & 7u) == 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -910,18 +938,20 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpgInfo* __restrict__ in
     if (wild) info[img].status = UCFP_IMAGE_NEEDS_HOST;
 }
 
-__global__ void jpeg_status_kernel(const JpgInfo* __restrict__ info, size_t n, int32_t* __restrict__ status) {
+__global__ void jpeg_status_kernel(const JpgInfo* __restrict__ info, const UpItem* __restrict__ items, size_t n,
+                                   int32_t* __restrict__ status) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) status[i] = info[i].status;
+    if (i < n) status[items ? items[i].file : i] = info[i].status;
 }
 
 // Records of files that did not decode are zeroed and carry the decoder's status.
-__global__ void jpeg_merge_status_kernel(const JpgInfo* __restrict__ info, size_t n, uint8_t* __restrict__ out, uint32_t rec,
-                                         int32_t* __restrict__ status) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x / 64 + threadIdx.x / 64;
-    if (i >= n) return;
-    const int32_t st = info[i].status;
+__global__ void jpeg_merge_status_kernel(const JpgInfo* __restrict__ info, const UpItem* __restrict__ items, size_t n,
+                                         uint8_t* __restrict__ out, uint32_t rec, int32_t* __restrict__ status) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x / 64 + threadIdx.x / 64;
+    if (e >= n) return;
+    const int32_t st = info[e].status;
     if (st == 0) return;
+    const size_t i = items ? items[e].file : e;
     const int lane = threadIdx.x & 63;
     for (uint32_t b = lane * 4; b < rec; b += 256) *reinterpret_cast<uint32_t*>(out + i * rec + b) = 0;
     if (lane == 0 && status) status[i] = st;
@@ -929,43 +959,62 @@ __global__ void jpeg_merge_status_kernel(const JpgInfo* __restrict__ info, size_
 
 }  // namespace
 
-size_t jpeg_ws_bytes(size_t n, size_t jpg_bytes, uint32_t w, uint32_t h, JpegWs* ws) {
-    JpegWs l;
-    // the luma plane in blocks, with room for the padding of the largest MCU (up to 3 more blocks each way)
-    l.bxp = (w + 7) / 8 + 4;
-    l.byp = (h + 7) / 8 + 4;
-    l.max_seg = ((w + 7) / 8) * ((h + 7) / 8);               // restart interval = 1 MCU of one block: the most segments
-    if (l.max_seg > (uint32_t)kMaxSeg) l.max_seg = (uint32_t)kMaxSeg;
-    l.coef_stride = (size_t)l.bxp * l.byp * 64;
+// the luma plane of a w x h file in blocks, with room for the padding of the largest MCU (up to 3 more blocks each way),
+// and the most restart segments its table may have to hold (restart interval = 1 MCU of one block)
+void jpeg_plane_geometry(uint32_t w, uint32_t h, uint32_t* bxp, uint32_t* byp, uint32_t* max_seg) {
+    *bxp = (w + 7) / 8 + 4;
+    *byp = (h + 7) / 8 + 4;
+    uint32_t ms = ((w + 7) / 8) * ((h + 7) / 8);
+    if (ms > (uint32_t)kMaxSeg) ms = (uint32_t)kMaxSeg;
+    *max_seg = ms;
+}
+
+// seg_words / coef_words: the batch's totals (uniform: n x per file)
+static size_t jpeg_ws_layout(size_t n, size_t jpg_bytes, size_t seg_words, size_t coef_words, JpegWs* l) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
         off += (bytes + 255) & ~(size_t)255;
         return at;
     };
-    l.jpg_bytes = jpg_bytes;
-    l.clean = take(jpg_bytes + 16 + 64 + 512);
-    l.info = take(n * sizeof(JpgInfo));
-    l.seg = take(n * (size_t)(l.max_seg + 2) * 4);
-    l.qtab = take(n * 64 * 2);
-    l.coef = take(n * l.coef_stride * 2);
-    l.total = off;
+    l->jpg_bytes = jpg_bytes;
+    l->clean = take(jpg_bytes + 16 + 64 + 512);
+    l->info = take(n * sizeof(JpgInfo));
+    l->seg = take(seg_words * 4);
+    l->qtab = take(n * 64 * 2);
+    l->coef = take(coef_words * 2);
+    l->first = take((n + 1) * 4);
+    l->total = off;
+    return off;
+}
+
+size_t jpeg_ws_bytes(size_t n, size_t jpg_bytes, uint32_t w, uint32_t h, JpegWs* ws) {
+    JpegWs l;
+    jpeg_plane_geometry(w, h, &l.bxp, &l.byp, &l.max_seg);
+    l.coef_stride = (size_t)l.bxp * l.byp * 64;
+    const size_t off = jpeg_ws_layout(n, jpg_bytes, n * (size_t)(l.max_seg + 2), n * l.coef_stride, &l);
     if (ws) *ws = l;
     return off;
 }
 
-int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, uint8_t* ws,
-                       const JpegWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
-                       hipStream_t stream) {
-    if (n == 0) return 0;
+size_t jpeg_ragged_ws_bytes(size_t n, size_t jpg_bytes, size_t seg_words, size_t coef_words, JpegWs* ws) {
+    JpegWs l;
+    const size_t off = jpeg_ws_layout(n, jpg_bytes, seg_words, coef_words, &l);
+    if (ws) *ws = l;
+    return off;
+}
+
+// idct_groups: workgroups of the inverse DCT launch (ragged: d_first[n]; uniform: n x uni_groups)
+static int jpeg_decode_launches(const uint8_t* jpg, const uint64_t* offsets, const UpItem* d_items, const UpUniform& uni, size_t n,
+                                const uint32_t* d_first, uint32_t uni_groups, size_t idct_groups, uint8_t* ws, const JpegWs& l,
+                                uint8_t* frames, int32_t* status, hipStream_t stream) {
     JpgInfo* info = reinterpret_cast<JpgInfo*>(ws + l.info);
     uint32_t* seg = reinterpret_cast<uint32_t*>(ws + l.seg);
     int16_t* coef = reinterpret_cast<int16_t*>(ws + l.coef);
     uint16_t* qtab = reinterpret_cast<uint16_t*>(ws + l.qtab);
-    hipLaunchKernelGGL(jpeg_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h, l.max_seg, ws + l.clean,
-                       seg, info);
-    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, w, h, l.max_seg,
-                       (const uint8_t*)(ws + l.clean), (const uint32_t*)seg, info, coef, l.coef_stride, l.bxp, qtab);
+    hipLaunchKernelGGL(jpeg_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, d_items, uni, ws + l.clean, seg, info);
+    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((unsigned)n), dim3(64), 0, stream, jpg, offsets, n, d_items, uni,
+                       (const uint8_t*)(ws + l.clean), (const uint32_t*)seg, info, coef, qtab);
     {
         // waves per file of the speculative decoder: as many as keep the batch within the chip's ~2048 wave slots and a
         // subsequence at >= 256 bits (measured on 9 KB config-1 files, images/s at 1 | 2 | 4 waves: 1000 files 458 k | 556 k |
@@ -976,29 +1025,53 @@ int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, ui
         auto go = [&](auto kern, int threads, size_t lds) {
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(threads), lds, stream, jpg, offsets, n, w, h,
-                       (const uint8_t*)(ws + l.clean), info, coef, l.coef_stride, l.bxp, qtab);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(threads), lds, stream, jpg, offsets, n, d_items, uni,
+                               (const uint8_t*)(ws + l.clean), info, coef, qtab);
         };
         if (nw == 1) go(jpeg_huff_spec_kernel<1>, 64, sizeof(SpecLds<1>));
         else if (nw == 2) go(jpeg_huff_spec_kernel<2>, 128, sizeof(SpecLds<2>));
         else if (nw == 4) go(jpeg_huff_spec_kernel<4>, 256, sizeof(SpecLds<4>));
         else go(jpeg_huff_spec_kernel<8>, 512, sizeof(SpecLds<8>));
     }
-    const size_t blocks = n * (size_t)l.bxp * l.byp;
-    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, stream, info, n, w, h,
-                       (const int16_t*)coef, l.coef_stride, l.bxp, l.byp, (const uint16_t*)qtab, frames, row_stride,
-                       frame_stride);
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)idct_groups), dim3(256), 0, stream, info, n, d_items, uni, d_first, uni_groups,
+                       (const int16_t*)coef, (const uint16_t*)qtab, frames);
     if (status)
-        hipLaunchKernelGGL(jpeg_status_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const JpgInfo*)info, n,
+        hipLaunchKernelGGL(jpeg_status_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const JpgInfo*)info, d_items, n,
                            status);
     return 0;
 }
 
+int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, uint8_t* ws,
+                       const JpegWs& l, uint8_t* frames, size_t row_stride, size_t frame_stride, int32_t* status,
+                       hipStream_t stream) {
+    if (n == 0) return 0;
+    UpUniform uni;
+    uni.w = w;
+    uni.h = h;
+    uni.pixfmt = UCFP_PIX_GRAY8;
+    uni.row_stride = (uint32_t)row_stride;
+    uni.bxp = l.bxp;
+    uni.byp = l.byp;
+    uni.max_seg = l.max_seg;
+    uni.frame_stride = frame_stride;
+    uni.aux_stride = l.coef_stride;
+    const uint32_t groups = (uint32_t)(((size_t)l.bxp * l.byp + 255) / 256);
+    return jpeg_decode_launches(jpg, offsets, nullptr, uni, n, nullptr, groups, n * (size_t)groups, ws, l, frames, status, stream);
+}
+
+// d_first: n + 1 device words at ws + l.first, written by the caller (host table): first workgroup of every entry's inverse DCT
+int launch_jpeg_decode_ragged(const uint8_t* jpg, const uint64_t* offsets, const UpItem* d_items, size_t n, size_t idct_groups,
+                              uint8_t* ws, const JpegWs& l, uint8_t* frames, int32_t* status, hipStream_t stream) {
+    if (n == 0) return 0;
+    return jpeg_decode_launches(jpg, offsets, d_items, UpUniform{}, n, reinterpret_cast<const uint32_t*>(ws + l.first), 0, idct_groups,
+                                ws, l, frames, status, stream);
+}
+
 int launch_jpeg_merge_status(const uint8_t* ws, const JpegWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
-                             hipStream_t stream) {
+                             hipStream_t stream, const UpItem* d_items) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(jpeg_merge_status_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
-                       reinterpret_cast<const JpgInfo*>(ws + l.info), n, out, rec, status);
+                       reinterpret_cast<const JpgInfo*>(ws + l.info), d_items, n, out, rec, status);
     return 0;
 }
 

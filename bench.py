@@ -377,6 +377,104 @@ def bench_config1_jpeg(dev, ctx, frames, oracle, cores):
             "gpu_over_cpu_decode_plus_hash_n_threads": (n_img / t_gh) / (n_img / (t_decn + t_hn))}
 
 
+def upload_mix_files(n_img=400, seed=0xA11, lo=64, hi=2048):
+    """A stated mix of uploads: sides log-uniform in [lo, hi] px (width and height drawn independently),
+    half PNG (RGB, compress level 1-6) and half baseline JPEG (quality 70-95, 4:2:0 / 4:4:4), content = smooth gradients + a
+    little noise; on top, every 16th upload is of a kind the device hands back (progressive JPEG, 16-bit PNG, BMP in turn).
+    -> (files, decoded pixel bytes of the PNG / JPEG ones as the device produces them)."""
+    import io
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    files, px_bytes = [], 0
+    for i in range(n_img):
+        w = int(round(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
+        h = int(round(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
+        yy, xx = np.mgrid[0:h, 0:w]
+        f = rng.uniform(1, 9, 3)
+        img = np.stack([128 + 90 * np.sin(xx / w * f[0] + i), 128 + 90 * np.cos(yy / h * f[1]), (xx * 255 // w + yy * 255 // h) // 2 +
+                        40 * np.sin((xx + yy) / (w + h) * f[2] * 3)], -1)
+        img = np.clip(img + rng.normal(0, 3, img.shape), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        if i % 16 == 15:
+            kind = (i // 16) % 3
+            if kind == 0:
+                Image.fromarray(img, "RGB").save(b, "JPEG", quality=85, progressive=True)
+            elif kind == 1:
+                Image.fromarray((img[..., 0].astype(np.uint16) << 8)).save(b, "PNG")
+            else:
+                Image.fromarray(img, "RGB").save(b, "BMP")
+        elif i % 2 == 0:
+            Image.fromarray(img, "RGB").save(b, "PNG", compress_level=int(rng.integers(1, 7)))
+            px_bytes += w * h * 3
+        else:
+            Image.fromarray(img, "RGB").save(b, "JPEG", quality=int(rng.integers(70, 96)), subsampling=int(rng.integers(0, 2)) * 2)
+            px_bytes += w * h
+        files.append(b.getvalue())
+    return files, px_bytes
+
+
+def bench_upload_mix(dev, ctx, n_img=400, threads=64):
+    """Uploads of any size and kind through the any-upload entry (ucfp_image_upload_hash_batch_dev) with the files resident in
+    HBM, and through ONE micro-batcher (ucfp_upload_batcher_*) fed by request threads -- the reference's route
+    (src/server/handlers.rs:232-302) with the decode on the device.  Records are checked against the per-request host path
+    on a sample."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from ucfp_amd import _lib, image
+    files, px_bytes = upload_mix_files(n_img)
+    n = len(files)
+    enc_bytes = sum(len(f) for f in files)
+    offs = np.zeros(n + 1, np.int64)
+    np.cumsum([len(f) for f in files], out=offs[1:])
+    d_blob = torch.from_numpy(np.frombuffer(b"".join(files) + bytes(64), np.uint8).copy()).to(dev)
+    d_off = torch.from_numpy(offs).to(dev)
+    d_out = torch.zeros((n, 536), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros((n,), dtype=torch.int32, device=dev)
+    info = image._probe_all(files)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def go():
+        image.fingerprint_uploads_dev(d_blob.data_ptr(), d_off.data_ptr(), n, int(offs[-1]), info, out_ptr=d_out.data_ptr(),
+                                      status_ptr=d_st.data_ptr(), stream=stream, ctx=ctx)
+    go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    st = d_st.cpu().numpy()
+    rec = d_out.cpu().numpy()
+    needs_host = int((st == 1).sum())
+    # the per-request host path (Pillow decode + the same hash kernels) must give the same records
+    same = True
+    for i in [k for k in range(n) if st[k] == 0][:12]:
+        same = same and bytes(image.fingerprint(files[i], 0, i).fingerprint) == rec[i].tobytes()
+    # one batcher, many request threads
+    bt = image.UploadBatcher(max_batch=512, max_bytes=512 << 20, max_delay_us=200, ctx=ctx)
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(bt.submit, files[:threads]))
+        t0 = time.perf_counter()
+        res = list(pool.map(bt.submit, files * 2))
+        dt = time.perf_counter() - t0
+    batches, items = bt.stats()
+    bt.close()
+    same_b = all(r[0] == rec[i % n].tobytes() and r[1] == st[i % n] for i, r in enumerate(res))
+    return {"what": f"{n} uploads, sides log-uniform 64-2048 px, 47 % PNG (RGB) / 47 % baseline JPEG / 6 % kinds the device hands "
+                    "back (progressive JPEG, 16-bit PNG, BMP); records = 536-B bundles",
+            "files": n, "encoded_MB": enc_bytes / 1e6, "decoded_MB": px_bytes / 1e6,
+            "resident": {"ms": ms, "images_per_s": n / ms * 1e3, "encoded_GBs": enc_bytes / ms / 1e6,
+                         "decoded_pixel_GBs": px_bytes / ms / 1e6},
+            "needs_host": needs_host, "needs_host_share": needs_host / n, "rejected": int((st < 0).sum()),
+            "batcher": {"request_threads": threads, "images_per_s": 2 * n / dt, "batches": batches, "items": items,
+                        "note": "Python request threads (ctypes releases the GIL inside submit); host memory in and out"},
+            "records_equal_per_request_host_path": bool(same), "batcher_records_equal_resident_call": bool(same_b)}
+
+
 def cpu_baseline(sample: int, gpu_records_head):
     """Time the CPU oracle (OpenMP over frames) on the first frames of the same synthetic workload -- at least 64 frames
     per thread, best of 3 -- and use the occasion to check the GPU records of those frames."""
@@ -1362,6 +1460,10 @@ def main():
             head = out[:want].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(want, head)
             res["config1_phash_png"] = bench_config1_phash_png(dev, ctx)
+            try:
+                res["upload_mix"] = bench_upload_mix(dev, ctx)
+            except Exception as e:   # noqa: BLE001  (a secondary leg: reported, never substituted)
+                res["upload_mix"] = {"error": f"{type(e).__name__}: {e}"}
         elif args.cpu_sample > 0:
             res["cpu_baseline"] = None  # measured at N=1 only (see BENCH at n_gpus=1)
     else:

@@ -142,6 +142,66 @@ int ucfp_image_hash_ragged_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_fr
 int ucfp_image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t frames_bytes, const ucfp_image_item* items,
                            size_t n, const ucfp_image_preprocess* pre, const uint8_t* exact, uint8_t* out, int32_t* status);
 
+/* ---- encoded uploads of any size and format in one batch (SURVEY 8f N1 + N4) ----
+ * What the reference's route receives (src/server/handlers.rs:232-302) is an encoded file of unknown kind and size, decoded
+ * inside the SDK call (src/modality/image.rs:68-70).  ucfp_image_probe tells from the first bytes what it is and what frame
+ * it decodes to; the batch entries below take files of ANY mix of kinds and sizes: PNG and baseline JPEG are decoded on
+ * the device (scope: the PNG / JPEG front-end sections below), everything else -- WebP, GIF, BMP, the PNG and JPEG kinds the
+ * device hands back -- gets status UCFP_IMAGE_NEEDS_HOST and goes to the host's decoder. */
+#define UCFP_IMAGE_NEEDS_HOST 1
+typedef enum ucfp_upload_format {
+    UCFP_UPLOAD_OTHER = 0, /* not PNG / JPEG: the host's decoder decides                    */
+    UCFP_UPLOAD_PNG = 1,
+    UCFP_UPLOAD_JPEG = 2
+} ucfp_upload_format;
+typedef struct ucfp_upload_info {
+    int32_t format;        /* ucfp_upload_format                                             */
+    int32_t status;        /* UCFP_OK: the device decodes it; UCFP_IMAGE_NEEDS_HOST; UCFP_E_MODALITY */
+    uint32_t width, height;
+    int32_t pixfmt;        /* the frame the file decodes to (a JPEG: its luma plane, GRAY8)   */
+    uint32_t reserved;
+} ucfp_upload_info;
+/* Host-side, on the upload's own bytes (a request thread calls it before submitting): fills *info, returns info->status. */
+int ucfp_image_probe(const uint8_t* bytes, size_t len, ucfp_upload_info* info);
+/* The same for uploads that are already in device memory (one blob + n + 1 byte offsets, like the text calls): d_info
+ * receives n entries.  No synchronisation. */
+int ucfp_image_probe_batch_dev(ucfp_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n, ucfp_upload_info* d_info,
+                               void* stream);
+/* Encoded uploads of ANY mix of kinds and sizes -> records.  info: n probe results in HOST memory (the library plans the
+ * launches and sizes its workspace from them; every file's own header is checked against its entry on the device, a
+ * mismatch is UCFP_IMAGE_NEEDS_HOST) -- or NULL: the files are probed on the device first, which costs one host
+ * synchronisation inside the call.  PNG files are inflated and unfiltered, JPEG files Huffman-decoded and inverse-
+ * transformed (luma plane) into frames of their own sizes in the context's workspace, BLAKE3 of every file is computed
+ * when d_exact is NULL, and ONE ragged hash (ucfp_image_hash_ragged_dev's kernels) makes the records.  status[i]: 0,
+ * UCFP_IMAGE_NEEDS_HOST (not PNG / JPEG, or a kind of them the device hands back, or a decode irregularity: the host's
+ * decoder decides), UCFP_E_MODALITY (damaged file; geometry outside `pre`); records of files with a non-zero status are
+ * zero.  blob_bytes = d_offsets[n]. */
+int ucfp_image_upload_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n,
+                                     size_t blob_bytes, const ucfp_upload_info* info, const ucfp_image_preprocess* pre,
+                                     const uint8_t* d_exact, uint8_t* d_out, int32_t* d_status, void* stream);
+/* Decode only: frames into the caller's buffer (16-byte aligned, ucfp_image_upload_frames_bytes(info, n) bytes), laid out
+ * by the library; items[i] (HOST, n entries) receives where frame i is and its geometry (width 0: not decoded) -- ready for
+ * ucfp_image_hash_ragged_dev. */
+size_t ucfp_image_upload_frames_bytes(const ucfp_upload_info* info, size_t n);
+int ucfp_image_upload_decode_batch_dev(ucfp_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n, size_t blob_bytes,
+                                       const ucfp_upload_info* info, uint8_t* d_frames, size_t frames_bytes, ucfp_image_item* items,
+                                       int32_t* d_status, void* stream);
+
+/* Host micro-batcher for uploads of ANY kind and size (SURVEY 8f N1 + N4): the per-request shape of handlers::ingest_image
+ * (src/server/handlers.rs:232-302: one upload per request thread, up to 512 in flight, src/bin/ucfp.rs:267) with NO geometry
+ * or format announced at creation.  submit() is BLOCKING and thread-safe: the calling thread probes its own bytes
+ * (ucfp_image_probe); what the device does not decode returns at once with *status = UCFP_IMAGE_NEEDS_HOST / UCFP_E_MODALITY
+ * and a zero record; everything else -- PNG and JPEG files of whatever sizes -- is coalesced with the other threads'
+ * uploads into ONE H2D copy + ucfp_image_upload_hash_batch_dev (decode, BLAKE3 of the file, ragged hash) + one D2H copy
+ * of the records, at most max_batch uploads / max_bytes encoded bytes per flush, flushed no later than max_delay_us after
+ * the first pending upload. */
+typedef struct ucfp_upload_batcher ucfp_upload_batcher;
+int ucfp_upload_batcher_create(ucfp_ctx* ctx, uint32_t algo, const ucfp_image_preprocess* pre, size_t max_batch, size_t max_bytes,
+                               uint32_t max_delay_us, ucfp_upload_batcher** out);
+void ucfp_upload_batcher_destroy(ucfp_upload_batcher* b);
+int ucfp_upload_batcher_submit(ucfp_upload_batcher* b, const uint8_t* bytes, size_t len, uint8_t* out, int32_t* status);
+int ucfp_upload_batcher_stats(ucfp_upload_batcher* b, uint64_t* batches, uint64_t* items);
+
 /* ---- PNG front end ----
  * The reference decodes the upload inside the SDK call (src/modality/image.rs:68-70, :176-179: imgfprint ->
  * image::load_from_memory); BASELINE config 1 (1 k 256x256 PNGs) is decode-bound on the CPU.  These entry points take
@@ -158,7 +218,6 @@ int ucfp_image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, 
  *                          the host's decoder decides -- decode it there, submit the pixels
  *   UCFP_E_MODALITY        not a PNG / damaged stream / bad CRC on a critical chunk (the reference answers 400)
  * png_bytes = d_offsets[n] (the host knows it; sizes the context's workspace: about png_bytes + n x (2 x frame bytes)). */
-#define UCFP_IMAGE_NEEDS_HOST 1
 /* Host-side: geometry and pixel format of a PNG from its IHDR.  UCFP_OK, UCFP_IMAGE_NEEDS_HOST or UCFP_E_MODALITY. */
 int ucfp_png_probe(const uint8_t* png, size_t len, uint32_t* width, uint32_t* height, int* pixfmt);
 /* Encoded files -> frames (frame i at d_frames + i*frame_stride, rows row_stride apart). */

@@ -63,3 +63,4 @@ s["valu_wave_instr_per_doc"] = s["valu_wave_instr_per_unit"]
 json.dump(s, open(dst, "w"), indent=1)
 print(json.dumps({k: v for k, v in s.items() if k not in ("counters_per_dispatch", "dispatches_seen")}, indent=1))
 PY
+cp "profiles/$R/${NAME}_pmc_summary.json" "$O/summary.json" 2>/dev/null; rm -rf "$O"/p1 "$O"/p2 "$O"/p3 "$O"/stats

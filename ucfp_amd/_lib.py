@@ -33,6 +33,12 @@ class ImageItem(C.Structure):
                 ("pixfmt", C.c_int32)]
 
 
+class UploadInfo(C.Structure):
+    """ucfp_upload_info: what ucfp_image_probe says about one encoded upload."""
+    _fields_ = [("format", C.c_int32), ("status", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("pixfmt", C.c_int32), ("reserved", C.c_uint32)]
+
+
 class ImagePreprocess(C.Structure):
     """ucfp_image_preprocess (imgfprint::PreprocessConfig guards)."""
     _fields_ = [("max_dimension", C.c_uint32), ("min_dimension", C.c_uint32)]
@@ -57,6 +63,15 @@ SIGNATURES = {
                                              C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_image_hash_ragged": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(ImageItem), C.c_size_t,
                                          C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_image_probe": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(UploadInfo)]),
+    "ucfp_image_probe_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ucfp_image_upload_hash_batch_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                   C.POINTER(UploadInfo), C.POINTER(ImagePreprocess), C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]),
+    "ucfp_image_upload_frames_bytes": (C.c_size_t, [C.POINTER(UploadInfo), C.c_size_t]),
+    "ucfp_image_upload_decode_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                     C.POINTER(UploadInfo), C.c_void_p, C.c_size_t, C.POINTER(ImageItem),
+                                                     C.c_void_p, C.c_void_p]),
     "ucfp_audio_wang_max_hashes": (C.c_size_t, [C.c_size_t, C.POINTER(WangConfig)]),
     "ucfp_audio_wang": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(WangConfig), C.c_void_p,
                                   C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -184,6 +199,11 @@ SIGNATURES = {
     "ucfp_png_batcher_destroy": (None, [C.c_void_p]),
     "ucfp_png_batcher_submit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32)]),
     "ucfp_png_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ucfp_upload_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(ImagePreprocess), C.c_size_t, C.c_size_t,
+                                             C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ucfp_upload_batcher_destroy": (None, [C.c_void_p]),
+    "ucfp_upload_batcher_submit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32)]),
+    "ucfp_upload_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ucfp_blake3": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ucfp_image_synth_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                        C.c_uint32, C.c_size_t, C.c_void_p]),

@@ -25,7 +25,7 @@ using ucfp::capi_fail;
 
 namespace {
 
-enum Kind { kTextMinhash, kTextSimhash, kAudioWang, kPngHash, kJpegHash };
+enum Kind { kTextMinhash, kTextSimhash, kAudioWang, kPngHash, kJpegHash, kUploadHash };
 
 // Pinned / device staging of one set.  Input: [max_batch + 1 payload offsets | payload], one H2D copy.
 // Result (text): [max_batch status words | n records], one D2H copy.  Result (audio): [max_batch + 1 hash offsets],
@@ -48,6 +48,7 @@ struct Ragged {
 
     uint8_t* h_in[2] = {nullptr, nullptr};
     uint8_t* h_out[2] = {nullptr, nullptr};
+    ucfp_upload_info* h_info[2] = {nullptr, nullptr};   // uploads of any kind and size: each slot's probe result
     uint8_t* d_in = nullptr;
     uint8_t* d_out = nullptr;
     uint8_t* d_hashes = nullptr;  // audio
@@ -84,6 +85,11 @@ int run_set(Ragged* b, int s, size_t n, size_t units) {
             rc = ucfp_image_jpeg_hash_batch_dev(b->ctx, b->algo, d_pay, d_off, n, units, b->width, b->height, &b->pre, nullptr,
                                                 b->d_out + b->out_head, reinterpret_cast<int32_t*>(b->d_out), b->stream);
             break;
+        case kUploadHash:
+            // uploads of any kind and size: PNG and JPEG decoded on the device, each to its own geometry, one ragged hash
+            rc = ucfp_image_upload_hash_batch_dev(b->ctx, b->algo, d_pay, d_off, n, units, b->h_info[s], &b->pre, nullptr,
+                                                  b->d_out + b->out_head, reinterpret_cast<int32_t*>(b->d_out), b->stream);
+            break;
         case kAudioWang:
             rc = ucfp_audio_wang_batch_dev(b->ctx, reinterpret_cast<const float*>(d_pay), d_off, units, n, b->sample_rate,
                                            &b->wang, b->d_hashes, b->out_cap, reinterpret_cast<uint64_t*>(b->d_out), b->stream);
@@ -114,6 +120,8 @@ void teardown(Ragged* b) {
     for (int s = 0; s < 2; s++) {
         if (b->h_in[s]) (void)hipHostFree(b->h_in[s]);
         if (b->h_out[s]) (void)hipHostFree(b->h_out[s]);
+        delete[] b->h_info[s];
+        b->h_info[s] = nullptr;
     }
     if (b->d_in) (void)hipFree(b->d_in);
     if (b->d_out) (void)hipFree(b->d_out);
@@ -175,6 +183,9 @@ struct ucfp_audio_batcher {
     Ragged r;
 };
 struct ucfp_png_batcher {
+    Ragged r;
+};
+struct ucfp_upload_batcher {
     Ragged r;
 };
 
@@ -307,6 +318,84 @@ int ucfp_png_batcher_submit(ucfp_png_batcher* b, const uint8_t* png, size_t len,
 }
 
 int ucfp_png_batcher_stats(ucfp_png_batcher* b, uint64_t* batches, uint64_t* items) {
+    if (!b) return capi_fail(UCFP_E_INVALID, "batcher is NULL");
+    b->r.core.stats(batches, items);
+    return UCFP_OK;
+}
+
+// ---- uploads of ANY kind and size (SURVEY 8f N1 + N4): no geometry at creation ----
+int ucfp_upload_batcher_create(ucfp_ctx* ctx, uint32_t algo, const ucfp_image_preprocess* pre, size_t max_batch, size_t max_bytes,
+                               uint32_t max_delay_us, ucfp_upload_batcher** out) {
+    if (!ctx || !out) return capi_fail(UCFP_E_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    const size_t rec = ucfp_image_record_bytes(algo);
+    if (!rec) return capi_fail(UCFP_E_UNSUPPORTED, "image algo mask %u", algo);
+    if (max_batch == 0 || max_batch > 65536 || max_bytes == 0 || max_bytes >= ((size_t)1 << 32))
+        return capi_fail(UCFP_E_INVALID, "batcher needs 1 <= max_batch <= 65536 and 1 <= max_bytes < 2^32");
+    ucfp_upload_batcher* b = new (std::nothrow) ucfp_upload_batcher();
+    if (!b) return capi_fail(UCFP_E_INDEX, "out of host memory");
+    Ragged& r = b->r;
+    r.ctx = ctx;
+    r.device = ucfp::ctx_device(ctx);
+    r.kind = kUploadHash;
+    r.algo = algo;
+    if (pre) r.pre = *pre;
+    r.unit = 1;
+    r.rec = rec;
+    r.max_batch = max_batch;
+    r.max_units = max_bytes;
+    for (int s = 0; s < 2; s++) {
+        r.h_info[s] = new (std::nothrow) ucfp_upload_info[max_batch];
+        if (!r.h_info[s]) {
+            teardown(&b->r);
+            delete b;
+            return capi_fail(UCFP_E_INDEX, "out of host memory");
+        }
+    }
+    const int rc = start(&b->r, max_delay_us);
+    if (rc) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return UCFP_OK;
+}
+
+void ucfp_upload_batcher_destroy(ucfp_upload_batcher* b) {
+    if (!b) return;
+    teardown(&b->r);
+    delete b;
+}
+
+int ucfp_upload_batcher_submit(ucfp_upload_batcher* b, const uint8_t* bytes, size_t len, uint8_t* out, int32_t* status) {
+    if (!b || !out || (len && !bytes)) return capi_fail(UCFP_E_INVALID, "batcher/bytes/out is NULL");
+    Ragged& r = b->r;
+    // the request thread looks at its own upload: what the device does not decode never takes a slot
+    ucfp_upload_info info;
+    const int pst = ucfp_image_probe(bytes, len, &info);
+    if (pst != UCFP_OK || len > r.max_units) {
+        memset(out, 0, r.rec);
+        if (status) *status = pst != UCFP_OK ? pst : UCFP_IMAGE_NEEDS_HOST;     // (larger than a whole batch: the host path)
+        return UCFP_OK;
+    }
+    ucfp::BatchCore::Ticket t;
+    t.set = -1;
+    if (!r.core.claim(len, &t)) return capi_fail(UCFP_E_INDEX, "batcher is shutting down");
+    r.offsets(t.set)[t.slot] = t.at;
+    r.h_info[t.set][t.slot] = info;
+    memcpy(r.payload(t.set) + t.at, bytes, len);
+    r.core.commit(t);
+    const int rc = r.core.wait(t);
+    if (rc == UCFP_OK) {
+        memcpy(out, r.h_out[t.set] + r.out_head + t.slot * r.rec, r.rec);
+        if (status) *status = reinterpret_cast<const int32_t*>(r.h_out[t.set])[t.slot];
+    }
+    r.core.release(t);
+    if (rc != UCFP_OK) return capi_fail(rc, "batched upload launch failed");
+    return UCFP_OK;
+}
+
+int ucfp_upload_batcher_stats(ucfp_upload_batcher* b, uint64_t* batches, uint64_t* items) {
     if (!b) return capi_fail(UCFP_E_INVALID, "batcher is NULL");
     b->r.core.stats(batches, items);
     return UCFP_OK;

@@ -30,72 +30,20 @@ int capi_fail(int code, const char* fmt, ...) {
 }
 }  // namespace ucfp
 
+#include "ctx.h"
+#include "upload_probe.h"
+
+using ucfp::grow;
+
 namespace {
 #define fail ucfp::capi_fail
-
-#define HIP_TRY(expr)                                                                      \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return fail(UCFP_E_INDEX, "%s failed: %s", #expr, hipGetErrorString(e_));      \
-    } while (0)
 
 constexpr size_t kNormWsFrames = 2048;  // generic-geometry normalised planes held at once (128 MiB: inside the 256 MB
                                        // Infinity Cache, and enough frames per launch to fill the chip with small frames)
 
 }  // namespace
 
-struct ucfp_ctx {
-    int device = 0;
-    uint8_t* norm_ws = nullptr;  // kNormWsFrames x 65536: ONE scratch area shared by every generic-geometry launch,
-    std::mutex norm_mu;          // so its users are ordered across streams: enqueue under norm_mu, wait on / record
-    hipEvent_t norm_done = nullptr;  // norm_done around the launch (ucfp::image_hash_ordered)
-    // host-variant staging (grown on demand), guarded by `mu`
-    std::mutex mu;
-    uint8_t* stage_in = nullptr;
-    size_t stage_in_cap = 0;
-    uint8_t* stage_out = nullptr;
-    size_t stage_out_cap = 0;
-    hipStream_t host_stream = nullptr;
-    // audio workspace (spilled spectrogram chunk, candidate lists), shared by successive calls
-    uint8_t* audio_ws = nullptr;
-    size_t audio_ws_cap = 0;
-    hipEvent_t audio_done = nullptr;
-    // PNG front end: gathered zlib streams, filtered scanlines, decoded frames of the last batch
-    uint8_t* png_ws = nullptr;
-    size_t png_ws_cap = 0;
-    hipEvent_t png_done = nullptr;
-    // BLAKE3 chaining values of the last batch (+ the digests when the PNG call computes `exact` itself); ordered by png_done
-    uint8_t* b3_ws = nullptr;
-    size_t b3_ws_cap = 0;
-    // per-frame tables of ragged image batches (ImgItem rows, rejected slots): two pinned + device buffer pairs used in
-    // turn; `used[i]` is recorded behind the kernels that read pair i and waited for before the host rewrites it
-    std::mutex item_mu;
-    uint8_t* item_h[2] = {nullptr, nullptr};
-    uint8_t* item_d[2] = {nullptr, nullptr};
-    size_t item_cap[2] = {0, 0};
-    hipEvent_t item_used[2] = {nullptr, nullptr};
-    int item_next = 0;
-    size_t any_max_pixels = (size_t)1 << 20;   // uniform batches: frames up to this size take the fused any-geometry kernel
-};
-
-namespace {
-
-int grow(uint8_t** p, size_t* cap, size_t need) {
-    if (*cap >= need) return 0;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    size_t want = need + need / 4;
-    HIP_TRY(hipMalloc((void**)p, want));
-    *cap = want;
-    return 0;
-}
-
-}  // namespace
-
 namespace ucfp {
-int capi_fail(int code, const char* fmt, ...);
 int ctx_device(const ucfp_ctx* ctx) { return ctx->device; }
 // Every image launch of the library goes through here.  The fused kernels touch no shared state; a geometry that
 // normalises into ctx->norm_ws first waits (on `stream`) for the previous user of that workspace -- whatever stream
@@ -128,86 +76,6 @@ int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size
     return (int)hipEventRecord(ctx->norm_done, stream);
 }
 
-// Ragged batch of decoded frames: every frame has its own geometry.  items: HOST array.  Frames inside the fused kernel's
-// range take ONE launch per form group (rows up to / beyond 512 pixels); the rest (more than any_max_pixels) go one by
-// one down the many-waves-per-frame path.  Returns a ucfp_status (message set), not a hipError_t.
-int image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* base, size_t frames_bytes, const ucfp_image_item* items, size_t n,
-                      uint32_t min_dim, uint32_t max_dim, const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t st) {
-    const size_t rec = algo == 7u ? 536 : 168, isz = image_any_item_bytes();
-    // plan on the host: form group, class and parts of every frame
-    std::vector<uint32_t> reject, big;
-    std::vector<uint8_t> tab[3];          // ImgItem rows of the three width groups (rows up to 512 / 1024 / 2048 pixels): a launch each
-    size_t cnt[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; i++) {
-        const ucfp_image_item& it = items[i];
-        if (it.pixfmt < UCFP_PIX_GRAY8 || it.pixfmt > UCFP_PIX_RGBA8) return capi_fail(UCFP_E_INVALID, "item %zu: unknown pixfmt %d", i, it.pixfmt);
-        const size_t bpp = it.pixfmt == UCFP_PIX_GRAY8 ? 1 : it.pixfmt == UCFP_PIX_RGB8 ? 3 : 4;
-        if (it.width == 0 || it.height == 0 || it.width < min_dim || it.height < min_dim || it.width > max_dim || it.height > max_dim) {
-            reject.push_back((uint32_t)i);            // Error::Modality for this frame (image.rs:70), the others go on
-            continue;
-        }
-        if (it.row_stride < (size_t)it.width * bpp) return capi_fail(UCFP_E_INVALID, "item %zu: row_stride %u < width * bpp", i, it.row_stride);
-        const uint64_t end = it.offset + (uint64_t)(it.height - 1) * it.row_stride + (uint64_t)it.width * bpp;
-        if (end > frames_bytes || end < it.offset) return capi_fail(UCFP_E_INVALID, "item %zu reaches beyond the %zu bytes of frames", i, frames_bytes);
-        uint32_t cls = 0, magic = 0, shift = 0;
-        if ((size_t)it.width * it.height > ctx->any_max_pixels ||
-            !image_any_plan(base, it.offset, it.width, it.height, it.row_stride, it.pixfmt, &cls, &magic, &shift)) {
-            big.push_back((uint32_t)i);
-            continue;
-        }
-        const int g = image_any_group(cls);
-        tab[g].resize((cnt[g] + 1) * isz);
-        image_any_item_write(tab[g].data(), cnt[g]++, it.offset, it.width, it.height, it.row_stride, (uint32_t)i, cls, magic, shift);
-    }
-    // tables -> device through one of the two pinned / device pairs
-    size_t o[4];
-    o[0] = 0;
-    for (int g = 0; g < 3; g++) o[g + 1] = o[g] + ((tab[g].size() + 255) & ~(size_t)255);
-    const size_t o2 = o[3];
-    const size_t bytes = o2 + reject.size() * 4;
-    const uint8_t* d_tab = nullptr;
-    int pair = -1;
-    if (bytes) {
-        std::lock_guard<std::mutex> lk(ctx->item_mu);
-        pair = ctx->item_next;
-        ctx->item_next ^= 1;
-        hipError_t e = hipEventSynchronize(ctx->item_used[pair]);          // the launches that read this pair last are done
-        if (e == hipSuccess && ctx->item_cap[pair] < bytes) {
-            if (ctx->item_h[pair]) (void)hipHostFree(ctx->item_h[pair]);
-            if (ctx->item_d[pair]) (void)hipFree(ctx->item_d[pair]);
-            ctx->item_h[pair] = ctx->item_d[pair] = nullptr;
-            ctx->item_cap[pair] = 0;
-            const size_t want = bytes + bytes / 2 + 4096;
-            e = hipHostMalloc((void**)&ctx->item_h[pair], want, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipMalloc((void**)&ctx->item_d[pair], want);
-            if (e == hipSuccess) ctx->item_cap[pair] = want;
-        }
-        if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "item table staging failed: %s", hipGetErrorString(e));
-        for (int g = 0; g < 3; g++)
-            if (!tab[g].empty()) memcpy(ctx->item_h[pair] + o[g], tab[g].data(), tab[g].size());
-        if (!reject.empty()) memcpy(ctx->item_h[pair] + o2, reject.data(), reject.size() * 4);
-        e = hipMemcpyAsync(ctx->item_d[pair], ctx->item_h[pair], bytes, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "item table copy failed: %s", hipGetErrorString(e));
-        d_tab = ctx->item_d[pair];
-    }
-    const uint8_t* hi = base + frames_bytes;
-    for (int g = 0; g < 3; g++)
-        if (cnt[g])
-            launch_image_hash_any(algo, base, d_tab + o[g], cnt[g], g, 0, 0, 0, 0, 0, 0, 0, base, hi, exact, out, status, st);
-    if (!reject.empty())
-        launch_image_reject_list(reinterpret_cast<const uint32_t*>(d_tab + o2), reject.size(), out, (uint32_t)rec, status, st);
-    hipError_t e = hipGetLastError();
-    if (pair >= 0 && e == hipSuccess) e = hipEventRecord(ctx->item_used[pair], st);
-    if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "ragged image launch failed: %s", hipGetErrorString(e));
-    for (uint32_t i : big) {
-        const ucfp_image_item& it = items[i];
-        e = (hipError_t)image_hash_ordered(ctx, algo, base + it.offset, 1, it.width, it.height, it.row_stride,
-                                           (size_t)it.row_stride * it.height, it.pixfmt, min_dim, max_dim,
-                                           exact ? exact + 32 * (size_t)i : nullptr, out + (size_t)i * rec, status ? status + i : nullptr, st);
-        if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "image launch failed: %s", hipGetErrorString(e));
-    }
-    return UCFP_OK;
-}
 }  // namespace ucfp
 
 extern "C" {
@@ -310,55 +178,6 @@ int ucfp_image_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frame
     return UCFP_OK;
 }
 
-int ucfp_image_hash_ragged_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d_frames, size_t frames_bytes,
-                               const ucfp_image_item* items, size_t n, const ucfp_image_preprocess* pre, const uint8_t* d_exact,
-                               uint8_t* d_out, int32_t* d_status, void* stream) {
-    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
-    if (ucfp_image_record_bytes(algo) == 0)
-        return fail(UCFP_E_UNSUPPORTED, "image algo mask %u is not one of ahash|phash|dhash|multi", algo);
-    if (n == 0) return UCFP_OK;
-    if (!items || !d_frames || !d_out) return fail(UCFP_E_INVALID, "items/frames/out is NULL");
-    if (n > 0x7fffffffu) return fail(UCFP_E_INVALID, "batch of %zu frames exceeds one launch", n);
-    const uint32_t min_dim = pre ? pre->min_dimension : 32u, max_dim = pre ? pre->max_dimension : 8192u;
-    HIP_TRY(hipSetDevice(ctx->device));
-    return ucfp::image_hash_ragged(ctx, algo, d_frames, frames_bytes, items, n, min_dim, max_dim, d_exact, d_out, d_status,
-                                   (hipStream_t)stream);
-}
-
-int ucfp_image_hash_ragged(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t frames_bytes, const ucfp_image_item* items,
-                           size_t n, const ucfp_image_preprocess* pre, const uint8_t* exact, uint8_t* out, int32_t* status) {
-    if (!ctx) return fail(UCFP_E_INVALID, "ctx is NULL");
-    const size_t rec = ucfp_image_record_bytes(algo);
-    if (rec == 0) return fail(UCFP_E_UNSUPPORTED, "image algo mask %u is not one of ahash|phash|dhash|multi", algo);
-    if (n == 0) return UCFP_OK;
-    if (!items || !frames || !out) return fail(UCFP_E_INVALID, "items/frames/out is NULL");
-    if (n > 0x7fffffffu) return fail(UCFP_E_INVALID, "batch of %zu frames exceeds one launch", n);
-    const uint32_t min_dim = pre ? pre->min_dimension : 32u, max_dim = pre ? pre->max_dimension : 8192u;
-    const size_t in_bytes = (frames_bytes + 64 + 255) & ~(size_t)255;
-    const size_t o_ex = (n * rec + 255) & ~(size_t)255, o_st = o_ex + ((n * 32 + 255) & ~(size_t)255);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
-    int rc = grow(&ctx->stage_in, &ctx->stage_in_cap, in_bytes);
-    if (rc) return rc;
-    rc = grow(&ctx->stage_out, &ctx->stage_out_cap, o_st + n * 4);
-    if (rc) return rc;
-    hipStream_t st = ctx->host_stream;
-    HIP_TRY(hipMemcpyAsync(ctx->stage_in, frames, frames_bytes, hipMemcpyHostToDevice, st));
-    uint8_t* d_exact = ctx->stage_out + o_ex;
-    int32_t* d_status = reinterpret_cast<int32_t*>(ctx->stage_out + o_st);
-    if (exact) HIP_TRY(hipMemcpyAsync(d_exact, exact, n * 32, hipMemcpyHostToDevice, st));
-    rc = ucfp::image_hash_ragged(ctx, algo, ctx->stage_in, frames_bytes, items, n, min_dim, max_dim, exact ? d_exact : nullptr,
-                                 ctx->stage_out, d_status, st);
-    if (rc) {
-        (void)hipStreamSynchronize(st);
-        return rc;
-    }
-    HIP_TRY(hipMemcpyAsync(out, ctx->stage_out, n * rec, hipMemcpyDeviceToHost, st));
-    if (status) HIP_TRY(hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return UCFP_OK;
-}
-
 // ---------------------------------- BLAKE3 on the device ----------------------------------------
 
 int ucfp_blake3_batch_dev(ucfp_ctx* ctx, const uint8_t* d_blob, const uint64_t* d_offsets, size_t n, size_t blob_bytes,
@@ -384,21 +203,9 @@ int ucfp_blake3_batch_dev(ucfp_ctx* ctx, const uint8_t* d_blob, const uint64_t* 
 
 int ucfp_png_probe(const uint8_t* png, size_t len, uint32_t* width, uint32_t* height, int* pixfmt) {
     if (!png || !width || !height || !pixfmt) return fail(UCFP_E_INVALID, "NULL argument");
-    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
-    auto be = [&](size_t o) { return (uint32_t)png[o] << 24 | (uint32_t)png[o + 1] << 16 | (uint32_t)png[o + 2] << 8 | png[o + 3]; };
-    if (len < 8 + 25 || memcmp(png, sig, 8) != 0 || be(8) != 13 || memcmp(png + 12, "IHDR", 4) != 0)
-        return fail(UCFP_E_MODALITY, "not a PNG file");
-    *width = be(16);
-    *height = be(20);
-    const int depth = png[24], ctype = png[25], comp = png[26], filt = png[27], lace = png[28];
-    if (*width == 0 || *height == 0 || comp != 0 || filt != 0 || lace > 1) return fail(UCFP_E_MODALITY, "damaged IHDR");
-    if (depth != 8 || lace != 0) return UCFP_IMAGE_NEEDS_HOST;
-    // the format the file DECODES to: indexed colour -> RGB8 through its palette, grey + alpha -> GRAY8 (alpha dropped)
-    if (ctype == 0 || ctype == 4) *pixfmt = UCFP_PIX_GRAY8;
-    else if (ctype == 2 || ctype == 3) *pixfmt = UCFP_PIX_RGB8;
-    else if (ctype == 6) *pixfmt = UCFP_PIX_RGBA8;
-    else return UCFP_IMAGE_NEEDS_HOST;
-    return UCFP_OK;
+    const int rc = ucfp::png_probe_bytes(png, len, width, height, pixfmt);
+    if (rc < 0) return fail(rc, "not a PNG file (or a damaged IHDR)");
+    return rc;
 }
 
 static int png_check(ucfp_ctx* ctx, const void* d_png, const void* d_offsets, size_t n, size_t png_bytes, uint32_t w, uint32_t h,
@@ -492,29 +299,9 @@ int ucfp_image_png_hash_batch_dev(ucfp_ctx* ctx, uint32_t algo, const uint8_t* d
 // ---------------------------------- JPEG front end ------------------------------------
 int ucfp_jpeg_probe(const uint8_t* jpg, size_t len, uint32_t* width, uint32_t* height) {
     if (!jpg || !width || !height) return fail(UCFP_E_INVALID, "NULL argument");
-    *width = *height = 0;
-    if (len < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return fail(UCFP_E_MODALITY, "not a JPEG file");
-    size_t pos = 2;
-    for (;;) {
-        if (pos + 4 > len || jpg[pos] != 0xFF) return UCFP_IMAGE_NEEDS_HOST;
-        while (pos < len && jpg[pos] == 0xFF) pos++;
-        if (pos >= len) return UCFP_IMAGE_NEEDS_HOST;
-        const int m = jpg[pos++];
-        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
-        if (m == 0xD9 || m == 0xDA || pos + 2 > len) return UCFP_IMAGE_NEEDS_HOST;      // a scan before any frame header
-        const size_t l = (size_t)jpg[pos] << 8 | jpg[pos + 1];
-        if (l < 2 || pos + l > len) return UCFP_IMAGE_NEEDS_HOST;
-        if (m == 0xC0 || m == 0xC1) {
-            if (l < 8 || jpg[pos + 2] != 8) return UCFP_IMAGE_NEEDS_HOST;
-            *height = (uint32_t)jpg[pos + 3] << 8 | jpg[pos + 4];
-            *width = (uint32_t)jpg[pos + 5] << 8 | jpg[pos + 6];
-            const int nc = jpg[pos + 7];
-            if (*width == 0 || *height == 0 || (nc != 1 && nc != 3)) return UCFP_IMAGE_NEEDS_HOST;
-            return UCFP_OK;
-        }
-        if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8) return UCFP_IMAGE_NEEDS_HOST;   // progressive, arithmetic ...
-        pos += l;
-    }
+    const int rc = ucfp::jpeg_probe_bytes(jpg, len, width, height);
+    if (rc < 0) return fail(rc, "not a JPEG file");
+    return rc;
 }
 
 static int jpeg_check(ucfp_ctx* ctx, const void* d_jpg, const void* d_offsets, size_t n, size_t jpg_bytes, uint32_t w, uint32_t h) {

@@ -40,7 +40,8 @@ int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_item
                           uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_magic, uint32_t proto_shift,
                           size_t frame_stride, const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out,
                           int32_t* status, hipStream_t stream);
-int launch_image_reject_list(const uint32_t* d_slots, size_t n, uint8_t* out, uint32_t rec, int32_t* status, hipStream_t stream);
+// (slot, status) pairs: zero record (out may be NULL) + the status for frames that are not hashed
+int launch_image_preset_list(const uint32_t* d_entries, size_t n, uint8_t* out, uint32_t rec, int32_t* status, hipStream_t stream);
 int launch_image_record_codes(const uint8_t* records, size_t n, uint32_t rec_bytes, uint32_t offset, uint64_t* codes,
                               hipStream_t stream);
 int launch_image_synth(uint8_t* frames, size_t n, uint32_t w, uint32_t h, size_t first,
@@ -96,7 +97,7 @@ int launch_png_decode_ragged(const uint8_t* png, const uint64_t* offsets, const 
 
 // jpeg.hip
 struct JpegWs {
-    size_t clean = 0, info = 0, seg = 0, qtab = 0, coef = 0, coef_stride = 0, first = 0, total = 0;
+    size_t clean = 0, info = 0, seg = 0, qtab = 0, coef = 0, coef_stride = 0, total = 0;
     size_t jpg_bytes = 0;   // the batch's encoded bytes (picks the decoder's waves per file)
     uint32_t bxp = 0, byp = 0, max_seg = 0;
 };
@@ -107,12 +108,12 @@ int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, ui
 int launch_jpeg_merge_status(const uint8_t* ws, const JpegWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,
                              hipStream_t stream, const UpItem* d_items = nullptr);
 // ragged: n files listed in d_items (device); seg_words / coef_words = the batch's totals of segment-table words and
-// coefficient-plane int16 (per file: jpeg_plane_geometry); the n + 1 words at ws + first (first inverse-DCT workgroup of
-// every entry, ceil(bxp byp / 256) each) are written by the caller before the launch
+// coefficient-plane int16 (per file: jpeg_plane_geometry); d_first: n + 1 device words, the first inverse-DCT workgroup of
+// every entry (ceil(bxp byp / 256) each), d_first[n] = idct_groups
 void jpeg_plane_geometry(uint32_t w, uint32_t h, uint32_t* bxp, uint32_t* byp, uint32_t* max_seg);
 size_t jpeg_ragged_ws_bytes(size_t n, size_t jpg_bytes, size_t seg_words, size_t coef_words, JpegWs* ws);
-int launch_jpeg_decode_ragged(const uint8_t* jpg, const uint64_t* offsets, const UpItem* d_items, size_t n, size_t idct_groups,
-                              uint8_t* ws, const JpegWs& l, uint8_t* frames, int32_t* status, hipStream_t stream);
+int launch_jpeg_decode_ragged(const uint8_t* jpg, const uint64_t* offsets, const UpItem* d_items, size_t n, const uint32_t* d_first,
+                              size_t idct_groups, uint8_t* ws, const JpegWs& l, uint8_t* frames, int32_t* status, hipStream_t stream);
 
 // hamming.hip
 struct HammingPlan {

@@ -23,6 +23,7 @@
 // HBM-bound by construction: 262 144 B read + 536 B written per 512x512 luma frame.
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/ucfp_dct32.h"
@@ -52,12 +53,13 @@ __device__ __forceinline__ uint4 load_frame16(const uint8_t* p) {
 struct ImageLds {
     uint8_t s2[128 * 128];   // 16 KiB
     uint16_t v8[32 * 256];   // 16 KiB
-    uint16_t cs32[8 * 256];  // 4 KiB: column sums over 32 normalised rows (global 9x8 dHash image)
     uint16_t gsum[32 * 32];  // 2 KiB
     uint8_t g32[32 * 32];    // 1 KiB
     float pbuf[kNW][32 * 8]; // per-wave P = X*C8^T
     float coef[kNW][64];     // per-wave DCT low block
     uint64_t hashes[3][17];  // [ahash, phash, dhash][region]
+    // LAST: phase B makes it from v8; the fused any-geometry kernel keeps its phase-A row buffers in these bytes (and beyond)
+    alignas(16) uint16_t cs32[8 * 256];  // 4 KiB: column sums over 32 normalised rows (global 9x8 dHash image)
 };
 
 // ---- phase A helpers -----------------------------------------------------------------
@@ -931,6 +933,9 @@ struct ImgItem {
 };
 static_assert(sizeof(ImgItem) == 40, "ImgItem is uploaded as raw bytes");
 
+#ifndef UCFP_ANY_WAVES0
+#define UCFP_ANY_WAVES0 6      // waves per SIMD the narrow group's kernel is built for: three workgroups per CU (measured against 4: 300x200 RGB 12.7 -> 13.8 M frames/s, 301x200 8.7 -> 11.3, 300x200 grey 13.1 -> 16.4)
+#endif
 constexpr uint32_t kAnyMaxWidth = 2048;                // the wave's row buffer: one byte per source pixel
 __host__ __device__ constexpr uint32_t any_row_bytes(int group) { return (512u << group) + 32u; }   // (+ the windows' look-ahead)
 constexpr uint32_t kAnyMaxPixels = (1u << 22) - 1;     // 2 w h < 2^23: the magic number fits 32 bits (any_magic)
@@ -956,6 +961,72 @@ __device__ __forceinline__ uint32_t strip_luma_bytes(const RawStrip<BPP>& r) {
     }
     // v_perm_b32(s0, s1, sel): selector 0-3 = bytes of s1, 4-7 = bytes of s0, 0x0c = the constant 0
     return __builtin_amdgcn_perm(x1, x0, 0x0c0c0501u) | __builtin_amdgcn_perm(x3, x2, 0x05010c0cu);
+}
+
+// What a lane loads of a source row at a time: 16 GRAY8 pixels (one 16-byte load: 64 lanes read 1 KiB), or 4 colour pixels
+// (12 / 16 bytes).  NL = dwords of luma bytes a unit becomes (4 / 1 / 1).
+template <int BPP>
+struct AnyUnit {
+    static constexpr int NW = BPP == 3 ? 3 : 4;      // dwords
+    static constexpr int NL = BPP == 1 ? 4 : 1;
+    static constexpr int kBytes = 4 * NW;
+    uint32_t w[NW];
+};
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));       // dword-aligned 16-byte access
+typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
+// ALIGNED: the unit starts on a dword (GRAY8, RGB8) / on 16 bytes (RGBA8).  Otherwise it is assembled from the aligned dwords
+// around it (one more dword, v_alignbyte).  Either way a unit whose dwords would reach outside [lo, hi) -- the first of the
+// first row, the last of the last -- is read byte by byte.
+template <int BPP, bool ALIGNED>
+__device__ __forceinline__ AnyUnit<BPP> load_any_unit(const uint8_t* __restrict__ p, const uint8_t* lo, const uint8_t* hi) {
+    constexpr int NW = AnyUnit<BPP>::NW;
+    AnyUnit<BPP> r;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = ALIGNED ? 0u : (uint32_t)(a & 3);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    if (reinterpret_cast<const uint8_t*>(q) >= lo && reinterpret_cast<const uint8_t*>(q + NW + (ALIGNED ? 0 : 1)) <= hi) {
+        uint32_t d[NW + 1];
+        if (NW == 3) {
+            if (ALIGNED) {
+                const u32x3a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x3a4*>(q));
+                d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = 0;
+            } else {
+                const u32x4a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4a4*>(q));
+                d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+            }
+        } else {
+            const u32x4a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4a4*>(q));
+            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+            d[NW] = ALIGNED ? 0u : __builtin_nontemporal_load(q + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) r.w[i] = ALIGNED ? d[i] : __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint8_t* pb = p + 4 * i + b;
+                if (pb >= lo && pb < hi) v |= (uint32_t)*pb << (8 * b);
+            }
+            r.w[i] = v;
+        }
+    }
+    return r;
+}
+// the unit's lumas as bytes (spec I1): NL dwords
+template <int BPP>
+__device__ __forceinline__ void any_unit_luma(const AnyUnit<BPP>& u, uint32_t (&l)[AnyUnit<BPP>::NL]) {
+    if (BPP == 1) {
+#pragma unroll
+        for (int i = 0; i < AnyUnit<BPP>::NL; i++) l[i] = u.w[i];
+    } else {
+        RawStrip<BPP> r;
+#pragma unroll
+        for (int i = 0; i < BPP; i++) r.w[i] = u.w[i];
+        l[0] = strip_luma_bytes<BPP>(r);
+    }
 }
 
 // Folds destination row j (the lane's four pixels q[0..3] of columns col4 .. col4 + 3) into the LDS planes.  Rows arrive in
@@ -995,14 +1066,15 @@ template <int BPP, int SP, bool ALIGNED>
 __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ lrow, const ImgItem& it,
                                             const uint8_t* __restrict__ base, const uint8_t* lo, const uint8_t* hi) {
     constexpr int NT = SP <= 2 ? 1 : SP <= 4 ? 2 : 3;      // windows of <= 4 / 6 / 10 pixels at any byte phase
-    const uint32_t t = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (the wave's number through readfirstlane: the compiler then keeps the row loop's control -- band, source row, overlaps --
+    // in scalar registers and branches on SCC; derived from threadIdx alone it ran on the vector unit under exec masks)
+    const uint32_t t = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t w = it.w, h = it.h;
     const size_t row_stride = it.row_stride;
     const uint8_t* __restrict__ f = base + it.src;
     const uint32_t j0 = (256u / kNW) * wave, j1 = j0 + 256u / kNW;
     const uint32_t ys = (h * j0) >> 8;
     const uint32_t D = w * h, magic = it.magic, shift = it.shift;
-    const uint32_t nblk = (w + 3) / 4;
     constexpr int PF = SP <= 1 ? 6 : SP <= 2 ? 4 : SP <= 4 ? 2 : 1;     // source rows in flight ahead of the one being consumed
     const uint32_t col4 = 4 * t;                          // this lane's four destination columns
     // horizontal geometry of the lane's columns, fixed for the frame: first dword and byte phase of the window, which of its
@@ -1032,15 +1104,20 @@ __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ l
     uint32_t acc[4] = {0, 0, 0, 0};
     RowFold fold;
     fold.init();
-    RawStrip<BPP> cur[SP], nxt[PF][SP];
-    auto load_row = [&](RawStrip<BPP> (&dst)[SP], uint32_t y) {
+    // units per lane: a GRAY8 unit is 16 pixels, a colour unit 4; unit u of the row = lane (u % 64) of round (u / 64)
+    using Unit = AnyUnit<BPP>;
+    constexpr int UPX = 4 * Unit::NL;
+    constexpr int SU = BPP == 1 ? (SP + 3) / 4 : SP;
+    const uint32_t nunit = (w + UPX - 1) / UPX;
+    Unit cur[SU], nxt[PF][SU];
+    auto load_row = [&](Unit (&dst)[SU], uint32_t y) {
         const uint8_t* __restrict__ row = f + (size_t)y * row_stride;
 #pragma unroll
-        for (int s = 0; s < SP; s++) {
-            if (s == 0 || (uint32_t)(64 * s) < nblk) {       // (wave-uniform: a narrow frame skips the idle strip slots)
-                const uint32_t blk = s * 64 + t;
-                // strips past the row's end re-read its last strip: they are never stored
-                dst[s] = load_raw_strip<BPP, ALIGNED>(row + (size_t)(blk < nblk ? blk : nblk - 1) * 4 * BPP, lo, hi);
+        for (int s = 0; s < SU; s++) {
+            if (s == 0 || (uint32_t)(64 * s) < nunit) {      // (wave-uniform: a narrow frame skips the idle rounds)
+                const uint32_t u = s * 64 + t;
+                // units past the row's end re-read its last unit: they are never stored
+                dst[s] = load_any_unit<BPP, ALIGNED>(row + (size_t)(u < nunit ? u : nunit - 1) * UPX * BPP, lo, hi);
             }
         }
     };
@@ -1053,10 +1130,15 @@ __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ l
         load_row(nxt[PF - 1], y + PF < h ? y + PF : h - 1);
         // 1. the row's lumas, as bytes, into the wave's row buffer
 #pragma unroll
-        for (int s = 0; s < SP; s++) {
-            if (s == 0 || (uint32_t)(64 * s) < nblk) {
-                const uint32_t blk = s * 64 + t;
-                if (blk < nblk) *reinterpret_cast<uint32_t*>(lrow + 4 * blk) = strip_luma_bytes<BPP>(cur[s]);
+        for (int s = 0; s < SU; s++) {
+            if (s == 0 || (uint32_t)(64 * s) < nunit) {
+                const uint32_t u = s * 64 + t;
+                uint32_t lb[Unit::NL];
+                any_unit_luma<BPP>(cur[s], lb);
+                if (u < nunit) {
+                    if (Unit::NL == 4) *reinterpret_cast<uint4*>(lrow + 16 * u) = make_uint4(lb[0], lb[1], lb[2], lb[Unit::NL - 1]);
+                    else *reinterpret_cast<uint32_t*>(lrow + 4 * u) = lb[0];
+                }
             }
         }
         wave_lds_fence();
@@ -1076,6 +1158,7 @@ __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ l
                 ed = __builtin_amdgcn_udot4(win, edge[c][k], ed, false);
             }
             H[c] = (in << 8) + ed;
+            __builtin_assume(H[c] < (1u << 24));      // <= 255 w: the multiply below needs no mask
         }
         wave_lds_fence();       // (the next row's stores stay behind these reads)
         // 3. vertical pass: source row y spans [256 y, 256 y + 256), destination row j [h j, h j + h)
@@ -1104,7 +1187,7 @@ __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ l
         }
         y++;
 #pragma unroll
-        for (int s = 0; s < SP; s++) {
+        for (int s = 0; s < SU; s++) {
             cur[s] = nxt[0][s];
 #pragma unroll
             for (int p = 0; p + 1 < PF; p++) nxt[p][s] = nxt[p + 1][s];
@@ -1119,7 +1202,7 @@ __host__ __device__ constexpr uint32_t any_class(int bppc, bool aligned, int spc
 // Three kernels, so that each gets the registers and the LDS ITS frames need: GROUP 0 = rows of up to 512 pixels (<= 99
 // VGPRs, 0.5 KiB row buffers), 1 = up to 1024 (<= 121 VGPRs, 1 KiB: still two workgroups per CU), 2 = up to 2048 (one).
 template <int GROUP>
-__global__ __launch_bounds__(kNT) void image_hash_any_kernel(const uint8_t* __restrict__ base, const ImgItem* __restrict__ items,
+__global__ __launch_bounds__(kNT, GROUP == 0 ? UCFP_ANY_WAVES0 : 1) void image_hash_any_kernel(const uint8_t* __restrict__ base, const ImgItem* __restrict__ items,
                                                              ImgItem proto, size_t frame_stride, uint32_t n_items,
                                                              uint32_t algo, const uint8_t* __restrict__ exact,
                                                              uint8_t* __restrict__ out, int32_t* __restrict__ status,
@@ -1134,7 +1217,7 @@ __global__ __launch_bounds__(kNT) void image_hash_any_kernel(const uint8_t* __re
         it.src += (uint64_t)blockIdx.x * frame_stride;
         it.slot = blockIdx.x;
     }
-    uint8_t* lrow = any_lds + ((sizeof(ImageLds) + 15) & ~(size_t)15) + (threadIdx.x >> 6) * any_row_bytes(GROUP);
+    uint8_t* lrow = any_lds + offsetof(ImageLds, cs32) + (threadIdx.x >> 6) * any_row_bytes(GROUP);     // (dead before phase B writes cs32)
     switch (it.cls) {
 #define UCFP_ANY_CASE(BC, BPP, AL)                                                                                     \
     case any_class(BC, AL, 0): if (GROUP == 0) any_phase_a<BPP, 1, AL>(L, lrow, it, base, lo, hi); break;             \
@@ -1319,14 +1402,16 @@ int launch_image_hash(uint32_t algo, const uint8_t* frames, size_t n, uint32_t w
 }
 
 // ---- the fused any-geometry path: planning (host) and launch ----------------------------------------------------------
-// Zero records + status for the frames a ragged batch rejects (geometry guards), by slot.
-__global__ void image_reject_list_kernel(const uint32_t* __restrict__ slots, uint32_t n, uint8_t* __restrict__ out, uint32_t rec,
+// Zero records + a given status for the frames of a ragged batch that are not hashed (geometry guards; uploads the device
+// does not decode): entries of (slot, status).
+__global__ void image_preset_list_kernel(const uint32_t* __restrict__ entries, uint32_t n, uint8_t* __restrict__ out, uint32_t rec,
                                          int32_t* __restrict__ status) {
     const uint32_t i = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
     if (i >= n) return;
-    const uint32_t slot = slots[i], lane = threadIdx.x & 63u;
-    for (uint32_t b = lane * 4; b < rec; b += 256) *reinterpret_cast<uint32_t*>(out + (size_t)slot * rec + b) = 0;
-    if (lane == 0 && status) status[slot] = -1;
+    const uint32_t slot = entries[2 * i], lane = threadIdx.x & 63u;
+    if (out)
+        for (uint32_t b = lane * 4; b < rec; b += 256) *reinterpret_cast<uint32_t*>(out + (size_t)slot * rec + b) = 0;
+    if (lane == 0 && status) status[slot] = (int32_t)entries[2 * i + 1];
 }
 
 // Class, magic number and validity of one frame for image_hash_any_kernel.  false: the fused kernel does not take it (rows
@@ -1335,8 +1420,10 @@ bool image_any_plan(const uint8_t* base, uint64_t src, uint32_t w, uint32_t h, s
                     uint32_t* magic, uint32_t* shift) {
     if (w > kAnyMaxWidth || (uint64_t)w * h > kAnyMaxPixels || row_stride > 0xffffffffull) return false;
     if (!any_magic(2u * w * h, magic, shift)) return false;
+    // aligned units: rows start on a dword (16 bytes for RGBA8: dwordx4 of whole pixels); a last unit that hangs over the
+    // row's end reads into the next row or, at the very end of the buffer, falls back to byte loads
     const uintptr_t need = pixfmt == 2 ? 15u : 3u;
-    const bool aligned = w % 4 == 0 && (((uintptr_t)base + src) & need) == 0 && (row_stride & need) == 0;
+    const bool aligned = (((uintptr_t)base + src) & need) == 0 && (row_stride & need) == 0;
     const uint32_t strips = (w + 3) / 4;
     const int spc = strips <= 64 ? 0 : strips <= 128 ? 1 : strips <= 256 ? 2 : 3;
     *cls = any_class(pixfmt, aligned, spc);
@@ -1357,7 +1444,10 @@ int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_item
                           size_t frame_stride, const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out,
                           int32_t* status, hipStream_t stream) {
     if (n == 0) return 0;
-    auto lds_of = [](int g) { return ((sizeof(ImageLds) + 15) & ~(size_t)15) + (size_t)kNW * any_row_bytes(g); };
+    auto lds_of = [](int g) {
+        const size_t rows = (size_t)kNW * any_row_bytes(g);
+        return offsetof(ImageLds, cs32) + (rows > sizeof(ImageLds::cs32) ? rows : sizeof(ImageLds::cs32));
+    };
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(image_hash_any_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(0));
@@ -1379,9 +1469,9 @@ int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_item
     return 0;
 }
 
-int launch_image_reject_list(const uint32_t* d_slots, size_t n, uint8_t* out, uint32_t rec, int32_t* status, hipStream_t stream) {
+int launch_image_preset_list(const uint32_t* d_entries, size_t n, uint8_t* out, uint32_t rec, int32_t* status, hipStream_t stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(image_reject_list_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_slots, (uint32_t)n, out, rec,
+    hipLaunchKernelGGL(image_preset_list_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_entries, (uint32_t)n, out, rec,
                        status);
     return 0;
 }

@@ -983,7 +983,6 @@ static size_t jpeg_ws_layout(size_t n, size_t jpg_bytes, size_t seg_words, size_
     l->seg = take(seg_words * 4);
     l->qtab = take(n * 64 * 2);
     l->coef = take(coef_words * 2);
-    l->first = take((n + 1) * 4);
     l->total = off;
     return off;
 }
@@ -1059,12 +1058,11 @@ int launch_jpeg_decode(const uint8_t* jpg, const uint64_t* offsets, size_t n, ui
     return jpeg_decode_launches(jpg, offsets, nullptr, uni, n, nullptr, groups, n * (size_t)groups, ws, l, frames, status, stream);
 }
 
-// d_first: n + 1 device words at ws + l.first, written by the caller (host table): first workgroup of every entry's inverse DCT
-int launch_jpeg_decode_ragged(const uint8_t* jpg, const uint64_t* offsets, const UpItem* d_items, size_t n, size_t idct_groups,
-                              uint8_t* ws, const JpegWs& l, uint8_t* frames, int32_t* status, hipStream_t stream) {
+// d_first: n + 1 device words (host table): first workgroup of every entry's inverse DCT, d_first[n] = idct_groups
+int launch_jpeg_decode_ragged(const uint8_t* jpg, const uint64_t* offsets, const UpItem* d_items, size_t n, const uint32_t* d_first,
+                              size_t idct_groups, uint8_t* ws, const JpegWs& l, uint8_t* frames, int32_t* status, hipStream_t stream) {
     if (n == 0) return 0;
-    return jpeg_decode_launches(jpg, offsets, d_items, UpUniform{}, n, reinterpret_cast<const uint32_t*>(ws + l.first), 0, idct_groups,
-                                ws, l, frames, status, stream);
+    return jpeg_decode_launches(jpg, offsets, d_items, UpUniform{}, n, d_first, 0, idct_groups, ws, l, frames, status, stream);
 }
 
 int launch_jpeg_merge_status(const uint8_t* ws, const JpegWs& l, size_t n, uint8_t* out, uint32_t rec, int32_t* status,

@@ -241,6 +241,138 @@ def fingerprint_pngs(pngs: Sequence[bytes], width: int, height: int, pixfmt: int
     return d_out[:n].cpu().numpy(), d_st[:n].cpu().numpy()
 
 
+# ---- uploads of any kind and size in one batch (ucfp_image_probe / ucfp_image_upload_*; upload.hip) ----
+UPLOAD_OTHER, UPLOAD_PNG, UPLOAD_JPEG = 0, 1, 2
+
+
+def probe(data: bytes) -> "_lib.UploadInfo":
+    """What an upload is, from its first bytes: .format (UPLOAD_*), .status (0: the device decodes it; NEEDS_HOST; < 0: no
+    image), .width / .height / .pixfmt of the frame it decodes to."""
+    info = _lib.UploadInfo()
+    _lib.load().ucfp_image_probe(data, len(data), C.byref(info))
+    return info
+
+
+def _probe_all(files: Sequence[bytes]):
+    arr = (_lib.UploadInfo * max(len(files), 1))()
+    lib = _lib.load()
+    for i, f in enumerate(files):
+        lib.ucfp_image_probe(f, len(f), C.byref(arr[i]))
+    return arr
+
+
+def decode_uploads(files: Sequence[bytes], ctx=None):
+    """Decode a batch of PNG / JPEG files of ANY sizes on the GPU -> (list of frames, status int32 [n]); frame i is uint8
+    [h, w] or [h, w, c] (a JPEG: its luma plane), None where status[i] != 0."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    dev = f"cuda:{ctx.device}"
+    n = len(files)
+    if n == 0:
+        return [], np.zeros(0, np.int32)
+    info = _probe_all(files)
+    lib = _lib.load()
+    need = int(lib.ucfp_image_upload_frames_bytes(info, n))
+    d_blob, d_off, total = _upload_pngs(files, dev)
+    d_fr = torch.zeros(need + 64, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    items = (_lib.ImageItem * n)()
+    _lib.check(lib.ucfp_image_upload_decode_batch_dev(ctx.handle, d_blob.data_ptr(), d_off.data_ptr(), n, total, info,
+                                                      d_fr.data_ptr(), need, items, d_st.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream or None))
+    st = d_st.cpu().numpy()
+    buf = d_fr.cpu().numpy()
+    out = []
+    for i in range(n):
+        it = items[i]
+        if st[i] != 0 or it.width == 0:
+            out.append(None)
+            continue
+        bpp = _BPP[it.pixfmt]
+        rows = np.lib.stride_tricks.as_strided(buf[it.offset:], shape=(it.height, it.width * bpp), strides=(it.row_stride, 1))
+        fr = np.ascontiguousarray(rows)
+        out.append(fr if bpp == 1 else fr.reshape(it.height, it.width, bpp))
+    return out, st
+
+
+def fingerprint_uploads_dev(blob_ptr: int, offsets_ptr: int, n: int, blob_bytes: int, info, *, algo: int = MULTI,
+                            exact_ptr: int = 0, out_ptr: int, status_ptr: int = 0, stream: int = 0,
+                            preprocess: Optional[PreprocessConfig] = None, ctx=None) -> None:
+    """Device-resident encoded uploads of any kinds and sizes -> records (ucfp_image_upload_hash_batch_dev).  info: the
+    UploadInfo array of `probe` results, or None: probed on the device (one synchronisation inside the call)."""
+    ctx = ctx or _lib.current_context()
+    pre = (preprocess or PreprocessConfig())._c()
+    _lib.check(_lib.load().ucfp_image_upload_hash_batch_dev(ctx.handle, algo, blob_ptr, offsets_ptr, n, blob_bytes, info,
+                                                            C.byref(pre), exact_ptr or None, out_ptr, status_ptr or None,
+                                                            stream or None))
+
+
+def fingerprint_uploads(files: Sequence[bytes], *, algo: int = MULTI, exact: Optional[np.ndarray] = None,
+                        preprocess: Optional[PreprocessConfig] = None, probe_on_device: bool = False, ctx=None):
+    """Host convenience: encoded uploads (PNG, JPEG, anything) -> (records uint8 [n, record_bytes], status int32 [n]);
+    status NEEDS_HOST: decode that upload on the host (`fingerprint_with`)."""
+    import torch
+    ctx = ctx or _lib.current_context()
+    dev = f"cuda:{ctx.device}"
+    n = len(files)
+    rec = record_bytes(algo)
+    if n == 0:
+        return np.zeros((0, rec), np.uint8), np.zeros(0, np.int32)
+    d_blob, d_off, total = _upload_pngs(files, dev)
+    d_out = torch.zeros((n, rec), dtype=torch.uint8, device=dev)
+    d_st = torch.full((n,), 77, dtype=torch.int32, device=dev)
+    d_ex = None
+    if exact is not None:
+        ex = np.ascontiguousarray(exact, dtype=np.uint8)
+        if ex.shape != (n, 32):
+            raise ModalityError("exact must be [n, 32] bytes")
+        d_ex = torch.from_numpy(ex).to(dev)
+    fingerprint_uploads_dev(d_blob.data_ptr(), d_off.data_ptr(), n, total, None if probe_on_device else _probe_all(files),
+                            algo=algo, exact_ptr=d_ex.data_ptr() if d_ex is not None else 0, out_ptr=d_out.data_ptr(),
+                            status_ptr=d_st.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, preprocess=preprocess,
+                            ctx=ctx)
+    return d_out.cpu().numpy(), d_st.cpu().numpy()
+
+
+class UploadBatcher:
+    """Host micro-batcher for uploads of ANY kind and size (ucfp_upload_batcher_*): request threads `submit` encoded bytes --
+    PNG, JPEG, anything; nothing is announced at creation -- and the library coalesces what the device decodes into one
+    copy + decode + ragged hash per flush.  status NEEDS_HOST: decode that upload on the host (`fingerprint_with`)."""
+
+    def __init__(self, *, algo: int = MULTI, max_batch: int = 1024, max_bytes: int = 256 << 20, max_delay_us: int = 0,
+                 preprocess: Optional[PreprocessConfig] = None, ctx=None):
+        self._lib = _lib.load()
+        self.ctx = ctx or _lib.current_context()
+        self.rec = record_bytes(algo)
+        pre = (preprocess or PreprocessConfig())._c()
+        h = C.c_void_p()
+        _lib.check(self._lib.ucfp_upload_batcher_create(self.ctx.handle, algo, C.byref(pre), max_batch, max_bytes, max_delay_us,
+                                                        C.byref(h)))
+        self.handle = h
+
+    def submit(self, data: bytes):
+        out = (C.c_uint8 * self.rec)()
+        st = C.c_int32(0)
+        _lib.check(self._lib.ucfp_upload_batcher_submit(self.handle, data, len(data), out, C.byref(st)))
+        return bytes(out), int(st.value)
+
+    def stats(self):
+        b, i = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.ucfp_upload_batcher_stats(self.handle, C.byref(b), C.byref(i)))
+        return int(b.value), int(i.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_upload_batcher_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def JpegBatcher(width: int, height: int, **kw):
     """Micro-batcher for JPEG uploads of one announced geometry (records of the files' luma planes, DESIGN J1)."""
     return PngBatcher(width, height, PIX_GRAY8, jpeg=True, **kw)

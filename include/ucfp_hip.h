@@ -486,6 +486,22 @@ int ucfp_index_search_dev(ucfp_index* idx, uint32_t tenant, const void* d_querie
                           uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_dist,
                           uint32_t* d_out_counts, void* stream);
 
+/* Host micro-batcher for the QUERY route: /v1/query is one query per request (src/server/handlers.rs:143-187),
+ * up to 512 requests in flight (src/bin/ucfp.rs:267).  submit() is BLOCKING and thread-safe: concurrent calls -- each with
+ * ITS OWN query (a u64 hash, or dim floats) and ITS OWN k (QueryRequest.k, src/server/dto.rs:74-87) -- become ONE copy of the
+ * queries + ONE ucfp_index_search_dev with the largest k of the batch + one copy of the results; a request gets the first k
+ * entries of its row (the order is total: (distance, id) / (score desc, id)).  One batcher per (index, tenant); at most
+ * max_batch (<= 4096) queries per flush, flushed no later than max_delay_us after the first pending query.
+ *   out_ids / out_scores / out_dist   k entries each (scores, dist may be NULL); places past *out_count carry
+ *                                     UCFP_INVALID_ID / -1 / 2^32 - 1 like ucfp_index_search. */
+typedef struct ucfp_search_batcher ucfp_search_batcher;
+int ucfp_index_search_batcher_create(ucfp_index* idx, uint32_t tenant, size_t max_batch, uint32_t max_delay_us,
+                                     ucfp_search_batcher** out);
+void ucfp_index_search_batcher_destroy(ucfp_search_batcher* b);
+int ucfp_index_search_batcher_submit(ucfp_search_batcher* b, const void* query, uint32_t k, uint64_t* out_ids, float* out_scores,
+                                     uint32_t* out_dist, uint32_t* out_count);
+int ucfp_index_search_batcher_stats(ucfp_search_batcher* b, uint64_t* batches, uint64_t* items);
+
 /* Final step of a sharded search: merge `parts` per-shard top-k lists -- the
  * all-gathered [parts][nq][k] ids + keys -- into one. Keys: Hamming distance (kind
  * HAMMING64) or the order-preserving u32 image of -score (COSINE_F32) as produced by

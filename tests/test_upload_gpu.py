@@ -27,7 +27,7 @@ def _mixed_files(rng, n):
     for i in range(n):
         h, w = int(rng.integers(32, 420)), int(rng.integers(32, 520))
         if i % 11 == 0:
-            w = int(rng.integers(520, 1300))
+            w, h = int(rng.integers(520, 1300)), int(rng.integers(32, 200))     # (a PNG's scanlines stay under the upload path's 1 MiB)
         img = picture(h, w, seed=int(rng.integers(1 << 30)))
         kind = i % 9
         if kind == 0:
@@ -85,6 +85,10 @@ def test_probe_tells_kind_geometry_and_who_decodes(gpu_ctx):
     assert image.probe(jpeg_of(img, progressive=True)).status == image.NEEDS_HOST
     assert image.probe(_png(np.zeros((8, 8), np.uint16))).status == image.NEEDS_HOST            # 16-bit PNG
     assert image.probe(b"\x89PNG\r\n\x1a\n" + bytes(40)).status < 0
+    # a PNG of more than 1 MiB of scanlines is the host's (one wave inflates a file: ~33 MB/s); the same picture as JPEG is not
+    big = picture(700, 700)
+    assert image.probe(_png(big, "RGB")).status == image.NEEDS_HOST
+    assert image.probe(jpeg_of(big, quality=80)).status == 0
 
 
 def test_mixed_uploads_decode_to_the_host_decoders_pixels(gpu_ctx):

@@ -118,6 +118,11 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_index_search_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ucfp_index_search_batcher_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ucfp_index_search_batcher_destroy": (None, [C.c_void_p]),
+    "ucfp_index_search_batcher_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.POINTER(C.c_uint32)]),
+    "ucfp_index_search_batcher_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ucfp_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t,
                                       C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ucfp_topk_pack_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -151,7 +151,7 @@ int launch_hamming_scores(const uint32_t* dist, size_t total, float* scores, hip
 // hamming_direct.hip: 1..8 queries, k <= 32, ONE launch (the request shape of /v1/query).  `state` =
 // hamming_direct_state_bytes() of device memory whose first kHammingDirectZeroBytes were zeroed once (the kernel leaves
 // them zero).
-constexpr uint32_t kHammingDirectMaxQ = 8, kHammingDirectMaxK = 32, kHammingDirectZeroBytes = 8192;
+constexpr uint32_t kHammingDirectMaxQ = 8, kHammingDirectMaxK = 32, kHammingDirectZeroBytes = 12288;
 bool hamming_direct_ok(size_t n, uint32_t nq, uint32_t k);
 size_t hamming_direct_state_bytes();
 int launch_hamming_direct(const uint64_t* codes, const uint64_t* ids, size_t n, const uint64_t* queries, uint32_t nq,

@@ -850,7 +850,11 @@ constexpr int kFewQueries = 64;   // most queries the lane-per-code scan takes (
 // matrix filter ~0.15 ms (10 M codes) .. 0.37 ms (100 M) nearly flat up to 100 queries (its longer chain of launches:
 // query image, rescans): measured crossovers 40 queries at 10 M codes, 20 at 100 M (tools/bench_hamming.py).
 static bool few_queries(size_t n, uint32_t nq) {
-    const uint32_t most = n >= (size_t)50'000'000 ? 20u : n >= (size_t)5'000'000 ? 40u : (uint32_t)kFewQueries;
+    // (round 4, 12.5 M codes, us per search lanes | matrix filter: 9 queries 79 | 90, 16: 92 | 89, 32: 124 | 90 -- the bound pass
+    // of round 3 made the matrix filter's chain shorter, so it takes over earlier than the 40 measured in round 2)
+    uint32_t most = n >= (size_t)50'000'000 ? 12u : n >= (size_t)5'000'000 ? 12u : (uint32_t)kFewQueries;
+    static const char* ov = getenv("UCFP_HAMMING_FEW");          // (tuning)
+    if (ov) most = (uint32_t)atoi(ov);
     return nq <= most;
 }
 
@@ -1161,7 +1165,11 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
         // 4 is fastest everywhere -- tighter thresholds mean fewer suspect blocks to rescan than a stage costs; the same
         // for batches of 9 .. 256 queries, where 16x measured 5-20 % slower)
-        constexpr size_t growth = 4;
+        // ... and 8 for batches of up to 256 queries, whose searches are chains of short launches (round 4, 12.5 M codes:
+        // 16 / 64 / 128 queries 99 / 110 / 124 us at 4, 89 / 99 / 116 at 8, 91 / 101 / 116 at 16)
+        size_t growth = nq <= 256 ? 8 : 4;
+        static const char* gs = getenv("UCFP_HAMMING_GROWTH_SMALL");   // (tuning)
+        if (gs && nq <= 256) growth = (size_t)atoi(gs);
         // (with the bound pass the first stage starts over at row 0, so there is one even when bound_n == n)
         do {
             e = e * growth < n ? e * growth : n;

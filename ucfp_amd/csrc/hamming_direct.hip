@@ -65,12 +65,13 @@ struct DirView {
     uint32_t* dstar;   // [8]
     uint32_t* ticket;  // [1]
     uint32_t* pend;    // [8][80]  histogram counts not yet moved to the global histogram
+    uint32_t* h0;      // [8][80]  histogram of the first trips' LANE MINIMA (the workgroup's first bound; never the exact one)
     uint64_t* s_id;    // [nq][kDSel]     the entries a merge selects from: id ...
     uint32_t* s_d;     // [nq][kDSel]     ... and distance
     uint32_t* l_d;     // [nq][16][64]    wave lists: distance ...
     uint32_t* l_row;   // [nq][16][64]    ... and row
 };
-constexpr size_t kDirFixed = 4784 + 2560;
+constexpr size_t kDirFixed = 4784 + 2560 + 2560;
 constexpr size_t kDirPerQuery = (size_t)kDSel * 12 + (size_t)kDW * kDCap * 8;
 
 __device__ __forceinline__ DirView dir_view(uint8_t* base, uint32_t nq) {
@@ -85,6 +86,7 @@ __device__ __forceinline__ DirView dir_view(uint8_t* base, uint32_t nq) {
     V.dstar = reinterpret_cast<uint32_t*>(base + 4736);
     V.ticket = reinterpret_cast<uint32_t*>(base + 4768);
     V.pend = reinterpret_cast<uint32_t*>(base + 4784);
+    V.h0 = reinterpret_cast<uint32_t*>(base + 4784 + 2560);
     V.s_id = reinterpret_cast<uint64_t*>(base + kDirFixed);
     V.s_d = reinterpret_cast<uint32_t*>(base + kDirFixed + (size_t)nq * kDSel * 8);
     V.l_d = reinterpret_cast<uint32_t*>(base + kDirFixed + (size_t)nq * kDSel * 12);
@@ -154,17 +156,22 @@ __device__ __noinline__ void dir_prune(uint8_t* lds_base, uint32_t nq, const uin
     }
 }
 
-// k-th smallest bin of a 65-bin histogram in LDS (64 when fewer than k entries were counted)
-__device__ __forceinline__ uint32_t dir_kth_bin(const uint32_t* hist, uint32_t k, int lane) {
-    uint32_t incl = hist[lane];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    const uint64_t mask = __ballot(incl >= k);
+// inclusive scan over the wave by DPP (row shifts, then the row totals passed on): six VALU instructions, no LDS round trips
+__device__ __forceinline__ uint32_t dir_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// k-th smallest bin of a 65-bin histogram, one bin per lane (64 when fewer than k entries were counted)
+__device__ __forceinline__ uint32_t dir_kth_of(uint32_t count_of_lane, uint32_t k) {
+    const uint64_t mask = __ballot(dir_scan(count_of_lane) >= k);
     return mask ? (uint32_t)__builtin_ctzll(mask) : 64u;
 }
+__device__ __forceinline__ uint32_t dir_kth_bin(const uint32_t* hist, uint32_t k, int lane) { return dir_kth_of(hist[lane], k); }
 
 // Wave-synchronous: the best min(m, k) of m entries by (d, id), emitted in order.  get(c) -> entry c.
 template <class Get, class Emit>
@@ -243,7 +250,7 @@ template <int NQ>
 __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
     const uint64_t* __restrict__ codes, const uint64_t* __restrict__ ids, size_t n, const uint64_t* __restrict__ queries,
     uint32_t nq, uint32_t k, const uint32_t* __restrict__ ids_ascending, uint32_t* wg_d, uint64_t* wg_id, uint32_t* counter,
-    uint32_t* ghist, uint32_t* tctr, uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_d, float* __restrict__ out_scores,
+    uint32_t* ghist, uint32_t* ghist2, uint32_t* tctr, uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_d, float* __restrict__ out_scores,
     uint32_t* __restrict__ out_cnt, uint64_t* prof) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dir_lds[];
     DIR_STAMP(0);
@@ -262,6 +269,7 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
     // of a 100 M-code search serialised at ~5 ns each -- 1.1 ms.
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const size_t ntrips = (n + kDTrip - 1) / kDTrip;
+    const uint32_t G0 = gridDim.x;
     const bool dyn = NQ == 8 && tctr != nullptr && gridDim.x == 256u && ntrips >= (size_t)4 * 256 * kDW;
     const size_t region = dyn ? (ntrips + 31) / 32 : ntrips;
     const uint32_t grp = dyn ? blockIdx.x >> 3 : 0u;
@@ -297,6 +305,7 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
     for (uint32_t i = threadIdx.x; i < nq * 80; i += kDW * 64) {
         V.hist[i] = 0u;
         V.pend[i] = 0u;
+        V.h0[i] = 0u;
     }
     if (threadIdx.x < nq * kDW) {
         V.wcnt[threadIdx.x] = 0u;
@@ -333,12 +342,50 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
         if (pv) __hip_atomic_fetch_add(ghist + j * 80 + lane, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    // ---- the first bound.  The bound starts at 64, where every code is a candidate -- 512 of them per wave and query through a
+    // listing path built for the rare one (PMC, round 3's kernel, 8 queries over 12.5 M codes = six trips per wave: 1250
+    // vector instructions per trip on average against ~350 for the distances).  So, before anything is listed: every wave takes
+    // the minimum distance each LANE sees in its first trip (64 different codes per wave and query), the workgroup histograms
+    // its up to 1024 minima, and the k-th smallest of them bounds the k-th distance (any k of those codes witness it).  The same
+    // histogram goes to a second global histogram (ghist2: never the exact one -- these codes are counted again when the stream
+    // evaluates them), which every workgroup reads back at its second trip: the k-th smallest of ~260 k minima from all over
+    // the corpus is within a bit or two of the final k-th distance, where a workgroup's own bound settles ~6 bits above it (a
+    // candidate in every other trip and query).  Nobody waits for anybody: what has been published by then bounds just as well.
+    {
+        const bool whole = first < t_hi && first * kDTrip + kDTrip <= n;      // (codes past the end read as 0: no witnesses)
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            if ((uint32_t)j < nq && whole) {
+                uint32_t best = 64;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t d = (uint32_t)__builtin_popcount((uint32_t)cn[u] ^ qlo[j]) +
+                                       (uint32_t)__builtin_popcount((uint32_t)(cn[u] >> 32) ^ qhi[j]);
+                    best = d < best ? d : best;
+                }
+                atomicAdd(&V.h0[j * 80 + best], 1u);
+            }
+        }
+        __syncthreads();
+        if (wave < nq) {
+            const uint32_t mine = V.h0[wave * 80 + lane];
+            const uint32_t t0 = dir_kth_of(mine, k);
+            if (lane == 0) V.tau[wave] = t0;                                  // (64 when fewer than k minima were seen)
+            if (mine && G0 > 1) __hip_atomic_fetch_add(ghist2 + wave * 80 + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+
     // ---- the stream
+    uint32_t it = 0;
     size_t tn = first + stride;
     for (size_t t = first; t < t_hi;) {
         uint64_t c[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) c[u] = cn[u];
+        uint32_t gcount = 0;
+        const bool read_now = G0 > 1 && wave < nq && it == 1;
+        if (read_now) gcount = UCFP_AGENT_LOAD(ghist2 + wave * 80 + lane);     // consumed after this trip's distances
         // the trip after next: by position, or what the region's counter answered (the answer came in with c[])
         const size_t t3 = dyn ? t_lo + 2 * stride + (uint32_t)__builtin_amdgcn_readfirstlane((int)ga) : tn + stride;
         load_trip(cn, tn);
@@ -360,6 +407,10 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
                 }
                 if (__any(best <= tj[j])) hits |= 1u << j;
             }
+        }
+        if (read_now) {
+            const uint32_t tg = dir_kth_of(gcount, k);
+            if (lane == 0) atomicMin(&V.tau[wave], tg);
         }
         // ---- rare: some code of this trip may enter the list of query j
         while (hits) {
@@ -441,6 +492,7 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
                 wave_lds_sync();
             }
         }
+        it++;
         t = tn;
         tn = t3;
     }
@@ -513,35 +565,34 @@ __global__ __launch_bounds__(kDW * 64) void hamming_direct_kernel(
     // the final k-th distance d* was counted (each was evaluated against a bound >= d*), so d* is simply its k-th bin.
     // The published entries at or below d* are taken in ONE pass: batches of 8 independent loads per thread.
     const uint32_t E = G * k, total = nq * E;
-    constexpr uint32_t kT = kDW * 64, kB = 8;
+    constexpr uint32_t kT = kDW * 64, kB = 20;      // 20 480 published distances (8 queries x 256 workgroups x k = 10) are ONE round trip
     if (threadIdx.x < nq) V.m[threadIdx.x] = 0;
     // the first batch of published distances is requested BEFORE d* is known (it does not depend on it): the histogram's
-    // round trip and the lists' are one
+    // round trip and the lists' are one.  Loads past the published entries are skipped a whole workgroup at a time (uniform).
     uint32_t v0[kB];
 #pragma unroll
     for (uint32_t u = 0; u < kB; u++) {
-        const uint32_t x = u * kT + threadIdx.x;
-        v0[u] = UCFP_AGENT_LOAD(wg_d + (x < total ? x : 0u));
+        v0[u] = 0xffffffffu;
+        if (u * kT < total) {
+            const uint32_t x = u * kT + threadIdx.x;
+            v0[u] = UCFP_AGENT_LOAD(wg_d + (x < total ? x : 0u));
+        }
     }
     if (wave < nq) {
-        uint32_t incl = UCFP_AGENT_LOAD(ghist + wave * 80 + lane);
+        const uint32_t cnt_l = UCFP_AGENT_LOAD(ghist + wave * 80 + lane);
         UCFP_AGENT_STORE(ghist + wave * 80 + lane, 0u);          // zero again for the next launch (bin 64 is never written)
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        const uint64_t mk = __ballot(incl >= k);
-        if (lane == 0) V.dstar[wave] = mk ? (uint32_t)__builtin_ctzll(mk) : 64u;
+        UCFP_AGENT_STORE(ghist2 + wave * 80 + lane, 0u);
+        const uint32_t ds = dir_kth_of(cnt_l, k);
+        if (lane == 0) V.dstar[wave] = ds;
     }
     __syncthreads();
     for (uint32_t b0 = 0; b0 < total; b0 += kT * kB) {
         uint32_t v[kB], pos[kB];
         uint64_t w[kB];
 #pragma unroll
-        for (uint32_t u = 0; u < kB; u++) {      // unconditional, so that the eight loads are ONE round trip
+        for (uint32_t u = 0; u < kB; u++) {      // unconditional within a batch row, so that the loads are ONE round trip
             const uint32_t x = b0 + u * kT + threadIdx.x;
-            v[u] = b0 == 0 ? v0[u] : UCFP_AGENT_LOAD(wg_d + (x < total ? x : 0u));
+            v[u] = b0 == 0 ? v0[u] : (b0 + u * kT < total ? UCFP_AGENT_LOAD(wg_d + (x < total ? x : 0u)) : 0xffffffffu);
         }
 #pragma unroll
         for (uint32_t u = 0; u < kB; u++) {
@@ -617,10 +668,11 @@ int launch_hamming_direct(const uint64_t* codes, const uint64_t* ids, size_t n, 
     if (G > 256) G = 256;
     if (G < 1) G = 1;
     const size_t lds = kDirFixed + (size_t)nq * kDirPerQuery;
-    static_assert(kHammingDirectZeroBytes >= 4096 + 32 * 128 && 4096 >= 256 + kHammingDirectMaxQ * 80 * 4,
-                  "ticket + histogram + 32 trip counters, each on a cache line of its own");
+    static_assert(kHammingDirectZeroBytes >= 8192 + kHammingDirectMaxQ * 80 * 4 && 4096 >= 256 + kHammingDirectMaxQ * 80 * 4,
+                  "ticket + histogram + 32 trip counters, each on a cache line of its own, + the histogram of first-trip minima");
     uint32_t* counter = reinterpret_cast<uint32_t*>(state);
     uint32_t* ghist = reinterpret_cast<uint32_t*>(state + 256);
+    uint32_t* ghist2 = reinterpret_cast<uint32_t*>(state + 8192);
     static const bool fixed_shares = getenv("UCFP_DIRECT_STATIC") != nullptr;      // A/B switch of the trip counters
     uint32_t* tctr = fixed_shares ? nullptr : reinterpret_cast<uint32_t*>(state + 4096);
     uint8_t* lists = state + kHammingDirectZeroBytes;
@@ -634,7 +686,7 @@ int launch_hamming_direct(const uint64_t* codes, const uint64_t* ids, size_t n, 
             attr_set[nqt] = true;
         }
         hipLaunchKernelGGL(kernel, dim3(G), dim3(kDW * 64), lds, stream, codes, ids, n, queries, nq, k, ids_ascending, wg_d,
-                           wg_id, counter, ghist, tctr, out_ids, out_dist, out_scores, out_cnt,
+                           wg_id, counter, ghist, ghist2, tctr, out_ids, out_dist, out_scores, out_cnt,
                            reinterpret_cast<uint64_t*>(lists + (size_t)kHammingDirectMaxQ * 256 * kHammingDirectMaxK * 12));
     };
     if (nq == 1) go(hamming_direct_kernel<1>, 1);

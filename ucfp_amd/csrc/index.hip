@@ -127,6 +127,7 @@ struct ucfp_index {
 namespace ucfp {
 int index_kind(const ucfp_index* ix) { return ix->kind; }
 int index_device(const ucfp_index* ix) { return ix->device; }
+uint32_t index_dim(const ucfp_index* ix) { return ix->dim; }
 }  // namespace ucfp
 
 namespace {

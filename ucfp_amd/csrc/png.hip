@@ -807,6 +807,18 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
             int nvalid = 0;
             PROF_ADD(1);  // stage
             PROF_CNT(9, 1);
+#ifndef UCFP_PNG_NO_WARMUP
+            // Warm-up (round 4).  A lane's guess j B is almost never a code boundary, so its first parse is wrong at the start and
+            // only its EXIT is (usually) right; the lane behind it then needs a second parse from that exit, and a third when its
+            // predecessor had not fallen into step within B bits: 4.3 parses per subsequence at level 1.  Instead every lane first
+            // runs through its PREDECESSOR's subsequence, from that one's guess: by the time it reaches its own first bit it is in
+            // step (or the chain below repairs it), and its counted parse starts on a true boundary -- the chain then mostly
+            // confirms what is there.  One uncounted parse of B bits buys back two counted ones.
+            {
+                const Parse W = parse_sub<false, C>(L, lane > 0 ? vbase - (uint32_t)B : vbase, vbase, 0, 0, 0);   // (lane 0 knows its start)
+                if (lane > 0 && !W.stopped()) start = W.exit;
+            }
+#endif
             for (;;) {
                 // the lane before stopped short of its limit (an end-of-block or an invalid code, real or in a parse
                 // from a wrong start): nothing to continue here

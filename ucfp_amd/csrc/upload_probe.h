@@ -58,12 +58,18 @@ __host__ __device__ inline int jpeg_probe_bytes(const uint8_t* jpg, size_t len, 
     }
 }
 
+// A PNG is inflated by ONE wave, serially in its bit stream (png.hip): ~33 MB/s of scanlines per file, whatever the batch --
+// a batch of uploads takes as long as its largest PNG.  Up to this many scanline bytes (about 590 x 590 RGB: ~30 ms) the
+// device's aggregate rate (150-220 k files/s over a full batch) is worth that latency; a larger PNG goes to the host, whose
+// zlib inflates it ten times faster than one wave does.  (The uniform-geometry PNG entry points have no such limit.)
+constexpr size_t kUploadPngMaxRawBytes = (size_t)1 << 20;
+
 // what the device decoders take of an upload of this geometry (beyond it: the host's decoder)
 __host__ __device__ inline bool upload_device_decodes(int format, uint32_t w, uint32_t h, int pixfmt) {
     if (w == 0 || h == 0 || w > 16384 || h > 16384) return false;
     if (format == UCFP_UPLOAD_PNG) {
         const size_t bpp = pixfmt == UCFP_PIX_GRAY8 ? 2 : pixfmt == UCFP_PIX_RGB8 ? 3 : 4;      // (a grey + alpha file: 2 bytes per pixel)
-        if ((size_t)h * ((size_t)w * bpp + 1) >= ((size_t)1 << 31)) return false;               // the inflate kernel's 32-bit positions
+        if ((size_t)h * ((size_t)w * bpp + 1) > kUploadPngMaxRawBytes) return false;
         if ((size_t)w * bpp > 60000) return false;                                              // the unfilter kernel's row buffer
     }
     return true;

@@ -27,6 +27,51 @@ MAX_K = 128
 INVALID_ID = 0xFFFFFFFFFFFFFFFF
 
 
+class SearchBatcher:
+    """Host micro-batcher for the query route (ucfp_index_search_batcher_*): request threads `submit` ONE query each (their
+    own k); the library coalesces them into one search launch per flush.  /v1/query is one query per request
+    (src/server/handlers.rs:143-187), up to 512 in flight (src/bin/ucfp.rs:267)."""
+
+    def __init__(self, index: "DeviceIndex", tenant: int = 0, *, max_batch: int = 256, max_delay_us: int = 0):
+        self._lib = _lib.load()
+        self.index = index
+        h = C.c_void_p()
+        _lib.check(self._lib.ucfp_index_search_batcher_create(index.handle, tenant, max_batch, max_delay_us, C.byref(h)))
+        self.handle = h
+
+    def submit(self, query, k: int):
+        """query: int (64-bit hash) or float32 [dim].  -> (ids u64 [n], scores f32 [n], dist u32 [n]) with n <= k hits."""
+        if self.index.kind == HAMMING64:
+            q = np.array([query], dtype=np.uint64)
+        else:
+            q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.index.dim)
+        kk = max(int(k), 1)
+        ids = np.empty(kk, np.uint64)
+        sc = np.empty(kk, np.float32)
+        d = np.empty(kk, np.uint32)
+        cnt = C.c_uint32(0)
+        _lib.check(self._lib.ucfp_index_search_batcher_submit(self.handle, q.ctypes.data, int(k), ids.ctypes.data, sc.ctypes.data,
+                                                              d.ctypes.data, C.byref(cnt)))
+        n = int(cnt.value)
+        return ids[:n], sc[:n], d[:n]
+
+    def stats(self):
+        b, i = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.ucfp_index_search_batcher_stats(self.handle, C.byref(b), C.byref(i)))
+        return int(b.value), int(i.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ucfp_index_search_batcher_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceIndex:
     """Thin RAII wrapper over one ucfp_index handle (one kind, one dim)."""
 

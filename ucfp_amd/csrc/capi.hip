@@ -45,6 +45,22 @@ constexpr size_t kNormWsFrames = 2048;  // generic-geometry normalised planes he
 
 namespace ucfp {
 int ctx_device(const ucfp_ctx* ctx) { return ctx->device; }
+int image_any_geometry_ready(ucfp_ctx* ctx, uint32_t w) {
+    if (w > 2048) return (int)hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(ctx->geo_mu);
+    if (ctx->geo_have[w >> 6] >> (w & 63) & 1) return 0;
+    const size_t tb = image_any_geometry_bytes();
+    if (!ctx->geo) {
+        hipError_t e = hipMalloc((void**)&ctx->geo, 2049 * tb);
+        if (e != hipSuccess) return (int)e;
+    }
+    std::vector<uint32_t> tab(tb / 4);
+    image_any_geometry_table(w, tab.data());
+    hipError_t e = hipMemcpy(reinterpret_cast<uint8_t*>(ctx->geo) + (size_t)w * tb, tab.data(), tb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+    ctx->geo_have[w >> 6] |= 1ull << (w & 63);
+    return 0;
+}
 // Every image launch of the library goes through here.  The fused kernels touch no shared state; a geometry that
 // normalises into ctx->norm_ws first waits (on `stream`) for the previous user of that workspace -- whatever stream
 // it ran on -- and leaves its own completion event behind.  The caller has already selected ctx->device.
@@ -62,8 +78,10 @@ int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size
     if (n && (size_t)w * h <= ctx->any_max_pixels && image_any_plan(frames, 0, w, h, row_stride, pixfmt, &cls, &magic, &shift)) {
         const size_t bpp = pixfmt == 0 ? 1 : pixfmt == 1 ? 3 : 4;
         const uint8_t* hi = frames + (n - 1) * frame_stride + (size_t)(h - 1) * row_stride + (size_t)w * bpp;
+        const int ge = image_any_geometry_ready(ctx, w);
+        if (ge) return ge;
         launch_image_hash_any(algo, frames, nullptr, n, image_any_group(cls), w, h, (uint32_t)row_stride, cls, magic, shift, frame_stride,
-                              frames, hi, exact, out, status, stream);
+                              frames, hi, exact, out, status, ctx->geo, stream);
         return (int)hipGetLastError();
     }
     std::lock_guard<std::mutex> lk(ctx->norm_mu);
@@ -131,6 +149,7 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->png_ws) (void)hipFree(c->png_ws);
     if (c->b3_ws) (void)hipFree(c->b3_ws);
     if (c->norm_done) (void)hipEventDestroy(c->norm_done);
+    if (c->geo) (void)hipFree(c->geo);
     for (int i = 0; i < 2; i++) {
         if (c->item_h[i]) (void)hipHostFree(c->item_h[i]);
         if (c->item_d[i]) (void)hipFree(c->item_d[i]);

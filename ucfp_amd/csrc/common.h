@@ -39,7 +39,11 @@ void image_any_item_write(void* dst, size_t i, uint64_t src, uint32_t w, uint32_
 int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, int group, uint32_t proto_w,
                           uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_magic, uint32_t proto_shift,
                           size_t frame_stride, const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out,
-                          int32_t* status, hipStream_t stream);
+                          int32_t* status, const uint32_t* d_geo, hipStream_t stream);
+// d_geo: the context's table area, image_any_geometry_bytes() per width, indexed by width (0 .. 2048); a width's table is
+// written once (image_any_geometry_table on the host, copied up) before the first launch that has a frame of that width
+size_t image_any_geometry_bytes();
+void image_any_geometry_table(uint32_t w, uint32_t* tab);
 // (slot, status) pairs: zero record (out may be NULL) + the status for frames that are not hashed
 int launch_image_preset_list(const uint32_t* d_entries, size_t n, uint8_t* out, uint32_t rec, int32_t* status, hipStream_t stream);
 int launch_image_record_codes(const uint8_t* records, size_t n, uint32_t rec_bytes, uint32_t offset, uint64_t* codes,

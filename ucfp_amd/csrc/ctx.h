@@ -49,6 +49,10 @@ struct ucfp_ctx {
     hipEvent_t item_used[2] = {nullptr, nullptr};
     int item_next = 0;
     size_t any_max_pixels = (size_t)1 << 20;   // uniform batches: frames up to this size take the fused any-geometry kernel
+    // column tables of the fused any-geometry kernel, one per width (0 .. 2048), made on first sight of a width
+    std::mutex geo_mu;
+    uint32_t* geo = nullptr;
+    uint64_t geo_have[2049 / 64 + 1] = {0};
 };
 
 
@@ -64,6 +68,8 @@ inline int grow(uint8_t** p, size_t* cap, size_t need) {
     *cap = want;
     return 0;
 }
+// the context's column table of width w is on the device (first sight: built on the host, copied with a BLOCKING copy)
+int image_any_geometry_ready(ucfp_ctx* ctx, uint32_t w);
 int image_hash_ordered(ucfp_ctx* ctx, uint32_t algo, const uint8_t* frames, size_t n, uint32_t w, uint32_t h,
                        size_t row_stride, size_t frame_stride, int pixfmt, uint32_t min_dim, uint32_t max_dim,
                        const uint8_t* exact, uint8_t* out, int32_t* status, hipStream_t stream);

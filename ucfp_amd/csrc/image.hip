@@ -939,6 +939,7 @@ static_assert(sizeof(ImgItem) == 40, "ImgItem is uploaded as raw bytes");
 constexpr uint32_t kAnyMaxWidth = 2048;                // the wave's row buffer: one byte per source pixel
 __host__ __device__ constexpr uint32_t any_row_bytes(int group) { return (512u << group) + 32u; }   // (+ the windows' look-ahead)
 constexpr uint32_t kAnyMaxPixels = (1u << 22) - 1;     // 2 w h < 2^23: the magic number fits 32 bits (any_magic)
+constexpr uint32_t kAnyGeoWords = 256 * 8;             // dwords of one width's column table (8 per destination column)
 
 // Four pixels of a strip -> their lumas as four bytes (spec I1), straight from the raw dwords: a luma is byte 1 of
 // 77 R + 150 G + 29 B + 128 < 2^16, so v_perm_b32 gathers them without shifts.
@@ -977,14 +978,16 @@ typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
 // ALIGNED: the unit starts on a dword (GRAY8, RGB8) / on 16 bytes (RGBA8).  Otherwise it is assembled from the aligned dwords
 // around it (one more dword, v_alignbyte).  Either way a unit whose dwords would reach outside [lo, hi) -- the first of the
 // first row, the last of the last -- is read byte by byte.
-template <int BPP, bool ALIGNED>
+// CHECK = false: the caller has established (once per row, in scalar registers) that every dword of every unit of the row lies
+// inside [lo, hi) -- true for every row but a buffer's first and last -- and the per-lane comparison is not even compiled.
+template <int BPP, bool ALIGNED, bool CHECK>
 __device__ __forceinline__ AnyUnit<BPP> load_any_unit(const uint8_t* __restrict__ p, const uint8_t* lo, const uint8_t* hi) {
     constexpr int NW = AnyUnit<BPP>::NW;
     AnyUnit<BPP> r;
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const uint32_t sh = ALIGNED ? 0u : (uint32_t)(a & 3);
     const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-    if (reinterpret_cast<const uint8_t*>(q) >= lo && reinterpret_cast<const uint8_t*>(q + NW + (ALIGNED ? 0 : 1)) <= hi) {
+    if (!CHECK || (reinterpret_cast<const uint8_t*>(q) >= lo && reinterpret_cast<const uint8_t*>(q + NW + (ALIGNED ? 0 : 1)) <= hi)) {
         uint32_t d[NW + 1];
         if (NW == 3) {
             if (ALIGNED) {
@@ -1064,7 +1067,8 @@ struct RowFold {
 // SP = strips per lane (1, 2, 4, 8: w <= 256 SP); NT = dwords a destination column's window of luma bytes spans at most
 template <int BPP, int SP, bool ALIGNED>
 __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ lrow, const ImgItem& it,
-                                            const uint8_t* __restrict__ base, const uint8_t* lo, const uint8_t* hi) {
+                                            const uint8_t* __restrict__ base, const uint32_t* __restrict__ geo, const uint8_t* lo,
+                                            const uint8_t* hi) {
     constexpr int NT = SP <= 2 ? 1 : SP <= 4 ? 2 : 3;      // windows of <= 4 / 6 / 10 pixels at any byte phase
     // (the wave's number through readfirstlane: the compiler then keeps the row loop's control -- band, source row, overlaps --
     // in scalar registers and branches on SCC; derived from threadIdx alone it ran on the vector unit under exec masks)
@@ -1077,28 +1081,21 @@ __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ l
     const uint32_t D = w * h, magic = it.magic, shift = it.shift;
     constexpr int PF = SP <= 1 ? 6 : SP <= 2 ? 4 : SP <= 4 ? 2 : 1;     // source rows in flight ahead of the one being consumed
     const uint32_t col4 = 4 * t;                          // this lane's four destination columns
-    // horizontal geometry of the lane's columns, fixed for the frame: first dword and byte phase of the window, which of its
-    // bytes are whole pixels (weight 256: `inside`) and the weights of the partly covered ones (`edge`, < 256)
+    // horizontal geometry of the lane's columns, fixed for a WIDTH: first dword and byte phase of the window, which of its
+    // bytes are whole pixels (weight 256: `inside`) and the weights of the partly covered ones (`edge`, < 256) -- from the
+    // width's table (image_any_geometry_table, made on the host once per width: 8 dwords per destination column)
     uint32_t gw[4], gs[4], inside[4][NT], edge[4][NT];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const uint32_t i = col4 + c;
-        const uint32_t di0 = w * i, di1 = di0 + w;
-        const uint32_t xa = di0 >> 8, xb = (di1 - 1) >> 8;
-        gw[c] = xa >> 2;
-        gs[c] = xa & 3u;
+        const uint4* gp = reinterpret_cast<const uint4*>(geo + (size_t)(col4 + c) * 8);
+        const uint4 g0 = gp[0], g1 = gp[1];
+        gw[c] = g0.x & 0xffffu;
+        gs[c] = g0.x >> 16;
+        const uint32_t in3[3] = {g0.y, g0.z, g0.w}, ed3[3] = {g1.x, g1.y, g1.z};
 #pragma unroll
-        for (int k = 0; k < NT; k++) inside[c][k] = edge[c][k] = 0;
-        // byte b of the window is source pixel xa + b; its weight = overlap of [256 x, 256 x + 256) with [di0, di1)
-        for (uint32_t x = xa; x <= xb; x++) {
-            const uint32_t a = 256u * x > di0 ? 256u * x : di0, b = 256u * x + 256u < di1 ? 256u * x + 256u : di1;
-            const uint32_t ov = b - a, pos = x - xa;
-#pragma unroll
-            for (int k = 0; k < NT; k++)
-                if ((pos >> 2) == (uint32_t)k) {
-                    if (ov == 256u) inside[c][k] |= 1u << (8 * (pos & 3u));
-                    else edge[c][k] |= ov << (8 * (pos & 3u));
-                }
+        for (int k = 0; k < NT; k++) {
+            inside[c][k] = in3[k];
+            edge[c][k] = ed3[k];
         }
     }
     uint32_t acc[4] = {0, 0, 0, 0};
@@ -1112,12 +1109,26 @@ __device__ __forceinline__ void any_phase_a(ImageLds& L, uint8_t* __restrict__ l
     Unit cur[SU], nxt[PF][SU];
     auto load_row = [&](Unit (&dst)[SU], uint32_t y) {
         const uint8_t* __restrict__ row = f + (size_t)y * row_stride;
+        // wave-uniform: do all the row's units (whole dwords around them) lie inside the buffer?  Every row but the first and the
+        // last of a buffer: then the lanes load without looking.  (ONE branch around all the row's loads: a branch per unit
+        // kept them from being in flight together -- 640 x 480 RGB 4.5 -> 3.7 TB/s.)
+        const bool inside_buf = row >= lo + 4 && row + (size_t)nunit * UPX * BPP + 4 <= hi;
+        if (inside_buf) {
 #pragma unroll
-        for (int s = 0; s < SU; s++) {
-            if (s == 0 || (uint32_t)(64 * s) < nunit) {      // (wave-uniform: a narrow frame skips the idle rounds)
-                const uint32_t u = s * 64 + t;
-                // units past the row's end re-read its last unit: they are never stored
-                dst[s] = load_any_unit<BPP, ALIGNED>(row + (size_t)(u < nunit ? u : nunit - 1) * UPX * BPP, lo, hi);
+            for (int s = 0; s < SU; s++) {
+                if (s == 0 || (uint32_t)(64 * s) < nunit) {      // (wave-uniform: a narrow frame skips the idle rounds)
+                    const uint32_t u = s * 64 + t;
+                    // units past the row's end re-read its last unit: they are never stored
+                    dst[s] = load_any_unit<BPP, ALIGNED, false>(row + (size_t)(u < nunit ? u : nunit - 1) * UPX * BPP, lo, hi);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < SU; s++) {
+                if (s == 0 || (uint32_t)(64 * s) < nunit) {
+                    const uint32_t u = s * 64 + t;
+                    dst[s] = load_any_unit<BPP, ALIGNED, true>(row + (size_t)(u < nunit ? u : nunit - 1) * UPX * BPP, lo, hi);
+                }
             }
         }
     };
@@ -1206,7 +1217,7 @@ __global__ __launch_bounds__(kNT, GROUP == 0 ? UCFP_ANY_WAVES0 : 1) void image_h
                                                              ImgItem proto, size_t frame_stride, uint32_t n_items,
                                                              uint32_t algo, const uint8_t* __restrict__ exact,
                                                              uint8_t* __restrict__ out, int32_t* __restrict__ status,
-                                                             const uint8_t* lo, const uint8_t* hi) {
+                                                             const uint8_t* lo, const uint8_t* hi, const uint32_t* __restrict__ geo_all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t any_lds[];
     ImageLds& L = *reinterpret_cast<ImageLds*>(any_lds);
     if (blockIdx.x >= n_items) return;
@@ -1218,12 +1229,13 @@ __global__ __launch_bounds__(kNT, GROUP == 0 ? UCFP_ANY_WAVES0 : 1) void image_h
         it.slot = blockIdx.x;
     }
     uint8_t* lrow = any_lds + offsetof(ImageLds, cs32) + (threadIdx.x >> 6) * any_row_bytes(GROUP);     // (dead before phase B writes cs32)
+    const uint32_t* geo = geo_all + (size_t)it.w * kAnyGeoWords;                                       // the width's column table
     switch (it.cls) {
 #define UCFP_ANY_CASE(BC, BPP, AL)                                                                                     \
-    case any_class(BC, AL, 0): if (GROUP == 0) any_phase_a<BPP, 1, AL>(L, lrow, it, base, lo, hi); break;             \
-    case any_class(BC, AL, 1): if (GROUP == 0) any_phase_a<BPP, 2, AL>(L, lrow, it, base, lo, hi); break;             \
-    case any_class(BC, AL, 2): if (GROUP == 1) any_phase_a<BPP, 4, AL>(L, lrow, it, base, lo, hi); break;             \
-    case any_class(BC, AL, 3): if (GROUP == 2) any_phase_a<BPP, 8, AL>(L, lrow, it, base, lo, hi); break;
+    case any_class(BC, AL, 0): if (GROUP == 0) any_phase_a<BPP, 1, AL>(L, lrow, it, base, geo, lo, hi); break;             \
+    case any_class(BC, AL, 1): if (GROUP == 0) any_phase_a<BPP, 2, AL>(L, lrow, it, base, geo, lo, hi); break;             \
+    case any_class(BC, AL, 2): if (GROUP == 1) any_phase_a<BPP, 4, AL>(L, lrow, it, base, geo, lo, hi); break;             \
+    case any_class(BC, AL, 3): if (GROUP == 2) any_phase_a<BPP, 8, AL>(L, lrow, it, base, geo, lo, hi); break;
         UCFP_ANY_CASE(0, 1, true)
         UCFP_ANY_CASE(0, 1, false)
         UCFP_ANY_CASE(1, 3, true)
@@ -1429,6 +1441,28 @@ bool image_any_plan(const uint8_t* base, uint64_t src, uint32_t w, uint32_t h, s
     *cls = any_class(pixfmt, aligned, spc);
     return true;
 }
+// The column table of width w (image_hash_any_kernel): for destination column i, word 0 = first dword of its window of luma
+// bytes | byte phase << 16; words 1-3 = which bytes of the window's three dwords are whole pixels (0x01 each); words 4-6 = the
+// weights (< 256) of the partly covered pixels at either end.  Byte b of the window is source pixel xa + b; its weight is the
+// overlap of [256 x, 256 x + 256) with [w i, w i + w).
+size_t image_any_geometry_bytes() { return (size_t)kAnyGeoWords * 4; }
+void image_any_geometry_table(uint32_t w, uint32_t* tab) {
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t* g = tab + (size_t)i * 8;
+        for (int k = 0; k < 8; k++) g[k] = 0;
+        const uint32_t di0 = w * i, di1 = di0 + w;
+        const uint32_t xa = di0 >> 8, xb = (di1 - 1) >> 8;
+        g[0] = (xa >> 2) | (xa & 3u) << 16;
+        for (uint32_t x = xa; x <= xb; x++) {
+            const uint32_t a = 256u * x > di0 ? 256u * x : di0, b = 256u * x + 256u < di1 ? 256u * x + 256u : di1;
+            const uint32_t ov = b - a, pos = x - xa;
+            if (pos >= 12) break;                                  // (w <= 2048: a window is at most 10 pixels)
+            if (ov == 256u) g[1 + (pos >> 2)] |= 1u << (8 * (pos & 3u));
+            else g[4 + (pos >> 2)] |= ov << (8 * (pos & 3u));
+        }
+    }
+}
+
 int image_any_group(uint32_t cls) { return (cls >> 3) <= 1 ? 0 : (int)(cls >> 3) - 1; }
 
 size_t image_any_item_bytes() { return sizeof(ImgItem); }
@@ -1442,7 +1476,7 @@ void image_any_item_write(void* dst, size_t i, uint64_t src, uint32_t w, uint32_
 int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_items, size_t n, int group, uint32_t proto_w,
                           uint32_t proto_h, uint32_t proto_row_stride, uint32_t proto_cls, uint32_t proto_magic, uint32_t proto_shift,
                           size_t frame_stride, const uint8_t* lo, const uint8_t* hi, const uint8_t* exact, uint8_t* out,
-                          int32_t* status, hipStream_t stream) {
+                          int32_t* status, const uint32_t* d_geo, hipStream_t stream) {
     if (n == 0) return 0;
     auto lds_of = [](int g) {
         const size_t rows = (size_t)kNW * any_row_bytes(g);
@@ -1459,13 +1493,13 @@ int launch_image_hash_any(uint32_t algo, const uint8_t* base, const void* d_item
     const ImgItem* items = reinterpret_cast<const ImgItem*>(d_items);
     if (group == 0)
         hipLaunchKernelGGL(image_hash_any_kernel<0>, dim3((unsigned)n), dim3(kNT), lds_of(0), stream, base, items, proto, frame_stride,
-                           (uint32_t)n, algo, exact, out, status, lo, hi);
+                           (uint32_t)n, algo, exact, out, status, lo, hi, d_geo);
     else if (group == 1)
         hipLaunchKernelGGL(image_hash_any_kernel<1>, dim3((unsigned)n), dim3(kNT), lds_of(1), stream, base, items, proto, frame_stride,
-                           (uint32_t)n, algo, exact, out, status, lo, hi);
+                           (uint32_t)n, algo, exact, out, status, lo, hi, d_geo);
     else
         hipLaunchKernelGGL(image_hash_any_kernel<2>, dim3((unsigned)n), dim3(kNT), lds_of(2), stream, base, items, proto, frame_stride,
-                           (uint32_t)n, algo, exact, out, status, lo, hi);
+                           (uint32_t)n, algo, exact, out, status, lo, hi, d_geo);
     return 0;
 }
 

@@ -105,6 +105,8 @@ int plan_hash(ucfp_ctx* ctx, const uint8_t* base, size_t frames_bytes, const ucf
             hp->big.push_back((uint32_t)k);
             continue;
         }
+        if (const int ge = ucfp::image_any_geometry_ready(ctx, it.width))
+            return capi_fail(UCFP_E_INDEX, "column table of width %u: %s", it.width, hipGetErrorString((hipError_t)ge));
         const int g = ucfp::image_any_group(cls);
         tab[g].resize((hp->cnt[g] + 1) * isz);
         ucfp::image_any_item_write(tab[g].data(), hp->cnt[g]++, it.offset, it.width, it.height, it.row_stride, slot, cls, magic, shift);
@@ -120,7 +122,7 @@ int launch_hash(ucfp_ctx* ctx, const HashPlan& hp, const uint8_t* d_tab, uint32_
     for (int g = 0; g < 3; g++)
         if (hp.cnt[g])
             ucfp::launch_image_hash_any(algo, base, d_tab + hp.off[g], hp.cnt[g], g, 0, 0, 0, 0, 0, 0, 0, base, base + frames_bytes, exact, out,
-                                        status, st);
+                                        status, ctx->geo, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return capi_fail(UCFP_E_INDEX, "ragged image launch failed: %s", hipGetErrorString(e));
     for (uint32_t k : hp.big) {

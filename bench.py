@@ -414,7 +414,7 @@ def upload_mix_files(n_img=400, seed=0xA11, lo=64, hi=2048):
     return files, px_bytes
 
 
-def bench_upload_mix(dev, ctx, n_img=400, threads=64):
+def bench_upload_mix(dev, ctx, n_img=300, threads=64):
     """Uploads of any size and kind through the any-upload entry (ucfp_image_upload_hash_batch_dev) with the files resident in
     HBM, and through ONE micro-batcher (ucfp_upload_batcher_*) fed by request threads -- the reference's route
     (src/server/handlers.rs:232-302) with the decode on the device.  Records are checked against the per-request host path
@@ -473,6 +473,23 @@ def bench_upload_mix(dev, ctx, n_img=400, threads=64):
             "batcher": {"request_threads": threads, "images_per_s": 2 * n / dt, "batches": batches, "items": items,
                         "note": "Python request threads (ctypes releases the GIL inside submit); host memory in and out"},
             "records_equal_per_request_host_path": bool(same), "batcher_records_equal_resident_call": bool(same_b)}
+
+
+def bench_search_batcher():
+    """/v1/query's request shape -- ONE query per request thread (src/server/handlers.rs:143-187), 64 / 256 threads -- through the
+    search micro-batcher over a 12.5 M-code Hamming shard, from NATIVE threads (tools/bench_search_batcher.cpp, built by
+    __graft_entry__.build(); a Python driver would measure the interpreter lock).  A child process with its own context."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "bench_search_batcher.bin")
+    if not os.path.exists(exe):
+        return {"error": "tools/bench_search_batcher.bin is not built (__graft_entry__.build() makes it)"}
+    try:
+        r = subprocess.run([exe, "--n=12500000", "--k=10", "64", "256"], capture_output=True, text=True, timeout=240)
+        rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        return {"what": "12.5 M codes, k = 10, one query per request thread, host memory in and out; every 170th request's answer "
+                        "checked against a brute-force scan on the host", "runs": rows, "rc": r.returncode}
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def cpu_baseline(sample: int, gpu_records_head):
@@ -1460,6 +1477,7 @@ def main():
             head = out[:want].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(want, head)
             res["config1_phash_png"] = bench_config1_phash_png(dev, ctx)
+            res["search_batcher"] = bench_search_batcher()
             try:
                 res["upload_mix"] = bench_upload_mix(dev, ctx)
             except Exception as e:   # noqa: BLE001  (a secondary leg: reported, never substituted)

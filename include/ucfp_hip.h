@@ -208,11 +208,12 @@ int ucfp_upload_batcher_stats(ucfp_upload_batcher* b, uint64_t* batches, uint64_
  * the ENCODED files: one blob + n + 1 byte offsets (like the text calls), all announced with ONE geometry and pixel
  * format -- the host reads those 24 bytes of each upload with ucfp_png_probe and groups by them.  One wave per file:
  * chunk walk, inflate (RFC 1950/1951, speculative parallel Huffman decoding), PNG filter reconstruction.
- * Decoded on the device: 8-bit, non-interlaced, without tRNS -- greyscale and grey + alpha (-> GRAY8, the alpha byte is
- * dropped: luma takes no alpha), RGB and indexed colour (-> RGB8 through the file's PLTE), RGBA (-> RGBA8); files of
- * both layouts of a format may share a batch.  ucfp_png_probe reports the format a file DECODES to.  status[i]:
+ * Decoded on the device: 8-bit, non-interlaced -- greyscale and grey + alpha (-> GRAY8, the alpha byte is dropped: luma
+ * takes no alpha), RGB and indexed colour (-> RGB8 through the file's PLTE), RGBA (-> RGBA8), each with or without a tRNS
+ * chunk (simple transparency only adds an alpha channel: no colour sample changes); files of both layouts of a format may
+ * share a batch.  ucfp_png_probe reports the format a file DECODES to.  status[i]:
  *   0                      decoded (and hashed)
- *   UCFP_IMAGE_NEEDS_HOST  a valid PNG of another kind (16-bit, 1/2/4-bit, interlaced, tRNS) or of another geometry /
+ *   UCFP_IMAGE_NEEDS_HOST  a valid PNG of another kind (16-bit, 1/2/4-bit, interlaced) or of another geometry /
  *                          format than announced, or a file whose only fault is a CHECKSUM (the Adler-32 of a stream that
  *                          inflated to the right length, the CRC of an ancillary chunk): decoders differ on those, so
  *                          the host's decoder decides -- decode it there, submit the pixels

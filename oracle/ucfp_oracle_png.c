@@ -12,7 +12,8 @@
  * synthetic config-1 set, on every filter type, colour type and compression level, and on stored / fixed / dynamic
  * blocks.
  *
- * Scope (mirrors the HIP path): 8-bit greyscale (0), RGB (2), RGBA (6), non-interlaced, no tRNS.  Everything else
+ * Scope (mirrors the HIP path): 8-bit greyscale (0), RGB (2), RGBA (6), non-interlaced, with or without a well-formed tRNS
+ * chunk (it only adds an alpha channel: luma takes none).  Everything else
  * returns UCFP_PNG_NEEDS_HOST: the host's own decoder (the `image` crate) takes those.
  */
 #include <stdint.h>
@@ -300,7 +301,14 @@ int ucfp_oracle_png_decode(const uint8_t* png, size_t n, uint8_t* pixels, size_t
         } else {
             if (seen_idat) idat_done = 1;
             if (memcmp(type, "IEND", 4) == 0) { seen_end = 1; break; }
-            if (memcmp(type, "tRNS", 4) == 0) needs_host = 1;       /* the host decoder adds an alpha channel */
+            if (memcmp(type, "tRNS", 4) == 0) {
+                /* PNG 11.3.2.1: simple transparency adds an alpha channel and changes no colour sample; luma takes no alpha
+                 * (I1), so a well-formed chunk -- grey: 2 bytes, RGB: 6, indexed: 1 .. palette entries, behind PLTE, all in
+                 * front of IDAT -- is skipped; anything else is the host decoder's to judge */
+                const int fine = !seen_idat && ((ctype == 0 && len == 2) || (ctype == 2 && len == 6) ||
+                                                (ctype == 3 && plte_n && len >= 1 && len <= plte_n));
+                if (!fine) needs_host = 1;
+            }
             if (memcmp(type, "PLTE", 4) == 0) {                      /* PNG 11.2.3 */
                 if (len == 0 || len % 3 != 0 || len > 768 || seen_idat || plte_n) { rc = PNG_CORRUPT; break; }
                 memcpy(plte, png + pos + 8, len);

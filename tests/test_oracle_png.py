@@ -107,7 +107,15 @@ def test_formats_handed_back_to_the_host(oracle):
     pal = PIL.fromarray(rng.integers(0, 256, (40, 40), dtype=np.uint8), "L").convert("P")
     b = io.BytesIO()
     pal.save(b, "PNG", transparency=3)
-    assert oracle.png_decode(b.getvalue())[0] == oracle.PNG_NEEDS_HOST            # palette with tRNS
+    rc, px = oracle.png_decode(b.getvalue())                                      # palette with tRNS: the alpha it adds is
+    assert rc == oracle.PNG_OK and np.array_equal(px, np.asarray(pal.convert("RGB")))   # dropped (I1), no colour changes
+    f = b.getvalue()
+    i = f.index(b"tRNS")
+    ln = int.from_bytes(f[i - 4:i], "big")
+    import struct
+    import zlib
+    wrong = f[:i - 4] + struct.pack(">I", 300) + b"tRNS" + bytes(300) + struct.pack(">I", zlib.crc32(b"tRNS" + bytes(300))) + f[i + 8 + ln:]
+    assert oracle.png_decode(wrong)[0] == oracle.PNG_NEEDS_HOST                   # more alphas than palette entries: the host's
     b = io.BytesIO()
     PIL.fromarray(rng.integers(0, 16, (40, 40), dtype=np.uint8), "L").convert("P").save(b, "PNG", bits=4)
     assert oracle.png_decode(b.getvalue())[0] == oracle.PNG_NEEDS_HOST            # 4-bit palette

@@ -25,7 +25,7 @@ def _raw_png(arr, idat_split=None, comp=None, extra=b""):
     rows = b"".join(b"\0" + arr[y].tobytes() for y in range(h))
     z = (comp or (lambda d: zlib.compress(d, 6)))(rows)
     parts = [z] if not idat_split else [z[i:i + idat_split] for i in range(0, len(z), idat_split)]
-    ctype = {1: 0, 3: 2, 4: 6}[bpp]
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[bpp]
     return (b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + extra +
             b"".join(_chunk(b"IDAT", p) for p in parts) + _chunk(b"IEND", b""))
 
@@ -157,8 +157,8 @@ def test_needs_host_and_damaged_files(gpu_ctx, oracle):
     from ucfp_amd import image
     rng = np.random.default_rng(5)
     good, img = config1_png(7, side=64)
-    pal = io.BytesIO()             # indexed colour WITH transparency: the host's decoder adds the alpha channel
-    PIL.fromarray(rng.integers(0, 256, (64, 64), dtype=np.uint8), "L").convert("P").save(pal, "PNG", transparency=3)
+    pal = io.BytesIO()             # a grey + alpha file whose tRNS chunk has no business there (PNG 11.3.2.1): the host decides
+    pal.write(_raw_png(rng.integers(0, 256, (64, 64, 2), dtype=np.uint8), extra=_chunk(b"tRNS", bytes(2))))
     deep = io.BytesIO()
     PIL.fromarray(rng.integers(0, 65535, (64, 64), dtype=np.uint16)).save(deep, "PNG")
     other_geom, _ = config1_png(8, side=32)
@@ -166,13 +166,13 @@ def test_needs_host_and_damaged_files(gpu_ctx, oracle):
     truncated = good[: len(good) // 2]
     z = bytearray(good)
     z[len(z) // 2] ^= 0x40            # flips a bit inside the deflate stream: the IDAT chunk's CRC no longer matches
-    trns = _raw_png(img, extra=_chunk(b"tRNS", bytes(6)))
+    trns = _raw_png(img, extra=_chunk(b"tRNS", bytes(5)))      # an RGB file's tRNS is six bytes: a malformed one is the host's
     too_short = _raw_png(img[:40])    # IHDR says 64 rows... built with 40: patch the header
     too_short = too_short[:16] + struct.pack(">II", 64, 64) + too_short[24:]
     pngs = [good, pal.getvalue(), deep.getvalue(), other_geom, gray, truncated, b"GIF89a" + bytes(80), trns, too_short, good]
     assert image.png_probe(good) == (0, 64, 64, image.PIX_RGB8)
-    # (the probe reads the IHDR only: an indexed file announces RGB8; its tRNS chunk is the device's business, below)
-    assert image.png_probe(pal.getvalue())[0] == 0 and image.png_probe(deep.getvalue())[0] == image.NEEDS_HOST
+    # (the probe reads the IHDR only: chunks behind it are the device's business, below)
+    assert image.png_probe(deep.getvalue())[0] == image.NEEDS_HOST
     assert image.png_probe(b"GIF89a" + bytes(80))[0] < 0
     rec, st = image.fingerprint_pngs(pngs, 64, 64, image.PIX_RGB8, algo=image.MULTI, ctx=gpu_ctx)
     assert list(st[:5]) == [0, 1, 1, 1, 1], st
@@ -378,3 +378,43 @@ def test_every_round_shape_of_the_inflate_kernel(gpu_ctx, oracle, n):
     for i in range(n):
         want = np.full((64, 64, 3), 200, np.uint8) if i in (5, n - 3) else base[i % 40][1]
         assert np.array_equal(fr[i], want), i
+
+
+def test_simple_transparency_changes_no_pixel(gpu_ctx, oracle):
+    """tRNS (PNG 11.3.2.1) for grey, RGB and indexed colour: the chunk adds an alpha channel and changes no colour sample, and
+    luma takes no alpha (DESIGN I1) -- the device skips a well-formed one; pixels and records equal the host path's (Pillow
+    decode -> L / RGB, alpha dropped) and the oracle's."""
+    from ucfp_amd import image
+    from ucfp_amd.image import PreprocessConfig
+    rng = np.random.default_rng(77)
+    h, w = 72, 90
+    grey = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    files, want, fmts = [], [], []
+    b = io.BytesIO()
+    PIL.fromarray(grey, "L").save(b, "PNG", transparency=37)
+    files.append(b.getvalue()); want.append(grey); fmts.append(image.PIX_GRAY8)
+    b = io.BytesIO()
+    PIL.fromarray(rgb, "RGB").save(b, "PNG", transparency=(1, 2, 3))
+    files.append(b.getvalue()); want.append(rgb); fmts.append(image.PIX_RGB8)
+    pimg = PIL.fromarray(rgb, "RGB").quantize(40)
+    b = io.BytesIO()
+    pimg.save(b, "PNG", transparency=bytes(range(0, 200, 5)))           # an alpha per palette entry
+    files.append(b.getvalue()); want.append(np.asarray(pimg.convert("RGB"))); fmts.append(image.PIX_RGB8)
+    b = io.BytesIO()
+    pimg.save(b, "PNG", transparency=5)                                  # one fully transparent entry
+    files.append(b.getvalue()); want.append(np.asarray(pimg.convert("RGB"))); fmts.append(image.PIX_RGB8)
+    for f in files:
+        assert b"tRNS" in f
+    got, st = image.decode_uploads(files, ctx=gpu_ctx)
+    assert not st.any(), st
+    for i in range(len(files)):
+        assert np.array_equal(got[i], want[i]), i
+        rc, px = oracle.png_decode(files[i])
+        assert rc == 0 and np.array_equal(px, want[i]), i
+    rec, st = image.fingerprint_uploads(files, ctx=gpu_ctx)
+    for i, f in enumerate(files):
+        assert bytes(image.fingerprint_with(f, 0, i, PreprocessConfig()).fingerprint) == rec[i].tobytes(), i
+    # the uniform entry takes them too
+    fr, st = image.decode_pngs(files[1:], w, h, image.PIX_RGB8, ctx=gpu_ctx)
+    assert not st.any() and all(np.array_equal(fr[i], want[i + 1]) for i in range(3))

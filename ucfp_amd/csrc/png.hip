@@ -19,7 +19,8 @@
 //                 64 k + j one pixel behind lane j-1, so "above" and "above-left" are the neighbour lane's last two
 //                 outputs (a diagonal wavefront, 64 rows in flight).
 //
-// Scope: 8-bit greyscale / grey + alpha / RGB / indexed colour / RGBA, non-interlaced, no tRNS -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
+// Scope: 8-bit greyscale / grey + alpha / RGB / indexed colour / RGBA, non-interlaced, with or without a tRNS chunk (it only adds
+// an alpha channel, and luma takes no alpha) -- anything else gets UCFP_IMAGE_NEEDS_HOST and goes to
 // the host's decoder (like non-ASCII text).  Every chunk's CRC-32 and the Adler-32 trailer are computed; a bad CRC on a
 // critical chunk is UCFP_E_MODALITY, while the checksum-ONLY failures decoders disagree on (Adler-32 of a stream that
 // otherwise inflated to the right length, the CRC of an ancillary chunk) are UCFP_IMAGE_NEEDS_HOST: the host's decoder
@@ -558,8 +559,15 @@ __global__ __launch_bounds__(64) void png_scan_kernel(const uint8_t* __restrict_
                     seen_end = true;
                     break;
                 }
-                if (t0 == 't' && t1 == 'R' && t2 == 'N' && t3 == 'S') status = UCFP_IMAGE_NEEDS_HOST;
-                else if (t0 == 'P' && t1 == 'L' && t2 == 'T' && t3 == 'E') {
+                if (t0 == 't' && t1 == 'R' && t2 == 'N' && t3 == 'S') {
+                    // PNG 11.3.2.1: simple transparency for grey (one 16-bit sample), RGB (three) and indexed colour (an alpha
+                    // per palette entry, after PLTE), in front of the first IDAT.  It adds an alpha channel and changes no
+                    // colour sample -- and luma takes no alpha (DESIGN I1; the host path's conversion drops it the same way):
+                    // a well-formed one is skipped like any ancillary chunk, anything else is the host decoder's to judge
+                    const uint32_t ct = p[25];
+                    const bool fine = !seen_idat && ((ct == 0 && cl == 2) || (ct == 2 && cl == 6) || (ct == 3 && plte_n && cl >= 1 && cl <= plte_n));
+                    if (!fine) status = UCFP_IMAGE_NEEDS_HOST;
+                } else if (t0 == 'P' && t1 == 'L' && t2 == 'T' && t3 == 'E') {
                     // PNG 11.2.3: 1 .. 256 entries of 3 bytes, before the first IDAT, once
                     if (cl == 0 || cl % 3 != 0 || cl > 768 || seen_idat || plte_n) status = UCFP_E_MODALITY;
                     plte_off = (uint32_t)(pos + 8);

@@ -826,3 +826,25 @@ def test_cosine_pruned_pass(gpu_ctx, n, dim, nq, k):
         del os.environ["UCFP_COSINE_PRUNE_FALLBACK"]
     assert np.array_equal(g_c, d_c) and np.array_equal(g_ids, d_ids) and np.array_equal(g_sc, d_sc)
     ix.close()
+
+
+def test_hamming_few_tiles_pipeline_drain(gpu_ctx, oracle):
+    """Batches of up to 256 queries run the matrix-core filter as ONE pipeline across code steps (hamming_scan_mfma, stream
+    path) whose last fold happens in a drain step per wave.  Tie-heavy data makes nearly every step a suspect, so every
+    wave's drain step logs a record: a record damaged there (round 4: its ballots were read back from registers the
+    matrix core was still writing) loses a boundary candidate in the last query tile.  Repeated, because the damage
+    depended on timing."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(77)
+    n = 752_253
+    codes = rng.integers(0, 2**12, n, dtype=np.uint64) * np.uint64(0x0010000100001001)
+    ids = rng.permutation(n).astype(np.uint64) + np.uint64(1000)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=gpu_ctx)
+    ix.upsert(0, ids, codes)
+    for nq, k in ((216, 64), (30, 10), (64, 17), (256, 3)):
+        queries = codes[rng.integers(0, n, nq)] ^ (np.uint64(1) << rng.integers(0, 64, nq).astype(np.uint64))
+        o_ids, o_d, o_c = oracle.hamming_topk(ids, codes, queries, k)
+        for _ in range(6):
+            g_ids, _, g_d, g_c = ix.search(0, queries, k)
+            assert np.array_equal(g_c, o_c) and np.array_equal(g_d, o_d) and np.array_equal(g_ids, o_ids), (nq, k)
+    ix.close()

@@ -17,7 +17,6 @@
 //                                      heuristics of the other two.
 // Kernels in pipeline order:
 //   hamming_sample_hist[_lanes] / hist_reduce / tau0   k-th smallest sampled distance per query
-//   hamming_query_image                                +-1 image of the batch in the MFMA scan's LDS layout
 //   per stage: hamming_scan_mfma + hamming_rescan  (or hamming_scan_lanes), hamming_list_tau
 //   hamming_final_select                               top-k of the candidate lists by (d, id)
 //   hamming_scan + topk_merge_u32                      robust tier / fallback
@@ -298,6 +297,7 @@ constexpr int kQP = 4096;    // queries per pass (their +-1 image is resident in
 constexpr int kTB = 4;       // 32-code tiles per wave step
 constexpr int kMW = 16;      // waves per workgroup (4 per SIMD; the loop is software-pipelined inside a wave)
 constexpr int kStep = kTB * 32;
+constexpr int kStreamTiles = 8;     // hamming_scan_mfma: up to this many query tiles run as one pipeline across code steps
 static_assert(kQP >= (int)kHammingMaxBatch, "one pass covers a whole search call");
 
 // FP4 operand words of a 32-bit half: dword j nibble i <- bit 4 i + j.  Codes: 1 -> 0x2 (+1.0), 0 -> 0x0 (0.0).
@@ -383,16 +383,31 @@ __device__ __forceinline__ uint64_t filter_query(uint64_t q, uint32_t& slack) {
     return q == ~0ull ? q & ~1ull : q;
 }
 
-// +-1 image of the query batch in the scan's LDS layout, built once per search: [tile][lane] 16 B
-__global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __restrict__ queries, uint32_t nq,
-                                                           i32x4* __restrict__ img) {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= ((nq + 31) / 32) * 64) return;
-    const uint32_t t = s >> 6, l = s & 63, q = t * 32 + (l & 31);
-    i32x4 v = {0, 0, 0, 0};   // dead columns are all-zero: their sums are 0
-    uint32_t slack;
-    if (q < nq) v = expand_query_fp4((uint32_t)(filter_query(queries[q], slack) >> (32 * (l >> 5))));
-    img[s] = v;
+// +-1 image of the pass's queries in LDS, [tile][lane] 16 B (the B operand of query tile t is one ds_read_b128 per lane),
+// + 2 zero pad tiles.  Every workgroup builds it from the queries themselves: 8 bytes loaded and half a dozen vector
+// instructions per entry, where a prebuilt image cost 16 bytes loaded -- and a launch of its own per search (4 us of the
+// 90 a batch of 32 queries takes over 12.5 M codes).  8 loads in flight per thread (a plain loop would pay the global
+// latency 17 times in a row for a full pass).
+__device__ __forceinline__ void build_query_image(i32x4* QB, const uint64_t* __restrict__ queries, uint32_t nq, uint32_t q0,
+                                                  uint32_t ntiles, uint32_t nthreads) {
+    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += nthreads * 8) {
+        uint64_t qw[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t s = s0 + u * nthreads, q = q0 + (s >> 6) * 32 + (s & 31);
+            qw[u] = (s < ntiles * 64 && q < nq) ? queries[q] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t s = s0 + u * nthreads, q = q0 + (s >> 6) * 32 + (s & 31);
+            if (s < (ntiles + 2) * 64) {
+                uint32_t slack;
+                i32x4 v = {0, 0, 0, 0};   // dead columns are all-zero: their sums are 0
+                if (s < ntiles * 64 && q < nq) v = expand_query_fp4((uint32_t)(filter_query(qw[u], slack) >> (32 * ((s >> 5) & 1))));
+                QB[s] = v;
+            }
+        }
+    }
 }
 
 // log record (48 bytes, one per suspect step of a wave): query tile (global: q / 32), row - begin of the step's first
@@ -401,9 +416,9 @@ __global__ __launch_bounds__(256) void hamming_query_image(const uint64_t* __res
 // stage up to a smaller quantum, more waves cover each other's stalls in a long one).
 __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint64_t* __restrict__ codes, size_t begin, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
-    const i32x4* __restrict__ qimg, const uint32_t* __restrict__ tau, uint4* __restrict__ log,
+    const uint32_t* __restrict__ tau, uint4* __restrict__ log,
     uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ overflow, size_t strict_from,
-    const uint32_t* __restrict__ ids_ascending) {
+    const uint32_t* __restrict__ ids_ascending, uint32_t stream_tiles) {
     const uint32_t nthreads = blockDim.x, mw = nthreads >> 6;   // waves in this workgroup
     extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
     const uint32_t q0 = blockIdx.y * kQP;
@@ -417,25 +432,37 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     // follows the bound pass are the k-th smallest of group minima over rows < strict_from, so k records at most that far
     // AND with smaller ids exist already -- a tie from a later row cannot displace them (as in hamming_list_tau)
     const bool strict_rows = ids_ascending && *ids_ascending;
-    // copy of the prebuilt image + 2 zero pad tiles; 8 loads in flight per thread (a plain loop would pay the
-    // global latency 17 times in a row)
-    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += nthreads * 8) {
-        i32x4 v[8];
+
+    const int lane = threadIdx.x & 63;
+    const int nn = lane & 31, hh = lane >> 5;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, in an SGPR
+    // step st goes to wave (st / workgroups) % mw of workgroup st % workgroups: the steps of a last, partial round land on
+    // different CUs and SIMDs (the waves of a SIMD share its matrix pipe, so a stage takes as long as the busiest SIMD has
+    // steps: with the partial round's steps all in the first workgroups it cost a whole round, 231 us instead of ~160 for
+    // the 1.6 M codes behind 8.4 M of a 10 M corpus)
+    const size_t gwave = (size_t)wv * gridDim.x + blockIdx.x, nwaves = (size_t)gridDim.x * mw;
+    const size_t nsuper = (end - begin + kStep - 1) / kStep;
+    // lane (nn, hh) needs bits [32 hh, +32) of code nn: one 4-byte load, a wave reads 256 contiguous bytes per tile
+    const uint32_t* __restrict__ halves = reinterpret_cast<const uint32_t*>(codes);
+    auto load_codes = [&](uint32_t (&x)[kTB], size_t st) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t s = s0 + u * nthreads;
-            v[u] = s < ntiles * 64 ? qimg[(size_t)(q0 / 32) * 64 + s] : i32x4{0, 0, 0, 0};
+        for (int b = 0; b < kTB; b++) {
+            const size_t row = begin + st * kStep + 32 * b + nn;
+            const bool ok = st < nsuper && row < end;
+            x[b] = ok ? __builtin_nontemporal_load(halves + row * 2 + hh) : 0u;
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t s = s0 + u * nthreads;
-            if (s < (ntiles + 2) * 64) QB[s] = v[u];
-        }
-    }
-    // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) never hit
-    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 32; s0 += nthreads * 4) {
-        uint64_t qv[4];
-        uint32_t tv[4];
+    };
+    // The codes of the wave's first two steps leave before the prologue: a batch of a few dozen queries is one query tile, a
+    // wave's whole share of a 12.5 M-code shard is 20 steps of ~300 ns, and the memory latency of a step's codes (2-3 us
+    // under load) then needs TWO steps of lead -- with one the last stage of 32 queries ran at 2.5 TB/s.
+    uint32_t x[kTB], xn[kTB];
+    load_codes(x, gwave);
+    load_codes(xn, gwave + nwaves);
+    // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) never hit.  The first round's inputs are requested
+    // before the image is built, so that the prologue pays the global latency once, not twice.
+    uint64_t qv[4];
+    uint32_t tv[4];
+    auto thr_load = [&](uint32_t s0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t s = s0 + u * nthreads, q = q0 + s;
@@ -443,6 +470,8 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
             qv[u] = live ? queries[q] : 0ull;
             tv[u] = live ? (tau[q] < 64u ? tau[q] : 64u) : 0u;
         }
+    };
+    auto thr_store = [&](uint32_t s0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t s = s0 + u * nthreads, q = q0 + s;
@@ -455,32 +484,20 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
                              : kNever;
             }
         }
+    };
+    thr_load(threadIdx.x);
+    build_query_image(QB, queries, nq, q0, ntiles, nthreads);
+    thr_store(threadIdx.x);
+    for (uint32_t s0 = threadIdx.x + nthreads * 4; s0 < (ntiles + 2) * 32; s0 += nthreads * 4) {
+        thr_load(s0);
+        thr_store(s0);
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int nn = lane & 31, hh = lane >> 5;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, in an SGPR
-    // step st goes to wave (st / workgroups) % mw of workgroup st % workgroups: the steps of a last, partial round land on
-    // different CUs and SIMDs (the waves of a SIMD share its matrix pipe, so a stage takes as long as the busiest SIMD has
-    // steps: with the partial round's steps all in the first workgroups it cost a whole round, 231 us instead of ~160 for
-    // the 1.6 M codes behind 8.4 M of a 10 M corpus)
-    const size_t gwave = (size_t)wv * gridDim.x + blockIdx.x, nwaves = (size_t)gridDim.x * mw;
-    const size_t nsuper = (end - begin + kStep - 1) / kStep;
     const size_t slice = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * mw + wv;
     uint4* __restrict__ mylog = log + slice * log_cap * 3;   // 48-byte records
     uint32_t ln = 0;   // records written, wave-uniform
 
-    // lane (nn, hh) needs bits [32 hh, +32) of code nn: one 4-byte load, a wave reads 256 contiguous bytes per tile
-    const uint32_t* __restrict__ halves = reinterpret_cast<const uint32_t*>(codes);
-    auto load_codes = [&](uint32_t (&x)[kTB], size_t st) {
-#pragma unroll
-        for (int b = 0; b < kTB; b++) {
-            const size_t row = begin + st * kStep + 32 * b + nn;
-            const bool ok = st < nsuper && row < end;
-            x[b] = ok ? __builtin_nontemporal_load(halves + row * 2 + hh) : 0u;
-        }
-    };
     // results of the software pipeline, in place: one accumulator per PAIR of code tiles.  Their content at the start
     // of a code step is irrelevant: the first fold of every step runs against the threshold "never" ("tile -1").
     static_assert(kTB == 4, "two pairs of code tiles per step");
@@ -494,13 +511,84 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     for (int e = 0; e < 16; e++) cc[e] = 8388608.f + 4194304.f + (float)kFieldLo;
     asm volatile("" : "+v"(cc));   // sixteen registers, not one rematerialised constant
     const int sa = 127 + 16, sb = 127;   // E8M0 block scales: 2^16 on the pair's second code tile, 1 on the queries
-    uint32_t x[kTB];
-    load_codes(x, gwave);
+    // the four per-tile ballots of a suspect step (m01 = fields of tiles 1 | 0, m23 = tiles 3 | 2; a threshold field holds
+    // threshold - 1) and ONE 48-byte record written by lanes 0..2
+    auto log_step = [&](uint32_t thr, uint32_t m01, uint32_t m23, uint32_t tile, uint32_t off) {
+        const uint32_t tl = thr & 0xffffu, th = thr >> 16;
+        const uint64_t k0 = __ballot((m01 & 0xffffu) > tl), k1 = __ballot((m01 >> 16) > th),
+                       k2 = __ballot((m23 & 0xffffu) > tl), k3 = __ballot((m23 >> 16) > th);
+        const uint4 ra = make_uint4(tile, off, (uint32_t)k0, (uint32_t)(k0 >> 32));
+        const uint4 rb = make_uint4((uint32_t)k1, (uint32_t)(k1 >> 32), (uint32_t)k2, (uint32_t)(k2 >> 32));
+        const uint4 rc = make_uint4((uint32_t)k3, (uint32_t)(k3 >> 32), 0u, 0u);
+        uint4 v;
+        v.x = lane == 0 ? ra.x : lane == 1 ? rb.x : rc.x;
+        v.y = lane == 0 ? ra.y : lane == 1 ? rb.y : rc.y;
+        v.z = lane == 0 ? ra.z : lane == 1 ? rb.z : rc.z;
+        v.w = lane == 0 ? ra.w : lane == 1 ? rb.w : rc.w;
+        if (ln < log_cap) {
+            if (lane < 3) mylog[(size_t)ln * 3 + lane] = v;
+        } else if (lane == 0) {
+            *overflow = 1;
+        }
+        ln++;
+    };
+    if (ntiles <= stream_tiles) {
+        // Few query tiles (a batch of up to 256 queries): ONE pipeline over all (code step, query tile) pairs of the wave --
+        // the fold inside a step tests the previous pair's results, whichever code step that was, and a single pad tile
+        // drains the pipeline at the very end.  The loop below drains after every code step, which for one query tile is
+        // half of all matrix instructions plus 24 wait states per step (32 queries over 10.5 M codes: 29.7 us, 2.8 TB/s).
+        i32x4 A[kTB];
+        auto stepc = [&](const i32x4& bq, uint32_t thr, uint32_t tile, uint32_t off, uint32_t nxt, i32x4& nq_, uint32_t& nthr) {
+            uint32_t m01, m23, vs;
+            uint64_t hit;
+            asm volatile(UCFP_FOLD_PAIR : "+v"(D[0]), "=&v"(m01) : UCFP_FOLD_PAIR_IN(0) : "memory");
+            nq_ = QB[nxt * 64 + lane];
+            nthr = THR[nxt * 32 + nn];
+            asm volatile(UCFP_FOLD_PAIR_LAST
+                         : "+v"(D[1]), "=&v"(m23), "=&v"(vs), "=s"(hit)
+                         : UCFP_FOLD_PAIR_IN(1), "v"(m01), "v"(thr)
+                         : "memory");
+            if (__builtin_expect(hit != 0, 0)) log_step(thr, m01, m23, tile, off);
+        };
+        i32x4 bcur = QB[lane], bnext;
+        uint32_t thr_cur = THR[nn], thr_next;
+        uint32_t thr_prev = kNever, tile_prev = 0, off_prev = 0;   // the very first fold reads the zeroed accumulators
+        for (size_t st = gwave; st < nsuper; st += nwaves) {
+#pragma unroll
+            for (int b = 0; b < kTB; b++) {
+                A[b] = expand_code_fp4(x[b]);
+                x[b] = xn[b];
+            }
+            load_codes(xn, st + 2 * nwaves);
+            const uint32_t off = (uint32_t)(st * kStep);
+            const uint32_t dlt = strict_rows && begin + st * kStep >= strict_from ? 0x00010001u : 0u;
+            for (uint32_t t = 0; t < ntiles; t++) {
+                stepc(bcur, thr_prev, tile_prev, off_prev, t + 1 == ntiles ? 0u : t + 1, bnext, thr_next);
+                thr_prev = thr_cur + dlt;
+                tile_prev = q0 / 32 + t;
+                off_prev = off;
+                bcur = bnext;
+                thr_cur = thr_next;
+            }
+        }
+        if (gwave < nsuper) {   // wave-uniform
+            bcur = QB[ntiles * 64 + lane];   // a pad tile: all zero
+            stepc(bcur, thr_prev, tile_prev, off_prev, ntiles, bnext, thr_next);
+            // The pad tile's MFMAs are still writing D.  To the compiler D is dead after the last fold, and it hands D's
+            // registers to that very step's fold results (seen: m23 in D[0][0], read again by log_step after the matrix
+            // core had overwritten it -- one suspect record in a few thousand searches lost its ballots).  Keep both
+            // accumulators alive until the wait states are over.
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(D[0]), "+v"(D[1])::"memory");
+        }
+    } else
     for (size_t st = gwave; st < nsuper; st += nwaves) {
         i32x4 A[kTB];
 #pragma unroll
-        for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(x[b]);
-        load_codes(x, st + nwaves);   // next step's codes travel while this one computes
+        for (int b = 0; b < kTB; b++) {
+            A[b] = expand_code_fp4(x[b]);
+            x[b] = xn[b];
+        }
+        load_codes(xn, st + 2 * nwaves);   // the codes of the step after next travel while this one and the next compute
         const uint32_t off = (uint32_t)(st * kStep);   // row - begin of code tile 0 (the span is < 2^32)
         const uint32_t dlt = strict_rows && begin + st * kStep >= strict_from ? 0x00010001u : 0u;   // wave-uniform
         // Software pipeline over the query tiles: per pair of code tiles, the v_pk_maximum3 folding query tile t-1's
@@ -525,28 +613,9 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
                          : "+v"(D[1]), "=&v"(m23), "=&v"(vs), "=s"(hit)
                          : UCFP_FOLD_PAIR_IN(1), "v"(m01), "v"(thr)
                          : "memory");
-            if (__builtin_expect(hit != 0, 0)) {
-                // straight-line: the four per-tile ballots (m01 = fields of tiles 1 | 0, m23 = tiles 3 | 2; a threshold
-                // field holds threshold - 1) and ONE 48-byte record written by lanes 0..2 (in the first stages nearly
-                // every step comes through here, and a branch per code tile was most of their time)
-                const uint32_t tl = thr & 0xffffu, th = thr >> 16;
-                const uint64_t k0 = __ballot((m01 & 0xffffu) > tl), k1 = __ballot((m01 >> 16) > th),
-                               k2 = __ballot((m23 & 0xffffu) > tl), k3 = __ballot((m23 >> 16) > th);
-                const uint4 ra = make_uint4(q0 / 32 + (t - 1), off, (uint32_t)k0, (uint32_t)(k0 >> 32));
-                const uint4 rb = make_uint4((uint32_t)k1, (uint32_t)(k1 >> 32), (uint32_t)k2, (uint32_t)(k2 >> 32));
-                const uint4 rc = make_uint4((uint32_t)k3, (uint32_t)(k3 >> 32), 0u, 0u);
-                uint4 v;
-                v.x = lane == 0 ? ra.x : lane == 1 ? rb.x : rc.x;
-                v.y = lane == 0 ? ra.y : lane == 1 ? rb.y : rc.y;
-                v.z = lane == 0 ? ra.z : lane == 1 ? rb.z : rc.z;
-                v.w = lane == 0 ? ra.w : lane == 1 ? rb.w : rc.w;
-                if (ln < log_cap) {
-                    if (lane < 3) mylog[(size_t)ln * 3 + lane] = v;
-                } else if (lane == 0) {
-                    *overflow = 1;
-                }
-                ln++;
-            }
+            // straight-line (in the first stages nearly every step comes through here, and a branch per code tile was most
+            // of their time)
+            if (__builtin_expect(hit != 0, 0)) log_step(thr, m01, m23, q0 / 32 + (t - 1), off);
         };
         i32x4 p = QB[lane], r;
         // tiles 0 .. ntiles: the last one is a pad tile that only drains the pipeline.  Two steps per
@@ -593,7 +662,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
 
 __global__ __launch_bounds__(kMW * 64) void hamming_bound_mfma(
     const uint64_t* __restrict__ codes, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
-    const i32x4* __restrict__ qimg, uint8_t* __restrict__ table, uint32_t table_stride) {
+    uint8_t* __restrict__ table, uint32_t table_stride) {
     const uint32_t nthreads = blockDim.x, mw = nthreads >> 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
     const uint32_t q0 = blockIdx.y * kQP;
@@ -602,19 +671,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_bound_mfma(
     i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
     // [1 + tile][32]: largest (1088 + sum) seen for the query; row 0 takes the fold of "tile -1" (pipeline fill); 0 = nothing seen
     uint32_t* MX = reinterpret_cast<uint32_t*>(mf_lds + (size_t)(ntiles + 2) * 1024);
-    for (uint32_t s0 = threadIdx.x; s0 < (ntiles + 2) * 64; s0 += nthreads * 8) {
-        i32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t s = s0 + u * nthreads;
-            v[u] = s < ntiles * 64 ? qimg[(size_t)(q0 / 32) * 64 + s] : i32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t s = s0 + u * nthreads;
-            if (s < (ntiles + 2) * 64) QB[s] = v[u];
-        }
-    }
+    build_query_image(QB, queries, nq, q0, ntiles, nthreads);
     for (uint32_t s = threadIdx.x; s < (ntiles + 2) * 32; s += nthreads) MX[s] = 0;
     __syncthreads();
 
@@ -994,7 +1051,7 @@ constexpr int kSelCap = 512;   // 6 KiB of LDS per query: all 4096 one-wave work
 __global__ __launch_bounds__(64) void hamming_final_select(
     const uint32_t* __restrict__ cand_cnt, const uint32_t* __restrict__ cand_d, const uint64_t* __restrict__ cand_id,
     uint32_t cand_cap, uint32_t k, uint64_t* __restrict__ out_ids, uint32_t* __restrict__ out_d,
-    uint32_t* __restrict__ out_cnt) {
+    uint32_t* __restrict__ out_cnt, uint32_t regs_ok) {
     __shared__ uint32_t h[65];
     __shared__ uint32_t sd[kSelCap];
     __shared__ uint64_t si[kSelCap];
@@ -1007,7 +1064,27 @@ __global__ __launch_bounds__(64) void hamming_final_select(
     const uint32_t nc = sl.total;
     const uint32_t* __restrict__ gd = cand_d + (size_t)q * cand_cap;
     const uint64_t* __restrict__ gi = cand_id + (size_t)q * cand_cap;
-    for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[gd[sl.slot(c)]], 1u);
+    // A list of up to 8 entries per lane -- nearly every list -- is read ONCE, distances and ids together, into registers: the
+    // histogram pass, the compaction's second read of the distances and its dependent read of the ids were three global
+    // round trips in a row of a kernel that is one wave per query (10.7 us at 32 queries, most of it those).
+    constexpr uint32_t kRegs = 8;
+    const bool in_regs = regs_ok && nc <= kRegs * kWave;
+    uint32_t rd[kRegs];
+    uint64_t ri[kRegs];
+    if (in_regs) {
+#pragma unroll
+        for (uint32_t u = 0; u < kRegs; u++) {
+            const uint32_t c = u * kWave + lane;
+            const uint32_t at = c < nc ? sl.slot(c) : 0u;
+            rd[u] = c < nc ? gd[at] : 0xffffffffu;
+            ri[u] = c < nc ? gi[at] : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kRegs; u++)
+            if (rd[u] <= 64u) atomicAdd(&h[rd[u]], 1u);
+    } else {
+        for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[gd[sl.slot(c)]], 1u);
+    }
     wave_lds_sync();
     uint32_t dstar = 64, cum = 0;   // wave-uniform: every lane walks the same 65 bins
     for (uint32_t b = 0; b < 65; b++) {
@@ -1019,19 +1096,35 @@ __global__ __launch_bounds__(64) void hamming_final_select(
     }
     // compact the possible winners
     uint32_t m = 0;   // wave-uniform
-    for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
-        const uint32_t c = c0 + lane;
-        const uint32_t at = c < nc ? sl.slot(c) : 0u;
-        const uint32_t dd = c < nc ? gd[at] : 0xffffffffu;
-        const bool w = dd <= dstar;
-        const uint64_t mask = __ballot(w);
-        const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (w && pos < (uint32_t)kSelCap) {
-            sd[pos] = dd;
-            si[pos] = gi[at];
+    if (in_regs) {
+        static_assert(kRegs * kWave <= (uint32_t)kSelCap, "a register-held list fits the LDS selection buffer");
+#pragma unroll
+        for (uint32_t u = 0; u < kRegs; u++) {
+            const bool w = rd[u] <= dstar;   // (an empty place holds 0xffffffff)
+            const uint64_t mask = __ballot(w);
+            const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (w) {
+                sd[pos] = rd[u];
+                si[pos] = ri[u];
+            }
+            m += (uint32_t)__popcll(mask);
         }
-        m += (uint32_t)__popcll(mask);
+    } else {
+        for (uint32_t c0 = 0; c0 < nc; c0 += kWave) {
+            const uint32_t c = c0 + lane;
+            const uint32_t at = c < nc ? sl.slot(c) : 0u;
+            const uint32_t dd = c < nc ? gd[at] : 0xffffffffu;
+            const bool w = dd <= dstar;
+            const uint64_t mask = __ballot(w);
+            const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (w && pos < (uint32_t)kSelCap) {
+                sd[pos] = dd;
+                si[pos] = gi[at];
+            }
+            m += (uint32_t)__popcll(mask);
+        }
     }
     wave_lds_sync();
     const bool in_lds = m <= (uint32_t)kSelCap;
@@ -1192,7 +1285,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
 
 namespace {
 struct HammingWs {
-    size_t btab, hist, tau0, part_ids, part_d, part_cnt, tau1, tau2, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, qimg, total;
+    size_t btab, hist, tau0, part_ids, part_d, part_cnt, tau1, tau2, cand_cnt, overflow, cand_d, cand_id, log_cnt, log, total;
 };
 HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1213,7 +1306,6 @@ HammingWs hamming_ws_layout(const HammingPlan& p, uint32_t nq, uint32_t k) {
     w.cand_id = off;   off = align(off + (p.fast ? (size_t)nq * p.cand_cap * 8 : 0));
     w.log_cnt = off;   off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * 4 : 0));
     w.log = off;       off = align(off + (p.fast ? (size_t)hamming_log_slices(nq) * p.log_cap * 48 : 0));
-    w.qimg = off;      off = align(off + (p.fast ? (size_t)((nq + 31) / 32) * 64 * 16 : 0));
     w.total = off;
     return w;
 }
@@ -1253,19 +1345,16 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
     }
     // tau0: from the bound pass (matrix-core batches), else from the sample
     const bool few = few_queries(n, nq);
-    i32x4* qimg = reinterpret_cast<i32x4*>(ws + w.qimg);
     if (p.bound) {
         const size_t lds = hamming_mfma_lds_bytes(nq);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_bound_mfma),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 64 + 255) / 256), dim3(256), 0, stream, queries,
-                           nq, qimg);
         const size_t steps = p.bound_n / kStep;
         unsigned mw = steps >= (size_t)kBoundGroups * kMW ? kMW : steps >= (size_t)kBoundGroups * 8 ? 8 : 4;
         const uint32_t stride = p.qgroups * kWave;
         hipLaunchKernelGGL(hamming_bound_mfma, dim3(kBoundGroups, (nq + kQP - 1) / kQP), dim3(mw * 64), lds, stream, codes,
-                           p.bound_n, queries, nq, (const i32x4*)qimg, ws + w.btab, stride);
+                           p.bound_n, queries, nq, ws + w.btab, stride);
         hipLaunchKernelGGL(hamming_bound_tau, dim3(p.qgroups), dim3(256), 0, stream, (const uint8_t*)(ws + w.btab),
                            kBoundGroups, stride, queries, nq, k, u32(w.tau0), u32(w.cand_cnt), u32(w.overflow));
     } else if (few) {
@@ -1292,13 +1381,12 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
                               stream);
     } else {
         const uint32_t passes = (nq + kQP - 1) / kQP;
+        static const uint32_t stream_tiles = getenv("UCFP_HAMMING_NO_STREAM") ? 0u : (uint32_t)kStreamTiles;   // (bisecting)
+        static const uint32_t select_regs = getenv("UCFP_HAMMING_NO_SELECT_REGS") ? 0u : 1u;
         const size_t lds = hamming_mfma_lds_bytes(nq);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_scan_mfma),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (!few && !p.bound)
-            hipLaunchKernelGGL(hamming_query_image, dim3(((nq + 31) / 32 * 64 + 255) / 256), dim3(256), 0, stream, queries,
-                               nq, qimg);
         // stage thresholds alternate between tau1 and tau2: tau0 (the sample's, never strict) stays intact for the
         // fallback tier, which filters the WHOLE corpus with d <= tau0 -- a strict stage threshold would drop the k-th itself
         uint32_t* tau_cur = u32(w.tau0);
@@ -1328,9 +1416,9 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             // every wave of the scan writes its slice's record count, and the slices of a launch are 0 .. wgs * passes *
             // mw - 1: the rescan covers exactly those (no memset of the counters)
             hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(mw * 64), lds, stream, codes, begin, end,
-                               queries, nq, (const i32x4*)qimg, (const uint32_t*)tau_cur,
+                               queries, nq, (const uint32_t*)tau_cur,
                                reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow), strict_from,
-                               ids_ascending);
+                               ids_ascending, stream_tiles);
             hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw, rescan_parts), dim3(kRescanThreads), 0, stream, codes, ids, begin, end, queries,
                                (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),
@@ -1348,7 +1436,7 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         }
         hipLaunchKernelGGL(hamming_final_select, dim3(nq), dim3(64), 0, stream, (const uint32_t*)u32(w.cand_cnt),
                            (const uint32_t*)u32(w.cand_d), (const uint64_t*)u64(w.cand_id), p.cand_cap, k, out_ids,
-                           out_dist, out_cnt);
+                           out_dist, out_cnt, select_regs);
         // fallback: only runs (device-side check) when some candidate list overflowed
         launch_robust(p.cap, dim3(p.fb_slices, p.qgroups), stream, codes, ids, n, p.fb_per_slice, queries, nq, k,
                       (const uint32_t*)u32(w.tau0), u64(w.part_ids), u32(w.part_d), u32(w.part_cnt),

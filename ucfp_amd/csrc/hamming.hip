@@ -297,6 +297,7 @@ constexpr int kQP = 4096;    // queries per pass (their +-1 image is resident in
 constexpr int kTB = 4;       // 32-code tiles per wave step
 constexpr int kMW = 16;      // waves per workgroup (4 per SIMD; the loop is software-pipelined inside a wave)
 constexpr int kStep = kTB * 32;
+constexpr size_t kFusedTauLds = 65 * 64 * 4 + 256 * 4;   // hamming_scan_mfma deriving its thresholds: counters [65][64] + 256 thresholds
 constexpr int kStreamTiles = 8;     // hamming_scan_mfma: up to this many query tiles run as one pipeline across code steps
 static_assert(kQP >= (int)kHammingMaxBatch, "one pass covers a whole search call");
 
@@ -418,7 +419,8 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     const uint64_t* __restrict__ codes, size_t begin, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
     const uint32_t* __restrict__ tau, uint4* __restrict__ log,
     uint32_t* __restrict__ log_cnt, uint32_t log_cap, uint32_t* __restrict__ overflow, size_t strict_from,
-    const uint32_t* __restrict__ ids_ascending, uint32_t stream_tiles) {
+    const uint32_t* __restrict__ ids_ascending, uint32_t stream_tiles, const uint8_t* __restrict__ btab, uint32_t btab_groups,
+    uint32_t btab_stride, uint32_t bound_k, uint32_t* __restrict__ tau_out) {
     const uint32_t nthreads = blockDim.x, mw = nthreads >> 6;   // waves in this workgroup
     extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
     const uint32_t q0 = blockIdx.y * kQP;
@@ -460,6 +462,51 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     load_codes(xn, gwave + nwaves);
     // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) never hit.  The first round's inputs are requested
     // before the image is built, so that the prologue pays the global latency once, not twice.
+    // The stage behind the bound pass derives its thresholds itself (batches of up to 256 queries: btab != nullptr): per
+    // query the k-th smallest of the table's group minima, + the filter query's slack -- what hamming_bound_tau computes, a
+    // launch of its own worth 7 us of such a batch's 80.  Every workgroup repeats it (16 KB of table per 64 queries, from L2);
+    // workgroup 0 also publishes the thresholds for the rescan and the fallback tier.  64 queries per round: lane = query,
+    // the waves split the groups, [bin][lane] counters in LDS.
+    uint32_t* TAU = reinterpret_cast<uint32_t*>(mf_lds + (size_t)(ntiles + 2) * (1024 + 128)) + 65 * kWave;
+    if (btab) {
+        uint32_t* H = reinterpret_cast<uint32_t*>(mf_lds + (size_t)(ntiles + 2) * (1024 + 128));
+        for (uint32_t r0 = 0; r0 < nqp; r0 += kWave) {
+            for (uint32_t b = threadIdx.x; b < 65 * kWave; b += nthreads) H[b] = 0;
+            __syncthreads();
+            const uint32_t q = q0 + r0 + lane;
+            const uint32_t qc = q < nq ? q : nq - 1;
+            for (uint32_t g0 = wv; g0 < btab_groups; g0 += mw * 16) {
+                uint32_t d[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const uint32_t g = g0 + mw * u;
+                    d[u] = g < btab_groups ? btab[(size_t)g * btab_stride + qc] : 255u;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    if (d[u] <= 64u) atomicAdd(&H[d[u] * kWave + lane], 1u);
+            }
+            __syncthreads();
+            if (wv == 0) {
+                uint32_t cum = 0, t = 64;
+                bool done = false;
+                for (int b = 0; b < 65; b++) {
+                    cum += H[b * kWave + lane];
+                    if (!done && cum >= bound_k) {
+                        t = b;
+                        done = true;
+                    }
+                }
+                uint32_t slack;
+                (void)filter_query(queries[qc], slack);
+                t += slack;   // d(q, x) <= d(fq, x) + slack
+                t = t < 64u ? t : 64u;
+                TAU[r0 + lane] = t;
+                if (blockIdx.x == 0 && q < nq) tau_out[q] = t;
+            }
+            __syncthreads();
+        }
+    }
     uint64_t qv[4];
     uint32_t tv[4];
     auto thr_load = [&](uint32_t s0) {
@@ -468,7 +515,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
             const uint32_t s = s0 + u * nthreads, q = q0 + s;
             const bool live = s < ntiles * 32 && q < nq;
             qv[u] = live ? queries[q] : 0ull;
-            tv[u] = live ? (tau[q] < 64u ? tau[q] : 64u) : 0u;
+            tv[u] = !live ? 0u : btab ? TAU[s] : (tau[q] < 64u ? tau[q] : 64u);
         }
     };
     auto thr_store = [&](uint32_t s0) {
@@ -662,7 +709,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
 
 __global__ __launch_bounds__(kMW * 64) void hamming_bound_mfma(
     const uint64_t* __restrict__ codes, size_t end, const uint64_t* __restrict__ queries, uint32_t nq,
-    uint8_t* __restrict__ table, uint32_t table_stride) {
+    uint8_t* __restrict__ table, uint32_t table_stride, uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow) {
     const uint32_t nthreads = blockDim.x, mw = nthreads >> 6;
     extern __shared__ __attribute__((aligned(16))) uint8_t mf_lds[];
     const uint32_t q0 = blockIdx.y * kQP;
@@ -671,6 +718,12 @@ __global__ __launch_bounds__(kMW * 64) void hamming_bound_mfma(
     i32x4* QB = reinterpret_cast<i32x4*>(mf_lds);
     // [1 + tile][32]: largest (1088 + sum) seen for the query; row 0 takes the fold of "tile -1" (pipeline fill); 0 = nothing seen
     uint32_t* MX = reinterpret_cast<uint32_t*>(mf_lds + (size_t)(ntiles + 2) * 1024);
+    // (cand_cnt != nullptr: no hamming_bound_tau follows -- the first scan derives the thresholds -- so the candidate lists
+    // and the overflow flag are emptied here)
+    if (cand_cnt && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (uint32_t s = threadIdx.x; s < nq * kSub; s += nthreads) cand_cnt[s] = 0;
+        if (threadIdx.x == 0) *overflow = 0;
+    }
     build_query_image(QB, queries, nq, q0, ntiles, nthreads);
     for (uint32_t s = threadIdx.x; s < (ntiles + 2) * 32; s += nthreads) MX[s] = 0;
     __syncthreads();
@@ -909,7 +962,10 @@ constexpr int kFewQueries = 64;   // most queries the lane-per-code scan takes (
 static bool few_queries(size_t n, uint32_t nq) {
     // (round 4, 12.5 M codes, us per search lanes | matrix filter: 9 queries 79 | 90, 16: 92 | 89, 32: 124 | 90 -- the bound pass
     // of round 3 made the matrix filter's chain shorter, so it takes over earlier than the 40 measured in round 2)
-    uint32_t most = n >= (size_t)50'000'000 ? 12u : n >= (size_t)5'000'000 ? 12u : (uint32_t)kFewQueries;
+    // (round 4, after the matrix filter's short chain for batches of up to 256 queries: it is ahead from 9 queries on at every
+    // corpus size it applies to -- 0.3 M / 1.25 M / 12.5 M codes, 9 queries 41 / 43 / 66 us against 57 / 54 / 82 on the lanes,
+    // 12 queries 34 / 39 / 63 against 49 / 52 / 84; up to 8 queries with k <= 32 go to hamming_direct before they get here)
+    uint32_t most = n >= ((size_t)1 << 18) ? 8u : (uint32_t)kFewQueries;
     static const char* ov = getenv("UCFP_HAMMING_FEW");          // (tuning)
     if (ov) most = (uint32_t)atoi(ov);
     return nq <= most;
@@ -1252,7 +1308,17 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
     // batches on the matrix-core filter take their first bound from the filter itself (hamming_bound_mfma): the k-th
     // smallest of 256 group minima over the first 256 k codes -- as tight as two stages of lists used to make it
     p.bound = p.fast && !few_queries(n, nq) && k <= 64 && !getenv("UCFP_HAMMING_NO_BOUND");
-    if (p.bound) p.bound_n = (n < kBoundCodes ? n : kBoundCodes) & ~(size_t)(128 - 1);
+    // A batch of up to 256 queries is a chain of short launches, each worth 4-10 us whatever it does: a bound pass over 2^20
+    // codes and ONE stage over everything beat the 2^18 bound + two stages (12.5 M codes, round 4: 16 / 32 / 64 / 128 / 256
+    // queries 79 / 75 / 85 / 108 / 152 us -> 70 / 64 / 74 / 95 / 142; 2^19 and 2^21 within 2 us of that).  Only for k <= 16:
+    // the k-th of 256 group minima is a loose bound for large k, and the stages are what tightens it.
+    const bool short_chain = p.bound && nq <= 256 && k <= 16;
+    if (p.bound) {
+        size_t bc = short_chain ? (size_t)1 << 20 : kBoundCodes;
+        static const char* bl = getenv("UCFP_HAMMING_BOUND_LOG2_SMALL");   // (tuning)
+        if (bl && nq <= 256) bc = (size_t)1 << atoi(bl);
+        p.bound_n = (n < bc ? n : bc) & ~(size_t)(128 - 1);
+    }
     if (p.fast) {
         size_t e = p.bound ? p.bound_n : p.sample_n;
         // ranges grow 4x per stage (measured 2 / 3 / 4 / 6 / 8 / 16 / 32 at 10 M, 12.5 M and 100 M codes x 4096 queries:
@@ -1260,7 +1326,7 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         // for batches of 9 .. 256 queries, where 16x measured 5-20 % slower)
         // ... and 8 for batches of up to 256 queries, whose searches are chains of short launches (round 4, 12.5 M codes:
         // 16 / 64 / 128 queries 99 / 110 / 124 us at 4, 89 / 99 / 116 at 8, 91 / 101 / 116 at 16)
-        size_t growth = nq <= 256 ? 8 : 4;
+        size_t growth = short_chain ? 64 : nq <= 256 ? 8 : 4;
         static const char* gs = getenv("UCFP_HAMMING_GROWTH_SMALL");   // (tuning)
         if (gs && nq <= 256) growth = (size_t)atoi(gs);
         // (with the bound pass the first stage starts over at row 0, so there is one even when bound_n == n)
@@ -1345,6 +1411,9 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
     }
     // tau0: from the bound pass (matrix-core batches), else from the sample
     const bool few = few_queries(n, nq);
+    // batches of up to 256 queries: the first scan derives its thresholds from the bound table itself (one launch fewer)
+    static const bool no_fused_tau = getenv("UCFP_HAMMING_NO_FUSED_TAU") != nullptr;   // (bisecting)
+    const bool fused_tau = p.bound && nq <= 256 && !no_fused_tau;
     if (p.bound) {
         const size_t lds = hamming_mfma_lds_bytes(nq);
         if (lds > 48 * 1024)
@@ -1354,9 +1423,11 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
         unsigned mw = steps >= (size_t)kBoundGroups * kMW ? kMW : steps >= (size_t)kBoundGroups * 8 ? 8 : 4;
         const uint32_t stride = p.qgroups * kWave;
         hipLaunchKernelGGL(hamming_bound_mfma, dim3(kBoundGroups, (nq + kQP - 1) / kQP), dim3(mw * 64), lds, stream, codes,
-                           p.bound_n, queries, nq, ws + w.btab, stride);
-        hipLaunchKernelGGL(hamming_bound_tau, dim3(p.qgroups), dim3(256), 0, stream, (const uint8_t*)(ws + w.btab),
-                           kBoundGroups, stride, queries, nq, k, u32(w.tau0), u32(w.cand_cnt), u32(w.overflow));
+                           p.bound_n, queries, nq, ws + w.btab, stride, fused_tau ? u32(w.cand_cnt) : (uint32_t*)nullptr,
+                           u32(w.overflow));
+        if (!fused_tau)
+            hipLaunchKernelGGL(hamming_bound_tau, dim3(p.qgroups), dim3(256), 0, stream, (const uint8_t*)(ws + w.btab),
+                               kBoundGroups, stride, queries, nq, k, u32(w.tau0), u32(w.cand_cnt), u32(w.overflow));
     } else if (few) {
         (void)hipMemsetAsync(u32(w.hist), 0, (size_t)nq * 65 * 4, stream);
         hipLaunchKernelGGL(hamming_sample_hist_lanes, dim3((unsigned)((p.sample_n + 1023) / 1024)), dim3(256), 0, stream,
@@ -1415,10 +1486,12 @@ int launch_hamming_search(const uint64_t* codes, const uint64_t* ids, size_t n,
             } else {
             // every wave of the scan writes its slice's record count, and the slices of a launch are 0 .. wgs * passes *
             // mw - 1: the rescan covers exactly those (no memset of the counters)
-            hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(mw * 64), lds, stream, codes, begin, end,
-                               queries, nq, (const uint32_t*)tau_cur,
+            const bool derive = fused_tau && sidx == 0;
+            hipLaunchKernelGGL(hamming_scan_mfma, dim3(wgs, passes), dim3(mw * 64), lds + (derive ? kFusedTauLds : 0), stream,
+                               codes, begin, end, queries, nq, (const uint32_t*)tau_cur,
                                reinterpret_cast<uint4*>(ws + w.log), u32(w.log_cnt), p.log_cap, u32(w.overflow), strict_from,
-                               ids_ascending, stream_tiles);
+                               ids_ascending, stream_tiles, derive ? (const uint8_t*)(ws + w.btab) : (const uint8_t*)nullptr,
+                               kBoundGroups, p.qgroups * kWave, k, u32(w.tau0));
             hipLaunchKernelGGL(hamming_rescan, dim3(wgs * passes * mw, rescan_parts), dim3(kRescanThreads), 0, stream, codes, ids, begin, end, queries,
                                (const uint32_t*)tau_cur, reinterpret_cast<const uint4*>(ws + w.log),
                                (const uint32_t*)u32(w.log_cnt), p.log_cap, u32(w.cand_cnt), u32(w.cand_d),

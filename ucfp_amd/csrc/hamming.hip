@@ -301,22 +301,26 @@ constexpr size_t kFusedTauLds = 65 * 64 * 4 + 256 * 4;   // hamming_scan_mfma de
 constexpr int kStreamTiles = 8;     // hamming_scan_mfma: up to this many query tiles run as one pipeline across code steps
 static_assert(kQP >= (int)kHammingMaxBatch, "one pass covers a whole search call");
 
-// FP4 operand words of a 32-bit half: dword j nibble i <- bit 4 i + j.  Codes: 1 -> 0x2 (+1.0), 0 -> 0x0 (0.0).
+// FP4 (E2M1) operand words of a 32-bit half: dword j nibble i <- bit 4 i + j.  A code bit is left IN PLACE inside its nibble
+// where that is a valid magnitude -- bit 0 -> 0x1 (0.5), bit 1 -> 0x2 (1.0), bit 2 -> 0x4 (2.0); only bit 3 (the sign
+// position) is moved, to 0x2 -- and the query image carries the reciprocal magnitude at the same position (+-2.0, +-1.0,
+// +-0.5, +-1.0), so that every product is +-1 or 0 exactly.  5 vector instructions per half instead of 7: a batch of one
+// query tile is bound by vector issue (round 4: 100 instructions per 128-code step against 4 matrix instructions).
 __device__ __forceinline__ i32x4 expand_code_fp4(uint32_t w) {
     i32x4 v;
-    v[0] = (int)((w << 1) & 0x22222222u);
+    v[0] = (int)(w & 0x11111111u);
     v[1] = (int)(w & 0x22222222u);
-    v[2] = (int)((w >> 1) & 0x22222222u);
+    v[2] = (int)(w & 0x44444444u);
     v[3] = (int)((w >> 2) & 0x22222222u);
     return v;
 }
-// Queries: 1 -> 0x2 (+1.0), 0 -> 0xA (-1.0).
+// Queries: 1 -> +m, 0 -> -m (sign = bit 3 of the nibble), m = 2.0 (0x4) / 1.0 (0x2) / 0.5 (0x1) / 1.0 (0x2) for dwords 0..3.
 __device__ __forceinline__ i32x4 expand_query_fp4(uint32_t w) {
     const uint32_t n = ~w;
     i32x4 v;
-    v[0] = (int)(0x22222222u | ((n << 3) & 0x88888888u));
+    v[0] = (int)(0x44444444u | ((n << 3) & 0x88888888u));
     v[1] = (int)(0x22222222u | ((n << 2) & 0x88888888u));
-    v[2] = (int)(0x22222222u | ((n << 1) & 0x88888888u));
+    v[2] = (int)(0x11111111u | ((n << 1) & 0x88888888u));
     v[3] = (int)(0x22222222u | (n & 0x88888888u));
     return v;
 }
@@ -457,9 +461,30 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     // The codes of the wave's first two steps leave before the prologue: a batch of a few dozen queries is one query tile, a
     // wave's whole share of a 12.5 M-code shard is 20 steps of ~300 ns, and the memory latency of a step's codes (2-3 us
     // under load) then needs TWO steps of lead -- with one the last stage of 32 queries ran at 2.5 TB/s.
+    // The few-tile path reads through a buffer descriptor rebuilt per step from wave-uniform values (first row of the step,
+    // bytes of it that exist): the per-lane part of the address is one constant register, rows past the end read as zero
+    // by the hardware's range check, and the step's 64-bit address arithmetic + four guards (28 of its 100 vector
+    // instructions) become scalar work.
+    const uint32_t voff = (uint32_t)(nn * 8 + hh * 4);
+    auto load_codes_buf = [&](uint32_t (&x)[kTB], size_t st) {
+        const size_t row0 = begin + st * kStep;
+        const size_t left = st < nsuper ? end - row0 : 0;
+        const uint32_t bytes = (uint32_t)(left < (size_t)kStep ? left : (size_t)kStep) * 8u;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(codes + row0), 0, (int)bytes, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < kTB; b++) x[b] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 256u * b, 0, 2 /* nt */);
+    };
+    const bool few_tiles = ntiles <= stream_tiles;   // (kernel-uniform)
+    // (two buffers, used alternately by the few-tile path: a buffer is refilled for the step after next as soon as its
+    // codes are expanded -- copying "next" into "current" instead would wait for the next step's codes a whole step early)
     uint32_t x[kTB], xn[kTB];
-    load_codes(x, gwave);
-    load_codes(xn, gwave + nwaves);
+    if (few_tiles) {
+        load_codes_buf(x, gwave);
+        load_codes_buf(xn, gwave + nwaves);
+    } else {
+        load_codes(x, gwave);
+    }
     // thresholds popc(q) - tau[q]; dead columns (and the pad tiles) never hit.  The first round's inputs are requested
     // before the image is built, so that the prologue pays the global latency once, not twice.
     // The stage behind the bound pass derives its thresholds itself (batches of up to 256 queries: btab != nullptr): per
@@ -579,7 +604,7 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         }
         ln++;
     };
-    if (ntiles <= stream_tiles) {
+    if (few_tiles) {
         // Few query tiles (a batch of up to 256 queries): ONE pipeline over all (code step, query tile) pairs of the wave --
         // the fold inside a step tests the previous pair's results, whichever code step that was, and a single pad tile
         // drains the pipeline at the very end.  The loop below drains after every code step, which for one query tile is
@@ -600,13 +625,10 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
         i32x4 bcur = QB[lane], bnext;
         uint32_t thr_cur = THR[nn], thr_next;
         uint32_t thr_prev = kNever, tile_prev = 0, off_prev = 0;   // the very first fold reads the zeroed accumulators
-        for (size_t st = gwave; st < nsuper; st += nwaves) {
+        auto code_step = [&](uint32_t (&xb)[kTB], size_t st) {
 #pragma unroll
-            for (int b = 0; b < kTB; b++) {
-                A[b] = expand_code_fp4(x[b]);
-                x[b] = xn[b];
-            }
-            load_codes(xn, st + 2 * nwaves);
+            for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(xb[b]);
+            load_codes_buf(xb, st + 2 * nwaves);
             const uint32_t off = (uint32_t)(st * kStep);
             const uint32_t dlt = strict_rows && begin + st * kStep >= strict_from ? 0x00010001u : 0u;
             for (uint32_t t = 0; t < ntiles; t++) {
@@ -617,6 +639,11 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
                 bcur = bnext;
                 thr_cur = thr_next;
             }
+        };
+        for (size_t st = gwave; st < nsuper; st += 2 * nwaves) {
+            code_step(x, st);
+            if (st + nwaves >= nsuper) break;
+            code_step(xn, st + nwaves);
         }
         if (gwave < nsuper) {   // wave-uniform
             bcur = QB[ntiles * 64 + lane];   // a pad tile: all zero
@@ -631,11 +658,8 @@ __global__ __launch_bounds__(kMW * 64) void hamming_scan_mfma(
     for (size_t st = gwave; st < nsuper; st += nwaves) {
         i32x4 A[kTB];
 #pragma unroll
-        for (int b = 0; b < kTB; b++) {
-            A[b] = expand_code_fp4(x[b]);
-            x[b] = xn[b];
-        }
-        load_codes(xn, st + 2 * nwaves);   // the codes of the step after next travel while this one and the next compute
+        for (int b = 0; b < kTB; b++) A[b] = expand_code_fp4(x[b]);
+        load_codes(x, st + nwaves);   // next step's codes travel while this one computes
         const uint32_t off = (uint32_t)(st * kStep);   // row - begin of code tile 0 (the span is < 2^32)
         const uint32_t dlt = strict_rows && begin + st * kStep >= strict_from ? 0x00010001u : 0u;   // wave-uniform
         // Software pipeline over the query tiles: per pair of code tiles, the v_pk_maximum3 folding query tile t-1's

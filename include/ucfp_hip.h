@@ -492,7 +492,10 @@ int ucfp_index_search_dev(ucfp_index* idx, uint32_t tenant, const void* d_querie
  * ITS OWN query (a u64 hash, or dim floats) and ITS OWN k (QueryRequest.k, src/server/dto.rs:74-87) -- become ONE copy of the
  * queries + ONE ucfp_index_search_dev with the largest k of the batch + one copy of the results; a request gets the first k
  * entries of its row (the order is total: (distance, id) / (score desc, id)).  One batcher per (index, tenant); at most
- * max_batch (<= 4096) queries per flush, flushed no later than max_delay_us after the first pending query.
+ * max_batch (<= 4096) queries per flush, flushed no later than max_delay_us after the first pending query.  (All batchers:
+ * behind a flush that carried several requests the next one waits up to 10 us -- or until as many requests have arrived
+ * as that flush carried -- even with max_delay_us = 0: its submitters are on their way back with their next request.  A
+ * lone sequential client is flushed at once.)
  *   out_ids / out_scores / out_dist   k entries each (scores, dist may be NULL); places past *out_count carry
  *                                     UCFP_INVALID_ID / -1 / 2^32 - 1 like ucfp_index_search. */
 typedef struct ucfp_search_batcher ucfp_search_batcher;

@@ -54,7 +54,7 @@ def main():
     ctx = _lib.default_context(0)
     rng = np.random.default_rng(1)
     prng = random.Random(2)
-    each = a.seconds / 4
+    each = a.seconds / 6
     # text
     docs = [" ".join(prng.choice(WORDS) for _ in range(prng.choice([3, 40, 300, 1500]))) for _ in range(400)]
     docs += ["Café naïve — " + d for d in docs[:40]]
@@ -89,7 +89,43 @@ def main():
     b = image.PngBatcher(48, 48, image.PIX_RGB8, max_batch=32, max_bytes=100_000, max_delay_us=0, ctx=ctx)
     n4 = hammer("png", b.submit, pngs, refs, each, a.threads)
     b.close()
-    print(f"soak ok: {n1} documents, {n2} frames, {n3} clips, {n4} PNG uploads through the batchers from {a.threads} threads")
+    # uploads of any kind and size through ONE batcher (round 4): PNG + JPEG of mixed geometries, host kinds in between
+    ups = list(pngs[:30])
+    for i in range(90):
+        h, w = int(rng.integers(32, 260)), int(rng.integers(32, 330))
+        arr = rng.integers(0, 256 >> (i % 4), (h, w, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        if i % 3 == 0:
+            Image.fromarray(arr, "RGB").save(buf, "PNG", compress_level=i % 10)
+        elif i % 3 == 1:
+            Image.fromarray(arr, "RGB").save(buf, "JPEG", quality=40 + i % 55, subsampling=i % 3)
+        else:
+            Image.fromarray(arr, "RGB").save(buf, ["BMP", "GIF", "JPEG"][i % 9 // 3], **({"progressive": True} if i % 9 // 3 == 2 else {}))
+        ups.append(buf.getvalue())
+    recs, st = image.fingerprint_uploads(ups, ctx=ctx)
+    refs = [(recs[i].tobytes(), int(st[i])) for i in range(len(ups))]
+    b = image.UploadBatcher(max_batch=24, max_bytes=400_000, max_delay_us=0, ctx=ctx)
+    n5 = hammer("upload", b.submit, ups, refs, each, a.threads)
+    b.close()
+    # the query route (round 4): one query and its own k per request against a resident Hamming shard
+    from ucfp_amd import index
+    codes = rng.integers(0, 2**63, 600_000, dtype=np.uint64)
+    ids = np.arange(600_000, dtype=np.uint64) + np.uint64(7)
+    ix = index.DeviceIndex(index.HAMMING64, ctx=ctx)
+    ix.upsert(0, ids, codes)
+    qs = [(int(codes[int(rng.integers(0, 600_000))]) ^ (1 << int(rng.integers(0, 63))), int(rng.choice([1, 3, 10, 17, 32]))) for _ in range(300)]
+    refs = []
+    for q, k in qs:
+        gi, _, gd, _ = ix.search(0, np.array([q], dtype=np.uint64), k)
+        refs.append((gi[0].tobytes(), gd[0].tobytes()))
+    sb = index.SearchBatcher(ix, 0, max_batch=40, max_delay_us=0)
+    n6 = hammer("search", lambda qk: (lambda r: (np.ascontiguousarray(np.pad(r[0], (0, qk[1] - len(r[0])), constant_values=np.uint64(2**64 - 1))).tobytes(),
+                                                  np.ascontiguousarray(np.pad(r[2], (0, qk[1] - len(r[2])), constant_values=np.uint32(2**32 - 1))).tobytes()))(sb.submit(*qk)),
+                qs, refs, each, a.threads)
+    sb.close()
+    ix.close()
+    print(f"soak ok: {n1} documents, {n2} frames, {n3} clips, {n4} PNG uploads, {n5} mixed uploads, {n6} searches through the batchers "
+          f"from {a.threads} threads")
 
 
 if __name__ == "__main__":

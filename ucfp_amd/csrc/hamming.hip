@@ -1341,6 +1341,8 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         size_t bc = short_chain ? (size_t)1 << 20 : kBoundCodes;
         static const char* bl = getenv("UCFP_HAMMING_BOUND_LOG2_SMALL");   // (tuning)
         if (bl && nq <= 256) bc = (size_t)1 << atoi(bl);
+        static const char* bg = getenv("UCFP_HAMMING_BOUND_LOG2_LARGE");   // (tuning)
+        if (bg && nq > 256) bc = (size_t)1 << atoi(bg);
         p.bound_n = (n < bc ? n : bc) & ~(size_t)(128 - 1);
     }
     if (p.fast) {
@@ -1353,6 +1355,8 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         size_t growth = short_chain ? 64 : nq <= 256 ? 8 : 4;
         static const char* gs = getenv("UCFP_HAMMING_GROWTH_SMALL");   // (tuning)
         if (gs && nq <= 256) growth = (size_t)atoi(gs);
+        static const char* gl = getenv("UCFP_HAMMING_GROWTH_LARGE");   // (tuning)
+        if (gl && nq > 256) growth = (size_t)atoi(gl);
         // (with the bound pass the first stage starts over at row 0, so there is one even when bound_n == n)
         do {
             e = e * growth < n ? e * growth : n;

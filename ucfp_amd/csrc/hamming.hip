@@ -6,7 +6,10 @@
 // ordered by (d ascending, record_id ascending); at most k per query.
 //
 // Three scans share one structure (an upper bound tau[q] on the final k-th distance turns the search into a
-// filter; bounds come from a 32k-code sample, then from the candidates found so far, over ranges growing 4x):
+// filter; bounds come from the matrix cores' own bound pass (hamming_bound_mfma: k-th smallest of 256 group minima) or, for
+// the lane and robust tiers, from a 32k-code sample, then from the candidates found so far, over ranges growing 4x.  Batches
+// of 9 .. 256 queries with k <= 16 -- what the search micro-batcher sends -- run a SHORT chain: bound pass over 2^20 codes,
+// ONE filter stage over the whole shard whose scan derives its thresholds itself, rescan, selection: 6 launches):
 //   many queries   hamming_scan_mfma   the pair distance as a +-1 x 0/1 contraction on the matrix cores (FP4
 //                                      operands, exact); suspect blocks are logged and re-evaluated exactly by hamming_rescan
 //   few queries    hamming_scan_lanes  lane = code, queries in SGPRs: a pure HBM stream
@@ -16,7 +19,8 @@
 //                                      any batch whose lists or logs overflowed.  Results never depend on the
 //                                      heuristics of the other two.
 // Kernels in pipeline order:
-//   hamming_sample_hist[_lanes] / hist_reduce / tau0   k-th smallest sampled distance per query
+//   hamming_bound_mfma (+ hamming_bound_tau above 256 queries)   first thresholds of matrix-core batches
+//   hamming_sample_hist[_lanes] / hist_reduce / tau0   k-th smallest sampled distance per query (lane and robust tiers)
 //   per stage: hamming_scan_mfma + hamming_rescan  (or hamming_scan_lanes), hamming_list_tau
 //   hamming_final_select                               top-k of the candidate lists by (d, id)
 //   hamming_scan + topk_merge_u32                      robust tier / fallback

@@ -126,3 +126,32 @@ def test_out_of_range_coefficients_go_to_the_host(oracle):
             seen.add(rc)
     assert oracle.JPG_NEEDS_HOST in seen
     assert oracle.jpeg_decode_luma(with_quantiser(jpeg_of(img, quality=95), 255))[0] == oracle.JPG_NEEDS_HOST
+
+
+def test_j1_luma_route_vs_rgb_route_hash_distance(oracle):
+    """DESIGN J1 hashes a JPEG's coded Y plane; the reference decodes to RGB and lets the SDK grey it.  How far
+    apart are the two routes' hashes?  Natural-statistics pictures (smooth gradients + texture), qualities 50-95, the three
+    common samplings: per 64-bit hash the two routes differ by a fraction of a bit on average -- the Y plane IS the luma of
+    the decoded RGB up to chroma-upsampling and rounding noise, which the 8x8 / 32x32 box means average away.  The bound
+    asserted here is what a near-duplicate threshold (the reference's UI uses <= 10 of 64 bits) has to absorb."""
+    rng = np.random.default_rng(12)
+    tot_bits, n_hash, worst = 0, 0, 0
+    for i in range(24):
+        h, w = int(rng.integers(120, 400)), int(rng.integers(120, 400))
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(xx / (17 + i) + c) * np.cos(yy / (23 + 2 * i) - c) for c in range(3)], -1)
+        img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+        jpg = jpeg_of(img, quality=int(rng.integers(50, 96)), subsampling=i % 3)
+        y = libjpeg_luma(jpg)
+        rgb = np.asarray(PIL.open(io.BytesIO(jpg)).convert("RGB"))
+        ra, _ = oracle.image_hash_batch(y[None], 7, pixfmt=0)
+        rb, _ = oracle.image_hash_batch(rgb[None], 7, pixfmt=1)
+        a = np.frombuffer(ra[0].tobytes()[32:], dtype="<u8")      # global + 16 block hashes
+        b = np.frombuffer(rb[0].tobytes()[32:], dtype="<u8")
+        d = [bin(int(x) ^ int(z)).count("1") for x, z in zip(a, b)]
+        tot_bits += sum(d)
+        n_hash += len(d)
+        worst = max(worst, max(d))
+    mean = tot_bits / n_hash
+    print(f"J1 vs RGB route: mean {mean:.3f} bits of 64 per hash, worst {worst} over {n_hash} hashes")
+    assert mean <= 1.0 and worst <= 8, (mean, worst)

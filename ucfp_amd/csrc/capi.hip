@@ -126,6 +126,9 @@ int ucfp_ctx_create(int device_id, ucfp_ctx** out) {
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->audio_done, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->png_done, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->norm_done, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming);
     for (int i = 0; i < 2 && e2 == hipSuccess; i++) e2 = hipEventCreateWithFlags(&c->item_used[i], hipEventDisableTiming);
     if (const char* v = getenv("UCFP_IMAGE_ANY_MAX_PIXELS")) c->any_max_pixels = (size_t)strtoull(v, nullptr, 10);   // (tuning)
     if (e2 != hipSuccess) {
@@ -146,6 +149,9 @@ void ucfp_ctx_destroy(ucfp_ctx* c) {
     if (c->audio_ws) (void)hipFree(c->audio_ws);
     if (c->audio_done) (void)hipEventDestroy(c->audio_done);
     if (c->png_done) (void)hipEventDestroy(c->png_done);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+    if (c->side_join) (void)hipEventDestroy(c->side_join);
     if (c->png_ws) (void)hipFree(c->png_ws);
     if (c->b3_ws) (void)hipFree(c->b3_ws);
     if (c->norm_done) (void)hipEventDestroy(c->norm_done);

@@ -37,6 +37,10 @@ struct ucfp_ctx {
     uint8_t* png_ws = nullptr;
     size_t png_ws_cap = 0;
     hipEvent_t png_done = nullptr;
+    // mixed uploads: the JPEG chain runs on `side` beside the PNG chain (a few hundred one-wave inflates leave most of the
+    // chip idle for tens of milliseconds); forked from and joined into the caller's stream with these two events
+    hipStream_t side = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     // BLAKE3 chaining values of the last batch (+ the digests when the PNG call computes `exact` itself); ordered by png_done
     uint8_t* b3_ws = nullptr;
     size_t b3_ws_cap = 0;

@@ -455,15 +455,27 @@ def bench_upload_mix(dev, ctx, n_img=300, threads=64):
     for i in [k for k in range(n) if st[k] == 0][:12]:
         same = same and bytes(image.fingerprint(files[i], 0, i).fingerprint) == rec[i].tobytes()
     # one batcher, many request threads
-    bt = image.UploadBatcher(max_batch=512, max_bytes=512 << 20, max_delay_us=200, ctx=ctx)
+    bt = image.UploadBatcher(max_batch=512, max_bytes=128 << 20, max_delay_us=200, ctx=ctx)
+
+    def timed(f):
+        t = time.perf_counter()
+        r = bt.submit(f)
+        return r, time.perf_counter() - t
     with ThreadPoolExecutor(max_workers=threads) as pool:
         list(pool.map(bt.submit, files[:threads]))
         t0 = time.perf_counter()
-        res = list(pool.map(bt.submit, files * 2))
+        res_t = list(pool.map(timed, files * 2))
         dt = time.perf_counter() - t0
+    res = [r for r, _ in res_t]
     batches, items = bt.stats()
     bt.close()
     same_b = all(r[0] == rec[i % n].tobytes() and r[1] == st[i % n] for i, r in enumerate(res))
+    # request latency by kind (device-decoded uploads only): PNG and JPEG coalesce in lanes of their own inside the batcher
+    lat = {"png": [], "jpeg": []}
+    for i, (r, t) in enumerate(res_t):
+        if r[1] == 0:
+            lat["png" if files[i % n][:4] == b"\x89PNG" else "jpeg"].append(t)
+    lat_ms = {k: {"median": float(np.median(v)) * 1e3, "p90": float(np.percentile(v, 90)) * 1e3} for k, v in lat.items() if v}
     return {"what": f"{n} uploads, sides log-uniform 64-2048 px, 47 % PNG (RGB) / 47 % baseline JPEG / 6 % kinds the device hands "
                     "back (progressive JPEG, 16-bit PNG, BMP); records = 536-B bundles",
             "files": n, "encoded_MB": enc_bytes / 1e6, "decoded_MB": px_bytes / 1e6,
@@ -471,6 +483,7 @@ def bench_upload_mix(dev, ctx, n_img=300, threads=64):
                          "decoded_pixel_GBs": px_bytes / ms / 1e6},
             "needs_host": needs_host, "needs_host_share": needs_host / n, "rejected": int((st < 0).sum()),
             "batcher": {"request_threads": threads, "images_per_s": 2 * n / dt, "batches": batches, "items": items,
+                        "request_latency_ms": lat_ms,
                         "note": "Python request threads (ctypes releases the GIL inside submit); host memory in and out"},
             "records_equal_per_request_host_path": bool(same), "batcher_records_equal_resident_call": bool(same_b)}
 

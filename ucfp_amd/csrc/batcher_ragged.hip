@@ -185,8 +185,13 @@ struct ucfp_audio_batcher {
 struct ucfp_png_batcher {
     Ragged r;
 };
+// Two lanes behind one handle: PNG uploads coalesce in `r` (the caller's context), JPEG uploads in `rj` on a context of the
+// batcher's own (its own decode workspace and streams), so the two kinds' flushes run side by side.  A PNG is one wave's tens
+// of milliseconds of serial inflate whatever the batch; a JPEG flush takes a few -- in one lane every JPEG request waited
+// for the largest PNG that happened to share its flush.
 struct ucfp_upload_batcher {
-    Ragged r;
+    Ragged r, rj;
+    ucfp_ctx* jctx = nullptr;
 };
 
 extern "C" {
@@ -334,26 +339,39 @@ int ucfp_upload_batcher_create(ucfp_ctx* ctx, uint32_t algo, const ucfp_image_pr
         return capi_fail(UCFP_E_INVALID, "batcher needs 1 <= max_batch <= 65536 and 1 <= max_bytes < 2^32");
     ucfp_upload_batcher* b = new (std::nothrow) ucfp_upload_batcher();
     if (!b) return capi_fail(UCFP_E_INDEX, "out of host memory");
-    Ragged& r = b->r;
-    r.ctx = ctx;
-    r.device = ucfp::ctx_device(ctx);
-    r.kind = kUploadHash;
-    r.algo = algo;
-    if (pre) r.pre = *pre;
-    r.unit = 1;
-    r.rec = rec;
-    r.max_batch = max_batch;
-    r.max_units = max_bytes;
-    for (int s = 0; s < 2; s++) {
-        r.h_info[s] = new (std::nothrow) ucfp_upload_info[max_batch];
-        if (!r.h_info[s]) {
-            teardown(&b->r);
-            delete b;
-            return capi_fail(UCFP_E_INDEX, "out of host memory");
+    int rc = ucfp_ctx_create(ucfp::ctx_device(ctx), &b->jctx);
+    if (rc) {
+        delete b;
+        return rc;
+    }
+    bool started[2] = {false, false};
+    for (int lane = 0; lane < 2 && rc == UCFP_OK; lane++) {
+        Ragged& r = lane ? b->rj : b->r;
+        r.ctx = lane ? b->jctx : ctx;
+        r.device = ucfp::ctx_device(ctx);
+        r.kind = kUploadHash;
+        r.algo = algo;
+        if (pre) r.pre = *pre;
+        r.unit = 1;
+        r.rec = rec;
+        r.max_batch = max_batch;
+        r.max_units = max_bytes;
+        for (int s = 0; s < 2; s++) {
+            r.h_info[s] = new (std::nothrow) ucfp_upload_info[max_batch];
+            if (!r.h_info[s]) rc = capi_fail(UCFP_E_INDEX, "out of host memory");
+        }
+        if (rc == UCFP_OK) {
+            rc = start(&r, max_delay_us);       // (tears the lane down itself when it fails)
+            started[lane] = rc == UCFP_OK;
         }
     }
-    const int rc = start(&b->r, max_delay_us);
     if (rc) {
+        if (started[0]) teardown(&b->r);
+        for (int s = 0; s < 2; s++) {
+            if (!started[0]) delete[] b->r.h_info[s], b->r.h_info[s] = nullptr;
+            if (!started[1]) delete[] b->rj.h_info[s], b->rj.h_info[s] = nullptr;
+        }
+        ucfp_ctx_destroy(b->jctx);
         delete b;
         return rc;
     }
@@ -364,15 +382,17 @@ int ucfp_upload_batcher_create(ucfp_ctx* ctx, uint32_t algo, const ucfp_image_pr
 void ucfp_upload_batcher_destroy(ucfp_upload_batcher* b) {
     if (!b) return;
     teardown(&b->r);
+    teardown(&b->rj);
+    ucfp_ctx_destroy(b->jctx);
     delete b;
 }
 
 int ucfp_upload_batcher_submit(ucfp_upload_batcher* b, const uint8_t* bytes, size_t len, uint8_t* out, int32_t* status) {
     if (!b || !out || (len && !bytes)) return capi_fail(UCFP_E_INVALID, "batcher/bytes/out is NULL");
-    Ragged& r = b->r;
     // the request thread looks at its own upload: what the device does not decode never takes a slot
     ucfp_upload_info info;
     const int pst = ucfp_image_probe(bytes, len, &info);
+    Ragged& r = info.format == UCFP_UPLOAD_JPEG ? b->rj : b->r;
     if (pst != UCFP_OK || len > r.max_units) {
         memset(out, 0, r.rec);
         if (status) *status = pst != UCFP_OK ? pst : UCFP_IMAGE_NEEDS_HOST;     // (larger than a whole batch: the host path)
@@ -397,7 +417,11 @@ int ucfp_upload_batcher_submit(ucfp_upload_batcher* b, const uint8_t* bytes, siz
 
 int ucfp_upload_batcher_stats(ucfp_upload_batcher* b, uint64_t* batches, uint64_t* items) {
     if (!b) return capi_fail(UCFP_E_INVALID, "batcher is NULL");
-    b->r.core.stats(batches, items);
+    uint64_t bp = 0, ip = 0, bj = 0, ij = 0;
+    b->r.core.stats(&bp, &ip);
+    b->rj.core.stats(&bj, &ij);
+    if (batches) *batches = bp + bj;
+    if (items) *items = ip + ij;
     return UCFP_OK;
 }
 

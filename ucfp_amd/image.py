@@ -339,7 +339,7 @@ class UploadBatcher:
     PNG, JPEG, anything; nothing is announced at creation -- and the library coalesces what the device decodes into one
     copy + decode + ragged hash per flush.  status NEEDS_HOST: decode that upload on the host (`fingerprint_with`)."""
 
-    def __init__(self, *, algo: int = MULTI, max_batch: int = 1024, max_bytes: int = 256 << 20, max_delay_us: int = 0,
+    def __init__(self, *, algo: int = MULTI, max_batch: int = 1024, max_bytes: int = 64 << 20, max_delay_us: int = 0,
                  preprocess: Optional[PreprocessConfig] = None, ctx=None):
         self._lib = _lib.load()
         self.ctx = ctx or _lib.current_context()

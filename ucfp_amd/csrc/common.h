@@ -85,6 +85,7 @@ __device__ __forceinline__ UpItem up_item(const UpItem* __restrict__ items, cons
 // png.hip
 struct PngWs {
     size_t zbuf = 0, info = 0, raw = 0, raw_stride = 0, raw_n = 0, total = 0;
+    size_t tok = 0, tinfo = 0;      // two-pass inflate: 16-bit token words (2 bytes per filtered byte at most), per-file counts
 };
 size_t png_ws_bytes(size_t n, size_t png_bytes, uint32_t w, uint32_t h, int pixfmt, PngWs* ws);
 int launch_png_decode(const uint8_t* png, const uint64_t* offsets, size_t n, uint32_t w, uint32_t h, int pixfmt, uint8_t* ws,

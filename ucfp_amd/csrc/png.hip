@@ -942,6 +942,594 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
     }
 }
 
+// ================= two-pass inflate (round 4): Huffman decoding by several waves per file, then LZ77 ================
+// png_inflate_kernel above is bound by its own latencies: a parse step is ~1000 cycles of dependent LDS round trips, one wave
+// per file means one wave per SIMD at a thousand files, and its 22-62 KB of LDS per wave (tables + stage + match list +
+// window) rule out a second wave.  The split:
+//   png_huff_kernel<BITS, W>   W waves per file: the same speculation rounds over W x 64 subsequences (the chain of
+//                              "start == predecessor's exit" crosses waves through LDS), and the accepted parse is written as
+//                              TOKENS to global memory -- 16-bit words: a literal is its byte; a match is 0x8000 | (len - 3)
+//                              followed by dist - 1 (a word is a distance iff the word before it has bit 15 set: distances
+//                              are < 2^15, so the stream can be cut anywhere).  LDS: tables + stage only.
+//   png_lz_kernel              one wave per file: 1024 token words per round -> literals and the match list in LDS, matches
+//                              resolved as before (resolve_matches), bytes flushed, Adler-32 checked.
+struct PngTok {
+    uint32_t ntok;      // 16-bit token words written
+    uint32_t end_bit;   // bit position behind the last block (the Adler-32 follows at the next byte boundary)
+};
+
+struct Parse2 {
+    uint32_t start, exit, packed, ntok;      // packed as Parse; ntok: token words (1 per literal, 2 per match)
+    __device__ __forceinline__ uint32_t nbytes() const { return packed & 0x1ffffu; }
+    __device__ __forceinline__ bool eob() const { return (packed >> 30) & 1u; }
+    __device__ __forceinline__ bool err() const { return packed >> 31; }
+    __device__ __forceinline__ bool stopped() const { return packed >> 30; }
+};
+
+template <int BITS, int W>
+struct HuffLds {
+    static constexpr int kStageWords = W * 64 * BITS / 32 + 64;      // W x 64 subsequences + overshoot + the fetch window
+    uint32_t lit[1 << kRoot];
+    uint32_t dst[1 << kDRoot];
+    uint32_t stage[kStageWords];
+    uint16_t ll_sorted[288];
+    uint16_t d_sorted[32];
+    uint16_t ll_count[16];
+    uint16_t d_count[16];
+    uint8_t lens[320];
+    uint32_t xexit[2][W], xfirst[2][W], xstop[2][W];   // per chain iteration (parity): last lane's exit, first dirty / stopped lane
+    alignas(8) uint32_t wsum[2][W];                     // workgroup scans (W 64-bit sums)
+    uint32_t bc[12];                                    // broadcasts of uniform decisions
+};
+
+// parse_sub for the token kernel: EMIT = false counts (bytes, matches, token words), EMIT = true writes the tokens.
+template <bool EMIT, class LT>
+__device__ __forceinline__ Parse2 parse_tok(LT& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint16_t* __restrict__ tok) {
+    uint32_t pos = start, nb = 0, nm = 0, nt = 0, flags = 0;
+    bool act = pos < limit;
+    while (__ballot(act)) {
+        const uint32_t p = act ? pos : start;
+        const uint32_t w = p >> 5, sh = p & 31;
+        const uint32_t w0 = L.stage[w], w1 = L.stage[w + 1], w2 = L.stage[w + 2];
+        const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, sh), x2 = __builtin_amdgcn_alignbit(w2, w1, sh);
+        uint32_t e = L.lit[x & ((1u << kRoot) - 1)];
+        if (__ballot(act && (e >> 24) == kSlow)) {
+            if ((e >> 24) == kSlow) e = slow_code32(x, L.ll_count, L.ll_sorted, false);
+        }
+        const uint32_t cl = (e >> 20) & 15u, kind = e >> 24, ex = (e >> 16) & 15u;
+        const uint32_t s1 = cl + ex;
+        const bool is_len = kind == kLen;
+        const uint32_t len = (e & 0xffffu) + ((x >> cl) & ((1u << ex) - 1u));
+        uint32_t adv = s1, dist = 0;
+        bool bad = cl == 0;
+        if (__ballot(act && is_len)) {
+            const uint32_t y = __builtin_amdgcn_alignbit(x2, x, s1);
+            uint32_t d = L.dst[y & ((1u << kDRoot) - 1)];
+            if (__ballot(act && is_len && (d >> 24) == kSlow)) {
+                if (is_len && (d >> 24) == kSlow) d = slow_code32(y, L.d_count, L.d_sorted, true);
+            }
+            const uint32_t dl = (d >> 20) & 15u, dex = (d >> 16) & 15u;
+            dist = (d & 0xffffu) + ((y >> dl) & ((1u << dex) - 1u));
+            adv = is_len ? s1 + dl + dex : adv;
+            bad = bad || (is_len && dl == 0);
+        }
+        const bool lit = kind == kLit, eob = kind == kEob;
+        const bool go = act && !bad;
+        if (EMIT) {
+            if (go && lit) tok[nt] = (uint16_t)(e & 0xffu);
+            if (go && is_len) {
+                if (dist > out_pos + nb) flags |= 2u;          // reaches back before the first byte of the image
+                tok[nt] = (uint16_t)(0x8000u | (len - 3u));
+                tok[nt + 1] = (uint16_t)(dist - 1u);
+            }
+        }
+        flags |= (act && bad) ? 2u : 0u;
+        flags |= (go && eob) ? 1u : 0u;
+        pos += go ? adv : 0u;
+        nb += (go && lit) ? 1u : (go && is_len) ? len : 0u;
+        nm += (go && is_len) ? 1u : 0u;
+        nt += (go && lit) ? 1u : (go && is_len) ? 2u : 0u;
+        act = go && !eob && pos < limit;
+    }
+    return Parse2{start, pos, nb | nm << 17 | flags << 30, nt};
+}
+
+struct ParseCache2 {
+    static constexpr int kWays = 4;
+    Parse2 way[kWays];
+    int next;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < kWays; i++) way[i] = Parse2{0xffffffffu, 0, 0, 0};
+        next = 0;
+    }
+    __device__ __forceinline__ bool find(uint32_t start, Parse2* out) const {
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < kWays; i++)
+            if (way[i].start == start) {
+                *out = way[i];
+                hit = true;
+            }
+        return hit;
+    }
+    __device__ __forceinline__ void put(const Parse2& p) {
+#pragma unroll
+        for (int i = 0; i < kWays; i++)
+            if (next == i) way[i] = p;
+        next = (next + 1) & (kWays - 1);
+    }
+};
+
+// W waves per file: zlib stream -> token words.
+template <int BITS, int W>
+__global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets, size_t n,
+                                                         const UpItem* __restrict__ items, UpUniform uni, PngInfo* __restrict__ info,
+                                                         uint16_t* __restrict__ tokens, PngTok* __restrict__ tinfo) {
+    using LT = HuffLds<BITS, W>;
+    __shared__ LT L;
+    constexpr int T = 64 * W;
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (info[img].status != 0) return;
+    const UpItem item = up_item(items, uni, img);
+    const uint32_t raw_n = info[img].raw_n;
+    const uint8_t* z = zbuf + ((offsets[item.file] + 15) & ~(uint64_t)15);
+    const uint32_t zlen = info[img].zlen;
+    const uint32_t zwords = (zlen + 3) / 4, total_bits = zlen * 8;
+    uint16_t* tok = tokens + item.aux_off;      // (2 bytes per filtered byte at most: the file's token area is its raw area, doubled)
+    auto wg_sync = [&]() {
+        if (W == 1) wave_lds_sync();
+        else __syncthreads();
+    };
+    auto stage_fill = [&](uint32_t bp, uint32_t words) {
+        const uint32_t w0 = bp >> 5;
+        const uint32_t* zw = reinterpret_cast<const uint32_t*>(z);
+        for (uint32_t i = tid; i < words; i += T) L.stage[i] = (w0 + i < zwords) ? zw[w0 + i] : 0u;
+        wg_sync();
+        return w0 << 5;
+    };
+    // inclusive scan of a 64-bit pair (bytes in the low word, token words in the high) over the workgroup; total = the sum of all
+    auto wg_scan = [&](uint64_t v, uint64_t& total, int slot) -> uint64_t {
+        uint64_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t o = (uint64_t)__shfl_up((long long)incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (W == 1) {
+            total = (uint64_t)__shfl((long long)incl, 63, 64);
+            return incl;
+        }
+        uint64_t* ws = reinterpret_cast<uint64_t*>(&L.wsum[0][0]) + 0;      // (wsum[2][W] u32 = W u64)
+        (void)slot;
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        uint64_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const uint64_t t = ws[w];
+            before += w < wave ? t : 0ull;
+            all += t;
+        }
+        __syncthreads();
+        total = all;
+        return incl + before;
+    };
+    bool bad = zlen < 6;
+    if (!bad) {
+        const uint32_t cmf = z[0], flg = z[1];
+        bad = (cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8 | flg) % 31) != 0 || (flg & 0x20);
+    }
+    uint32_t bp = 16, outpos = 0, tpos = 0;
+    bool last = false;
+    while (!bad && !last) {
+        // ---- block header and tables: wave 0, from the first 192 words behind bp; the others wait
+        const uint32_t hs0 = stage_fill(bp, 192 < LT::kStageWords ? 192 : LT::kStageWords);
+        if (wave == 0) {
+            uint32_t rel = bp - hs0;
+            uint32_t hbad = 0, stored_byte = 0, stored_len = 0;
+            const uint32_t is_last = peek_u(L.stage, rel, 1), type = peek_u(L.stage, rel + 1, 2);
+            rel += 3;
+            int used = 0;
+            if (type == 3 || bp + 3 > total_bits) {
+                hbad = 1;
+            } else if (type == 0) {
+                uint32_t byte = (hs0 + rel + 7) >> 3;
+                if (byte + 4 > zlen) {
+                    hbad = 2;
+                } else {
+                    const uint32_t len = z[byte] | (uint32_t)z[byte + 1] << 8, nlen = z[byte + 2] | (uint32_t)z[byte + 3] << 8;
+                    byte += 4;
+                    if ((len ^ 0xffffu) != nlen || byte + len > zlen || outpos + len > raw_n) hbad = 3;
+                    stored_byte = byte;
+                    stored_len = len;
+                }
+            } else if (type == 1) {
+                for (int s = lane; s < 320; s += 64) L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
+                wave_lds_sync();
+                build_table<false>(L.lens, 288, L.lit, L.ll_count, L.ll_sorted, lane, &used);
+                build_table<true>(L.lens + 288, 30, L.dst, L.d_count, L.d_sorted, lane, &used);
+            } else {
+                const uint32_t nlen = peek_u(L.stage, rel, 5) + 257, ndist = peek_u(L.stage, rel + 5, 5) + 1,
+                               ncode = peek_u(L.stage, rel + 10, 4) + 4;
+                rel += 14;
+                if (nlen > 286 || ndist > 30) hbad = 4;
+                if (!hbad) {
+                    if (lane < 19) L.lens[lane] = 0;
+                    wave_lds_sync();
+                    if (lane < (int)ncode) {
+                        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                        L.lens[order[lane]] = (uint8_t)peek_u(L.stage, rel + 3 * lane, 3);
+                    }
+                    rel += 3 * ncode;
+                    wave_lds_sync();
+                    for (int i = lane; i < 128; i += 64) L.dst[i] = 0;
+                    const uint32_t l = lane < 19 ? L.lens[lane] : 0;
+                    uint32_t cnt[8], next[8];
+                    int left = 1, code = 0;
+                    cnt[0] = next[0] = 0;
+#pragma unroll
+                    for (int q = 1; q <= 7; q++) {
+                        cnt[q] = (uint32_t)__popcll(__ballot(l == (uint32_t)q));
+                        left = (left << 1) - (int)cnt[q];
+                        next[q] = (uint32_t)code;
+                        code = (code + (int)cnt[q]) << 1;
+                    }
+                    if (left != 0) hbad = 5;
+                    uint32_t rank = 0, nx = 0;
+#pragma unroll
+                    for (int q = 1; q <= 7; q++)
+                        if (l == (uint32_t)q) {
+                            rank = (uint32_t)__popcll(__ballot(l == (uint32_t)q) & ((1ull << lane) - 1));
+                            nx = next[q];
+                        }
+                    wave_lds_sync();
+                    if (!hbad && l) {
+                        const uint32_t rev = __brev(nx + rank) >> (32 - l);
+                        for (uint32_t i = rev; i < 128; i += 1u << l) L.dst[i] = (uint32_t)lane | l << 20;
+                    }
+                    wave_lds_sync();
+                }
+                uint32_t idx = 0, prev = 0;
+                const uint32_t want = nlen + ndist;
+                while (!hbad && idx < want) {
+                    if (rel + 14 > (uint32_t)(192 - 2) * 32) {      // a header is at most ~4.5 kbit
+                        hbad = 6;
+                        break;
+                    }
+                    const uint32_t e = L.dst[peek_u(L.stage, rel, 7)];
+                    const uint32_t cl = e >> 20, sym = e & 31u;
+                    if (cl == 0) {
+                        hbad = 7;
+                        break;
+                    }
+                    rel += cl;
+                    if (sym < 16) {
+                        if (lane == 0) L.lens[idx] = (uint8_t)sym;
+                        prev = sym;
+                        idx++;
+                    } else {
+                        uint32_t rep, v = 0;
+                        if (sym == 16) {
+                            if (idx == 0) {
+                                hbad = 8;
+                                break;
+                            }
+                            v = prev;
+                            rep = 3 + peek_u(L.stage, rel, 2);
+                            rel += 2;
+                        } else if (sym == 17) {
+                            rep = 3 + peek_u(L.stage, rel, 3);
+                            rel += 3;
+                            prev = 0;
+                        } else {
+                            rep = 11 + peek_u(L.stage, rel, 7);
+                            rel += 7;
+                            prev = 0;
+                        }
+                        if (idx + rep > want) {
+                            hbad = 9;
+                            break;
+                        }
+                        if (lane < (int)rep) L.lens[idx + lane] = (uint8_t)v;
+                        if (lane + 64 < (int)rep) L.lens[idx + lane + 64] = (uint8_t)v;
+                        if (lane + 128 < (int)rep) L.lens[idx + lane + 128] = (uint8_t)v;
+                        idx += rep;
+                    }
+                }
+                if (!hbad) {
+                    wave_lds_sync();
+                    if (L.lens[256] == 0) hbad = 10;
+                }
+                if (!hbad) {
+                    const uint32_t dl = lane < (int)ndist ? L.lens[nlen + lane] : 0;
+                    wave_lds_sync();
+                    if (lane < 32) L.lens[288 + lane] = (uint8_t)dl;
+                    for (int s = nlen + lane; s < 288; s += 64) L.lens[s] = 0;
+                    wave_lds_sync();
+                    int r = build_table<false>(L.lens, 288, L.lit, L.ll_count, L.ll_sorted, lane, &used);
+                    if (r < 0 || (r > 0 && used != 1)) hbad = 11;
+                    if (!hbad) {
+                        r = build_table<true>(L.lens + 288, 30, L.dst, L.d_count, L.d_sorted, lane, &used);
+                        if (r < 0 || (r > 0 && used > 1)) hbad = 12;
+                    }
+                }
+            }
+            wave_lds_sync();
+            if (lane == 0) {
+                L.bc[0] = hbad;
+                L.bc[1] = is_last;
+                L.bc[2] = type;
+                L.bc[3] = hs0 + rel;
+                L.bc[4] = stored_byte;
+                L.bc[5] = stored_len;
+            }
+        }
+        wg_sync();
+        const uint32_t hbad = L.bc[0], type = L.bc[2];
+        last = L.bc[1] != 0;
+        const uint32_t bp_sym = L.bc[3], st_byte = L.bc[4], st_len = L.bc[5];
+        wg_sync();                                   // (bc is rewritten below)
+        if (hbad) {
+            bad = true;
+            break;
+        }
+        if (type == 0) {
+            // stored: its bytes become literal tokens
+            for (uint32_t k = tid; k < st_len; k += T) tok[tpos + k] = (uint16_t)z[st_byte + k];
+            tpos += st_len;
+            outpos += st_len;
+            bp = (st_byte + st_len) * 8;
+            continue;
+        }
+        bp = bp_sym;
+        // ---- the block's symbols, one speculation round of T subsequences after the other ----
+        bool eob = false;
+        while (!eob && !bad) {
+            if (tid == 0) L.bc[6] = L.bc[7] = 0;     // (read for the last time two barriers ago; the stage fill's barrier publishes it)
+            const uint32_t s0 = stage_fill(bp, LT::kStageWords);
+            const uint32_t r0 = bp - s0;
+            const uint32_t vbase = r0 + (uint32_t)tid * BITS, limit = vbase + BITS;
+            ParseCache2 cache;
+            cache.clear();
+            Parse2 P{vbase, vbase, 0, 0};
+            uint32_t start = vbase;
+            {   // warm-up through the predecessor's subsequence (see png_inflate_kernel)
+                const Parse2 Wm = parse_tok<false>(L, tid > 0 ? vbase - BITS : vbase, vbase, 0, nullptr);
+                if (tid > 0 && !Wm.stopped()) start = Wm.exit;
+            }
+            uint32_t nvalid = 0;
+            for (uint32_t it = 0;; it++) {
+                const uint32_t par = it & 1u;
+                const bool skip = start < vbase;
+                bool miss = !skip && !cache.find(start, &P);
+                if (skip) P = Parse2{start, start, 2u << 30, 0};
+                if (__ballot(miss)) {
+                    if (miss) {
+                        P = parse_tok<false>(L, start, limit, 0, nullptr);
+                        cache.put(P);
+                    }
+                }
+                if (W > 1) {
+                    if (lane == 63) L.xexit[par][wave] = P.exit;
+                    __syncthreads();
+                }
+                uint32_t prev_exit = __shfl_up(P.exit, 1, 64);
+                if (W > 1 && lane == 0 && wave > 0) prev_exit = L.xexit[par][wave - 1];
+                const bool dirty = tid > 0 && prev_exit != P.start;
+                if (dirty) start = prev_exit;
+                const uint64_t dm = __ballot(dirty), sm = __ballot(P.stopped());
+                uint32_t f, sfirst;
+                if (W == 1) {
+                    f = dm ? (uint32_t)__builtin_ctzll(dm) : (uint32_t)T;
+                    sfirst = sm ? (uint32_t)__builtin_ctzll(sm) : (uint32_t)T;
+                } else {
+                    if (lane == 0) {
+                        L.xfirst[par][wave] = dm ? (uint32_t)__builtin_ctzll(dm) : 64u;
+                        L.xstop[par][wave] = sm ? (uint32_t)__builtin_ctzll(sm) : 64u;
+                    }
+                    __syncthreads();
+                    f = T;
+                    sfirst = T;
+#pragma unroll
+                    for (int w = W - 1; w >= 0; w--) {
+                        const uint32_t a = L.xfirst[par][w], b = L.xstop[par][w];
+                        if (a < 64u) f = (uint32_t)w * 64u + a;
+                        if (b < 64u) sfirst = (uint32_t)w * 64u + b;
+                    }
+                }
+                if (sfirst < f) {            // the first stopped subsequence lies in the confirmed prefix
+                    nvalid = sfirst + 1;
+                    break;
+                }
+                if (f == (uint32_t)T) {
+                    nvalid = T;
+                    break;
+                }
+            }
+            // ---- the confirmed prefix: positions of its bytes and token words
+            const bool in = (uint32_t)tid < nvalid;
+            uint64_t tot;
+            const uint64_t inc = wg_scan(in ? ((uint64_t)P.ntok << 32 | P.nbytes()) : 0ull, tot, 0);
+            const uint32_t cb = (uint32_t)inc, ct = (uint32_t)(inc >> 32);
+            const bool fits = in && outpos + cb <= raw_n;
+            bool far = false;
+            if (fits) far = parse_tok<true>(L, P.start, limit, outpos + cb - P.nbytes(), tok + tpos + (ct - P.ntok)).err() && !P.err();
+            // the last subsequence taken decides how the round ends
+            const uint64_t fm = __ballot(fits);
+            const bool is_end = fits && (lane == 63 ? true : !((fm >> (lane + 1)) & 1));      // last fitting lane of this wave
+            if (__ballot(far) && lane == 0) L.bc[7] = 1;
+            wg_sync();
+            // the overall last fitting lane: the highest wave that has one (fits is a prefix)
+            if (is_end) atomicMax(&L.bc[6], (uint32_t)tid + 1u);
+            wg_sync();
+            const uint32_t take = L.bc[6];
+            if (take == 0) {                  // more output than the image has rows for
+                bad = true;
+                break;
+            }
+            if ((uint32_t)tid == take - 1u) {
+                L.bc[8] = cb;
+                L.bc[9] = ct;
+                L.bc[10] = P.exit;
+                L.bc[11] = (P.eob() ? 1u : 0u) | (P.err() ? 2u : 0u);
+            }
+            wg_sync();
+            const uint32_t add = L.bc[8], ntk = L.bc[9], ex_bits = L.bc[10], endf = L.bc[11], farf = L.bc[7];
+            wg_sync();
+            if (farf) {
+                bad = true;
+                break;
+            }
+            outpos += add;
+            tpos += ntk;
+            bp = s0 + ex_bits;
+            if ((endf & 2u) || bp > total_bits) bad = true;
+            eob = endf & 1u;
+        }
+    }
+    if (!bad && outpos != raw_n) bad = true;
+    if (tid == 0) {
+        if (bad) info[img].status = UCFP_E_MODALITY;
+        tinfo[img].ntok = tpos;
+        tinfo[img].end_bit = bp;
+    }
+}
+
+// One wave per file: token words -> filtered scanlines.  A lane takes 16 consecutive words of the round's 1024; a match
+// belongs to the lane that holds its first word.
+template <class C>
+__global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets, size_t n,
+                                                   const UpItem* __restrict__ items, UpUniform uni, PngInfo* __restrict__ info,
+                                                   const uint16_t* __restrict__ tokens, const PngTok* __restrict__ tinfo,
+                                                   uint8_t* __restrict__ raw) {
+    __shared__ InflateLds<C> L;
+    constexpr uint32_t kTPL = 32;      // token words per lane and round: 2048 words ~ 5 KB of output, ~1400 matches at level 1
+    const size_t img = blockIdx.x;
+    if (img >= n) return;
+    const int lane = threadIdx.x;
+    if (info[img].status != 0) return;
+    const UpItem item = up_item(items, uni, img);
+    const uint32_t raw_n = info[img].raw_n, ntok = tinfo[img].ntok;
+    const uint16_t* tok = tokens + item.aux_off;      // (16-byte aligned: aux_off is a multiple of 16)
+    uint8_t* out = raw + item.aux_off;
+    uint32_t tpos = 0, outpos = 0;
+    bool bad = false;
+    Adler adler;
+    while (tpos < ntok && !bad) {
+        // my words, and whether the first of them is the second half of a match that began before them
+        const uint32_t w0 = tpos + (uint32_t)lane * kTPL;
+        uint32_t wd[kTPL + 1];
+        const uint32_t before = w0 > 0 && w0 <= ntok ? tok[w0 - 1] : 0u;
+        {
+            // the lane's words as whole 16-byte pieces (the token area is padded: reading past ntok stays inside it)
+            const uint4* t4 = reinterpret_cast<const uint4*>(tok + w0);
+#pragma unroll
+            for (uint32_t q = 0; q < kTPL / 8; q++) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (w0 + 8 * q < ntok) v = t4[q];
+                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    wd[8 * q + 2 * c] = w0 + 8 * q + 2 * c < ntok ? (x[c] & 0xffffu) : 0u;
+                    wd[8 * q + 2 * c + 1] = w0 + 8 * q + 2 * c + 1 < ntok ? (x[c] >> 16) : 0u;
+                }
+            }
+            wd[kTPL] = w0 + kTPL < ntok ? tok[w0 + kTPL] : 0u;
+        }
+        uint32_t nb = 0, nm = 0;
+        bool dist_next = (before & 0x8000u) != 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kTPL; j++) {
+            const bool have = w0 + j < ntok;
+            const bool head = have && !dist_next && (wd[j] & 0x8000u);
+            const bool lit = have && !dist_next && !(wd[j] & 0x8000u);
+            nb += lit ? 1u : head ? (wd[j] & 0xffu) + 3u : 0u;
+            nm += head ? 1u : 0u;
+            dist_next = head;
+        }
+        const uint32_t cb = wave_incl_scan(nb, lane), cm = wave_incl_scan(nm, lane);
+        const bool fits = cb <= C::kIterOut && cm <= C::kMatchCap && outpos + cb <= raw_n;
+        const int take = __popcll(__ballot(fits));
+        if (take == 0) {                      // (a lane's 16 words are at most 16 x 258 bytes: only the image's size can refuse them)
+            bad = true;
+            break;
+        }
+        const uint32_t rb_base = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
+        bool far = false;
+        if (lane < take) {
+            uint32_t p = outpos + cb - nb, mi = cm - nm;
+            bool dn = (before & 0x8000u) != 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kTPL; j++) {
+                const bool have = w0 + j < ntok;
+                const bool head = have && !dn && (wd[j] & 0x8000u);
+                const bool lit = have && !dn && !(wd[j] & 0x8000u);
+                if (lit) L.rb[p - rb_base] = (uint8_t)wd[j];
+                if (head) {
+                    const uint32_t len = (wd[j] & 0xffu) + 3u, dist = (wd[j + 1] & 0x7fffu) + 1u;
+                    if (dist > p) far = true;
+                    L.m_dst[mi] = p;
+                    L.m_ld[mi] = len << 16 | (dist - 1u);
+                    mi++;
+                    p += len;
+                } else if (lit) {
+                    p++;
+                }
+                dn = head;
+            }
+        }
+        wave_lds_sync();
+        if (__ballot(far)) {
+            bad = true;
+            break;
+        }
+        const uint32_t add = __shfl(cb, take - 1, 64), nmt = __shfl(cm, take - 1, 64);
+        resolve_matches(L, out, rb_base, nmt, lane);
+        flush_out(L, out, outpos, outpos + add, rb_base, lane);
+        adler.add(add, [&](uint32_t j) { return (uint32_t)L.rb[outpos + j - rb_base]; }, lane);
+        __threadfence_block();
+        outpos += add;
+        {
+            const uint32_t nb2 = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
+            const uint32_t shift = nb2 - rb_base, keep = (outpos - nb2 + 3) / 4;
+            if (shift) {
+                uint32_t wv[(kHist + 4) / 4 / 64 + 1];
+#pragma unroll
+                for (int i = 0; i < (int)((kHist + 4) / 4 / 64 + 1); i++) {
+                    const uint32_t wi = lane + 64 * i;
+                    wv[i] = wi < keep ? *reinterpret_cast<const uint32_t*>(&L.rb[shift + 4 * wi]) : 0u;
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int i = 0; i < (int)((kHist + 4) / 4 / 64 + 1); i++) {
+                    const uint32_t wi = lane + 64 * i;
+                    if (wi < keep) *reinterpret_cast<uint32_t*>(&L.rb[4 * wi]) = wv[i];
+                }
+                wave_lds_sync();
+            }
+        }
+        // words consumed: the taken lanes' (a match head in a lane's last word takes its distance from the next lane's first)
+        tpos += (uint32_t)take * kTPL;
+    }
+    if (!bad && outpos != raw_n) bad = true;
+    bool checksum_only = false;
+    if (!bad) {
+        const uint8_t* z = zbuf + ((offsets[item.file] + 15) & ~(uint64_t)15);
+        const uint32_t zlen = info[img].zlen, e = (tinfo[img].end_bit + 7) / 8;
+        if (e + 4 > zlen ||
+            ((uint32_t)z[e] << 24 | (uint32_t)z[e + 1] << 16 | (uint32_t)z[e + 2] << 8 | z[e + 3]) != adler.value())
+            checksum_only = true;
+    }
+    if (lane == 0) {
+        if (bad) info[img].status = UCFP_E_MODALITY;
+        else if (checksum_only) info[img].status = UCFP_IMAGE_NEEDS_HOST;
+    }
+}
+
 // One wave per image: PNG 9.2 reconstruction.  Lane j takes rows j, j + 64, ...; it works one pixel behind lane j - 1
 // (lane 0 one pixel behind lane 63's previous row, kept in LDS), so the pixel above is the neighbour's last output.
 // A lane walks its row in blocks of 64 pixels, and the step loop only touches LDS:
@@ -1191,6 +1779,10 @@ static size_t png_ws_layout(size_t n, size_t png_bytes, size_t raw_total, PngWs*
     off += (n * sizeof(PngInfo) + 255) & ~(size_t)255;
     l->raw = off;
     off += raw_total;
+    l->tok = off;
+    off += 2 * raw_total;
+    l->tinfo = off;
+    off += (n * sizeof(PngTok) + 255) & ~(size_t)255;
     l->total = off;
     return off;
 }
@@ -1217,6 +1809,41 @@ static int png_decode_launches(const uint8_t* png, const uint64_t* offsets, cons
                                hipStream_t stream) {
     PngInfo* info = reinterpret_cast<PngInfo*>(ws + l.info);
     hipLaunchKernelGGL(png_scan_kernel, dim3((unsigned)n), dim3(64), 0, stream, png, offsets, n, d_items, uni, ws + l.zbuf, info);
+    // Two-pass inflate (png_huff_kernel + png_lz_kernel): waves per file by how many files there are to fill the chip with
+    // measured, 256-bit subsequences, images/s (one-kernel inflate | 1 | 2 | 4 | 8 waves per file):  64 files 12.7 k | - | 13.8 | 16.2 | 11.9;
+    // 256: 49 | - | 55 | 62 | 45;  500: 92 | - | 100 | 112 | 78;  1000: 160 | - | 187 | 206 | 135;  2000: 163 | - | 237 | 218 | 161;
+    // 3000: 191 | - | 228 | 227 | 174;  8000: 213 | 263 | 255 | 241 | 194 (128-bit subsequences need more re-parses: 151 k at
+    // 1000 x 4; 512-bit ones are level with 256)
+    static const char* two = getenv("UCFP_PNG_TWO_PASS");      // (A/B: 0 = the one-kernel inflate; 2 / 4 / 8 = that many waves per file)
+    if (!two || atoi(two) != 0) {
+        uint16_t* tokens = reinterpret_cast<uint16_t*>(ws + l.tok);
+        PngTok* tinfo = reinterpret_cast<PngTok*>(ws + l.tinfo);
+        const int force_w = two && atoi(two) > 1 ? atoi(two) : 0;
+        const int w = force_w ? force_w : n <= 1200 ? 4 : n <= 3000 ? 2 : 1;
+        auto huff = [&](auto kern, int waves) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64 * waves), 0, stream, ws + l.zbuf, offsets, n, d_items, uni, info, tokens, tinfo);
+        };
+        static const char* hb = getenv("UCFP_PNG_HUFF_BITS");      // (tuning)
+        const int bits = hb ? atoi(hb) : 256;
+        if (bits >= 512) {
+            if (w >= 8) huff(png_huff_kernel<512, 8>, 8);
+            else if (w >= 4) huff(png_huff_kernel<512, 4>, 4);
+            else if (w >= 2) huff(png_huff_kernel<512, 2>, 2);
+            else huff(png_huff_kernel<512, 1>, 1);
+        } else if (bits >= 256) {
+            if (w >= 8) huff(png_huff_kernel<256, 8>, 8);
+            else if (w >= 4) huff(png_huff_kernel<256, 4>, 4);
+            else if (w >= 2) huff(png_huff_kernel<256, 2>, 2);
+            else huff(png_huff_kernel<256, 1>, 1);
+        } else {
+            if (w >= 8) huff(png_huff_kernel<128, 8>, 8);
+            else if (w >= 4) huff(png_huff_kernel<128, 4>, 4);
+            else if (w >= 2) huff(png_huff_kernel<128, 2>, 2);
+            else huff(png_huff_kernel<128, 1>, 1);
+        }
+        hipLaunchKernelGGL(png_lz_kernel<RoundCfg<256>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, d_items, uni, info,
+                           (const uint16_t*)tokens, (const PngTok*)tinfo, ws + l.raw);
+    } else
     // wide rounds while the batch leaves most of the chip's wave slots empty anyway (RoundCfg)
     // measured (files/s, narrow | wide): 600: 83 k | 98 k, 1000: 130 k | 157 k, 1400: 162 k | 118 k, 2000: 141 k | 160 k,
     // 3000: 189 k | 164 k -- the chip holds about 1024 wide or 1536 narrow waves at a time

@@ -2,7 +2,9 @@
 // config 1 ("?algorithm=phash on 1 k 256x256 PNGs") no longer leaves the GPU waiting on a host decoder.
 //
 // The reference decodes inside the SDK call (src/modality/image.rs:68-70, :176-179: imgfprint -> image::load_from_memory
-// -> png crate).  Here a batch of PNG files takes three kernels, ONE WAVE PER IMAGE each:
+// -> png crate).  Here a batch of PNG files takes three stages (round 4: the inflate stage is two kernels, png_huff_kernel with
+// 1-4 waves per file and png_lz_kernel -- see "two-pass inflate" below; png_inflate_kernel is the one-kernel form it replaced,
+// kept behind UCFP_PNG_TWO_PASS=0 for A/B and for tools/prof_png_phases.py):
 //
 //   png_scan      walks the chunks (PNG 5.3), checks IHDR against the geometry the batch was announced with, gathers
 //                 the IDAT payloads into one contiguous zlib stream.
@@ -322,8 +324,8 @@ __device__ __forceinline__ uint32_t stage_load(InflateLds<C>& L, const uint8_t* 
 }
 
 // Round buffer -> frame memory for [from, to); rb[0] is position `base` (a multiple of 4), so whole words line up.
-template <class C>
-__device__ __forceinline__ void flush_out(const InflateLds<C>& L, uint8_t* out, uint32_t from, uint32_t to, uint32_t base, int lane) {
+template <class LT>
+__device__ __forceinline__ void flush_out(const LT& L, uint8_t* out, uint32_t from, uint32_t to, uint32_t base, int lane) {
     uint32_t p = from;
     const uint32_t head = (4 - (p & 3)) & 3;
     if (lane < (int)head && p + lane < to) out[p + lane] = L.rb[p + lane - base];
@@ -337,14 +339,14 @@ __device__ __forceinline__ void flush_out(const InflateLds<C>& L, uint8_t* out, 
 }
 
 // A byte of the stream: from the round buffer (this round and the kHist bytes before it), or from frame memory.
-template <class C>
-__device__ __forceinline__ uint8_t window_byte(const InflateLds<C>& L, const uint8_t* out, uint32_t p, uint32_t rb_base) {
+template <class LT>
+__device__ __forceinline__ uint8_t window_byte(const LT& L, const uint8_t* out, uint32_t p, uint32_t rb_base) {
     return p >= rb_base ? L.rb[p - rb_base] : out[p];
 }
 
 // Resolves the listed matches in stream order.  All literals of the round are already in the round buffer.
-template <class C>
-__device__ void resolve_matches(InflateLds<C>& L, const uint8_t* out, uint32_t rb_base, uint32_t total, int lane,
+template <class LT>
+__device__ void resolve_matches(LT& L, const uint8_t* out, uint32_t rb_base, uint32_t total, int lane,
                                 unsigned long long* rounds = nullptr, unsigned long long* coop = nullptr) {
     for (uint32_t g0 = 0; g0 < total; g0 += 64) {
         const uint32_t mi = g0 + lane;
@@ -1065,7 +1067,8 @@ struct ParseCache2 {
 template <int BITS, int W>
 __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets, size_t n,
                                                          const UpItem* __restrict__ items, UpUniform uni, PngInfo* __restrict__ info,
-                                                         uint16_t* __restrict__ tokens, PngTok* __restrict__ tinfo) {
+                                                         uint16_t* __restrict__ tokens, PngTok* __restrict__ tinfo, uint32_t warm,
+                                                         uint32_t max_iter) {
     using LT = HuffLds<BITS, W>;
     __shared__ LT L;
     constexpr int T = 64 * W;
@@ -1297,7 +1300,7 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
             cache.clear();
             Parse2 P{vbase, vbase, 0, 0};
             uint32_t start = vbase;
-            {   // warm-up through the predecessor's subsequence (see png_inflate_kernel)
+            if (warm) {   // warm-up through the predecessor's subsequence (see png_inflate_kernel)
                 const Parse2 Wm = parse_tok<false>(L, tid > 0 ? vbase - BITS : vbase, vbase, 0, nullptr);
                 if (tid > 0 && !Wm.stopped()) start = Wm.exit;
             }
@@ -1347,6 +1350,10 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
                 }
                 if (f == (uint32_t)T) {
                     nvalid = T;
+                    break;
+                }
+                if (it + 1 >= max_iter && f >= 64u) {      // enough chasing: the confirmed prefix goes out, the rest is next round's
+                    nvalid = f;
                     break;
                 }
             }
@@ -1401,12 +1408,20 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
 
 // One wave per file: token words -> filtered scanlines.  A lane takes 16 consecutive words of the round's 1024; a match
 // belongs to the lane that holds its first word.
+// round buffer + match list only (26 KB: six waves per CU where InflateLds' tables and stage left room for four)
+struct LzLds {
+    static constexpr uint32_t kIterOut = 8192, kMatchCap = 2048;
+    uint32_t m_dst[kMatchCap];
+    uint32_t m_ld[kMatchCap];                             // len << 16 | (dist - 1)
+    uint8_t rb[kHist + kIterOut + 8];
+};
+
 template <class C>
 __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ zbuf, const uint64_t* __restrict__ offsets, size_t n,
                                                    const UpItem* __restrict__ items, UpUniform uni, PngInfo* __restrict__ info,
                                                    const uint16_t* __restrict__ tokens, const PngTok* __restrict__ tinfo,
                                                    uint8_t* __restrict__ raw) {
-    __shared__ InflateLds<C> L;
+    __shared__ C L;
     constexpr uint32_t kTPL = 32;      // token words per lane and round: 2048 words ~ 5 KB of output, ~1400 matches at level 1
     const size_t img = blockIdx.x;
     if (img >= n) return;
@@ -1440,15 +1455,20 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
             }
             wd[kTPL] = w0 + kTPL < ntok ? tok[w0 + kTPL] : 0u;
         }
-        uint32_t nb = 0, nm = 0;
+        // Matches that follow one another with the SAME distance are one longer match (byte by byte the copy is the same):
+        // level-1 streams of photographs are chains of 3-byte matches one pixel back, each depending on the one before --
+        // as separate list entries they resolve a handful per step, merged they are periodic runs the whole wave copies.
+        uint32_t nb = 0, nm = 0, run_dist = 0;           // run_dist: distance word of the match the lane is extending (0: none)
         bool dist_next = (before & 0x8000u) != 0;
 #pragma unroll
         for (uint32_t j = 0; j < kTPL; j++) {
             const bool have = w0 + j < ntok;
             const bool head = have && !dist_next && (wd[j] & 0x8000u);
             const bool lit = have && !dist_next && !(wd[j] & 0x8000u);
+            const uint32_t dw = wd[j + 1] + 1u;           // (a head's distance word, + 1 so that 0 means "no run")
             nb += lit ? 1u : head ? (wd[j] & 0xffu) + 3u : 0u;
-            nm += head ? 1u : 0u;
+            nm += (head && dw != run_dist) ? 1u : 0u;
+            run_dist = head ? dw : lit ? 0u : run_dist;
             dist_next = head;
         }
         const uint32_t cb = wave_incl_scan(nb, lane), cm = wave_incl_scan(nm, lane);
@@ -1461,7 +1481,7 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
         const uint32_t rb_base = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
         bool far = false;
         if (lane < take) {
-            uint32_t p = outpos + cb - nb, mi = cm - nm;
+            uint32_t p = outpos + cb - nb, mi = cm - nm, rd = 0, run_len = 0;
             bool dn = (before & 0x8000u) != 0;
 #pragma unroll
             for (uint32_t j = 0; j < kTPL; j++) {
@@ -1470,14 +1490,20 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
                 const bool lit = have && !dn && !(wd[j] & 0x8000u);
                 if (lit) L.rb[p - rb_base] = (uint8_t)wd[j];
                 if (head) {
-                    const uint32_t len = (wd[j] & 0xffu) + 3u, dist = (wd[j + 1] & 0x7fffu) + 1u;
-                    if (dist > p) far = true;
-                    L.m_dst[mi] = p;
-                    L.m_ld[mi] = len << 16 | (dist - 1u);
-                    mi++;
+                    const uint32_t len = (wd[j] & 0xffu) + 3u, dw = wd[j + 1] + 1u, dist = (wd[j + 1] & 0x7fffu) + 1u;
+                    if (dw != rd) {                       // a new entry (the run before it, if any, is complete)
+                        if (dist > p) far = true;
+                        L.m_dst[mi] = p;
+                        run_len = 0;
+                        mi++;
+                    }
+                    run_len += len;
+                    L.m_ld[mi - 1] = run_len << 16 | (dist - 1u);      // (a 32-word lane holds at most 16 x 258 bytes: 16 bits)
+                    rd = dw;
                     p += len;
                 } else if (lit) {
                     p++;
+                    rd = 0;
                 }
                 dn = head;
             }
@@ -1821,7 +1847,11 @@ static int png_decode_launches(const uint8_t* png, const uint64_t* offsets, cons
         const int force_w = two && atoi(two) > 1 ? atoi(two) : 0;
         const int w = force_w ? force_w : n <= 1200 ? 4 : n <= 3000 ? 2 : 1;
         auto huff = [&](auto kern, int waves) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64 * waves), 0, stream, ws + l.zbuf, offsets, n, d_items, uni, info, tokens, tinfo);
+            static const char* wm = getenv("UCFP_PNG_HUFF_WARM");          // (tuning)
+            static const char* mi = getenv("UCFP_PNG_HUFF_MAX_ITER");
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64 * waves), 0, stream, ws + l.zbuf, offsets, n, d_items, uni, info, tokens, tinfo,
+                               wm ? (uint32_t)atoi(wm) : 1u, mi ? (uint32_t)atoi(mi) : 3u);      // (1000 files x 4 waves: 150 k images/s without the
+                               // warm-up parse, 210 k with; chain iterations capped at 2 / 3 / 4 / none: 200 / 217 / 215 / 210 k)
         };
         static const char* hb = getenv("UCFP_PNG_HUFF_BITS");      // (tuning)
         const int bits = hb ? atoi(hb) : 256;
@@ -1841,7 +1871,7 @@ static int png_decode_launches(const uint8_t* png, const uint64_t* offsets, cons
             else if (w >= 2) huff(png_huff_kernel<128, 2>, 2);
             else huff(png_huff_kernel<128, 1>, 1);
         }
-        hipLaunchKernelGGL(png_lz_kernel<RoundCfg<256>>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, d_items, uni, info,
+        hipLaunchKernelGGL(png_lz_kernel<LzLds>, dim3((unsigned)n), dim3(64), 0, stream, ws + l.zbuf, offsets, n, d_items, uni, info,
                            (const uint16_t*)tokens, (const PngTok*)tinfo, ws + l.raw);
     } else
     // wide rounds while the batch leaves most of the chip's wave slots empty anyway (RoundCfg)

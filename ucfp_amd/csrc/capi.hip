@@ -259,7 +259,8 @@ static int png_decode_impl(ucfp_ctx* ctx, const uint8_t* d_png, const uint64_t* 
     if (rc) return rc;
     HIP_TRY(hipStreamWaitEvent(st, ctx->png_done, 0));
     uint8_t* fr = frames ? frames : ctx->png_ws + frames_off;
-    ucfp::launch_png_decode(d_png, d_offsets, n, w, h, pixfmt, ctx->png_ws, l, fr, row_stride, frame_stride, d_status, st);
+    ucfp::launch_png_decode(d_png, d_offsets, n, w, h, pixfmt, ctx->png_ws, l, fr, row_stride, frame_stride, d_status, st, ctx->side,
+                            ctx->side_fork, ctx->side_join);
     HIP_TRY(hipGetLastError());
     if (layout) *layout = l;
     if (own_frames) *own_frames = fr;

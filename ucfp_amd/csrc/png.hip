@@ -1514,7 +1514,9 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
             break;
         }
         const uint32_t add = __shfl(cb, take - 1, 64), nmt = __shfl(cm, take - 1, 64);
-        resolve_matches(L, out, rb_base, nmt, lane);
+        resolve_matches(L, out, rb_base, nmt, lane);      // (four groups of 64 entries per step measured slower: 1000 files 217 k -> 144 k images/s --
+                                                           // the chains are real dependencies: 98 % of a level-1 photograph's bytes come from matches, so a source
+                                                           // inside the round lies in an earlier match's destination)
         flush_out(L, out, outpos, outpos + add, rb_base, lane);
         adler.add(add, [&](uint32_t j) { return (uint32_t)L.rb[outpos + j - rb_base]; }, lane);
         __threadfence_block();

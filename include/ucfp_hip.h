@@ -196,7 +196,7 @@ int ucfp_image_upload_decode_batch_dev(ucfp_ctx* ctx, const uint8_t* d_blob, con
  * of the records, at most max_batch uploads / max_bytes encoded bytes per flush, flushed no later than max_delay_us after
  * the first pending upload.  Inside, PNG and JPEG uploads coalesce in two lanes (each with max_batch / max_bytes of its own;
  * the JPEG lane on a context the batcher creates for itself), so that a JPEG request -- a few milliseconds of decode -- does
- * not wait for the largest PNG of a shared flush -- tens of milliseconds on its one wave. */
+ * not wait for the largest PNG of a shared flush -- tens of milliseconds, its LZ77 pass being one wave's serial work. */
 typedef struct ucfp_upload_batcher ucfp_upload_batcher;
 int ucfp_upload_batcher_create(ucfp_ctx* ctx, uint32_t algo, const ucfp_image_preprocess* pre, size_t max_batch, size_t max_bytes,
                                uint32_t max_delay_us, ucfp_upload_batcher** out);

@@ -1170,13 +1170,18 @@ __global__ __launch_bounds__(64) void hamming_final_select(
         for (uint32_t c = lane; c < nc; c += kWave) atomicAdd(&h[gd[sl.slot(c)]], 1u);
     }
     wave_lds_sync();
-    uint32_t dstar = 64, cum = 0;   // wave-uniform: every lane walks the same 65 bins
-    for (uint32_t b = 0; b < 65; b++) {
-        cum += h[b];
-        if (cum >= k) {
-            dstar = b;
-            break;
+    // d* = the first bin at which the running count reaches k (64 if it never does: fewer than k candidates): lane b takes bin b,
+    // a wave scan replaces 65 dependent LDS reads
+    uint32_t dstar;
+    {
+        uint32_t inc = h[lane];
+#pragma unroll
+        for (int dl = 1; dl < kWave; dl <<= 1) {
+            const uint32_t o = __shfl_up(inc, dl, kWave);
+            if (lane >= dl) inc += o;
         }
+        const uint64_t reach = __ballot(inc >= k);
+        dstar = reach ? (uint32_t)__builtin_ctzll(reach) : 64u;
     }
     // compact the possible winners
     uint32_t m = 0;   // wave-uniform

@@ -363,10 +363,11 @@ def test_micro_batcher_for_encoded_uploads(gpu_ctx, oracle):
         b.close()
 
 
-@pytest.mark.parametrize("n", [520, 1100])
+@pytest.mark.parametrize("n", [520, 1100, 1300, 1700, 3300])
 def test_every_round_shape_of_the_inflate_kernel(gpu_ctx, oracle, n):
-    """The inflate kernel is launched in one of three round shapes by batch size (<= 512 files: 512-bit subsequences,
-    <= 1024: 256-bit, beyond: 128-bit); the other tests use small batches, these two reach the other shapes."""
+    """The Huffman pass is launched with 4 / 2 / 1 waves per file by batch size (<= 1200 / <= 3000 / beyond), and batches of
+    1600+ files decode as two halves on two streams; the other tests use small batches, these reach every shape (round 3's
+    one-kernel inflate: three round shapes by batch size, the same sizes reach them under UCFP_PNG_TWO_PASS=0)."""
     from ucfp_amd import image
     rng = np.random.default_rng(n)
     base = [config1_png(i, side=64, level=(1, 6, 9)[i % 3]) for i in range(40)]
@@ -418,3 +419,48 @@ def test_simple_transparency_changes_no_pixel(gpu_ctx, oracle):
     # the uniform entry takes them too
     fr, st = image.decode_pngs(files[1:], w, h, image.PIX_RGB8, ctx=gpu_ctx)
     assert not st.any() and all(np.array_equal(fr[i], want[i + 1]) for i in range(3))
+
+
+@pytest.mark.parametrize("env", [{"UCFP_PNG_TWO_PASS": "1", "UCFP_PNG_HUFF_BITS": "128"}, {"UCFP_PNG_TWO_PASS": "2", "UCFP_PNG_HUFF_BITS": "512"},
+                                 {"UCFP_PNG_TWO_PASS": "8"}, {"UCFP_PNG_TWO_PASS": "4", "UCFP_PNG_HUFF_MAX_ITER": "1"},
+                                 {"UCFP_PNG_TWO_PASS": "4", "UCFP_PNG_HUFF_WARM": "0"}, {"UCFP_PNG_TWO_PASS": "0"}])
+def test_inflate_variants_in_a_process_of_their_own(env):
+    """Every instantiation of the two-pass inflate (subsequence length, waves per file, chain-iteration cap, warm-up) and the
+    one-kernel form decode the same assorted files to Pillow's pixels.  The switches are read once per process, hence a child."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import io, sys
+import numpy as np
+from PIL import Image
+sys.path.insert(0, 'tests')
+from test_oracle_png import config1_png, _png
+from ucfp_amd import image, _lib
+ctx = _lib.default_context(0)
+rng = np.random.default_rng(3)
+pngs, want = [], []
+for i in range(70):
+    if i % 5 == 0:
+        a = rng.integers(0, 256, (96, 96, 3), dtype=np.uint8)                      # incompressible: stored / literal-only blocks
+        p = _png(a, 'RGB', compress_level=(0, 1, 9)[i % 3])
+    elif i % 5 == 1:
+        a = np.full((96, 96, 3), i, np.uint8)
+        a[::7, ::5] = 255 - i                                                      # long runs: self-overlapping matches
+        p = _png(a, 'RGB', compress_level=9)
+    else:
+        p, a = config1_png(i, side=96, level=(1, 6, 9)[i % 3])
+    pngs.append(p)
+    want.append(a)
+fr, st = image.decode_pngs(pngs, 96, 96, image.PIX_RGB8, ctx=ctx)
+assert not st.any(), st
+for i in range(len(pngs)):
+    assert np.array_equal(fr[i], want[i]), i
+bad = bytearray(pngs[3]); bad[len(bad) // 2] ^= 0x40
+fr, st = image.decode_pngs([pngs[0], bytes(bad), pngs[1]], 96, 96, image.PIX_RGB8, ctx=ctx)
+assert st[0] == 0 and st[1] != 0 and st[2] == 0 and np.array_equal(fr[2], want[1])
+print('ok')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Cycle breakdown of png_lz_kernel (build with UCFP_HIPCC_EXTRA=-DPNG_PROF): python tools/prof_png_lz.py [n] [level]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np  # noqa: E402
+from bench_png import make  # noqa: E402
+from ucfp_amd import _lib, image  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+pngs, imgs = make(n, level)
+lib = _lib.load()
+f = lib.ucfp_debug_png_prof
+f.argtypes = [C.c_void_p, C.c_int]
+image.decode_pngs(pngs[:8], 256, 256, image.PIX_RGB8)
+f(None, 1)
+fr, st = image.decode_pngs(pngs, 256, 256, image.PIX_RGB8)
+acc = (C.c_ulonglong * 16)()
+f(acc, 0)
+a = np.array(list(acc), dtype=np.float64) / n
+names = ["tokens+scans", "literals+list", "matches", "flush+adler", "slide"]
+tot = a[:5].sum()
+print(f"ok={not st.any()} per image: total {tot/1e6:.2f} Mcycles; rounds {a[9]:.1f} matches/round {a[12]/max(a[9],1):.1f} "
+      f"resolve steps/round {a[13]/max(a[9],1):.1f} (whole-wave copies {a[14]/max(a[9],1):.1f})")
+for i, nm in enumerate(names):
+    print(f"  {nm:14s} {a[i]/1e3:9.1f} kcycles  {100*a[i]/tot:5.1f}%   per round {a[i]/max(a[9],1):8.0f}")

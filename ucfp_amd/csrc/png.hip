@@ -50,6 +50,9 @@ struct RoundCfg {
     static constexpr uint32_t kMatchCap = BITS * 8;                        // matches listed per round
     static constexpr int kStageWords = BITS * 2 + 32;                      // 64 subsequences + overshoot + the fetch window
 };
+#ifndef UCFP_PNG_LZ_WINDOW
+#define UCFP_PNG_LZ_WINDOW 2048
+#endif
 constexpr uint32_t kHist = 2048;                       // bytes of earlier rounds kept in LDS: a match one image row back (the common distance) never leaves the CU
 
 // table entries: value (literal / length base / distance base) | extra bits << 16 | code length << 20 | kind << 24
@@ -71,7 +74,7 @@ struct InflateLds {
     uint16_t ll_count[16];
     uint16_t d_count[16];
     uint8_t lens[320];
-    uint8_t rb[kHist + C::kIterOut + 8];                  // the last kHist bytes of earlier rounds + this round's output; rb[0] is stream position rb_base
+    alignas(4) uint8_t rb[kHist + C::kIterOut + 8];       // the last kHist bytes of earlier rounds + this round's output; rb[0] is stream position rb_base
 };
 
 __device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t len) {
@@ -345,15 +348,52 @@ __device__ __forceinline__ uint8_t window_byte(const LT& L, const uint8_t* out, 
 }
 
 // Resolves the listed matches in stream order.  All literals of the round are already in the round buffer.
+//
+// A group of 64 entries (one per lane) is resolved in steps: every entry whose source ends at or below the first unresolved
+// destination moves together.  What the steps cost was measured piece by piece (round 4, png_lz_kernel, a level-1 photograph:
+// 950 three-byte matches per round, 38 steps): a source older than the LDS window is a round trip to frame memory for the whole
+// wave, and nearly every step had one; sixteen byte-wide LDS instructions at random addresses are ~6-way bank conflicts each.
+// So: (1) sources below the window never depend on a pending match -- they are fetched for the WHOLE group when it is loaded,
+// one group ahead of the one being stepped through, as aligned words; (2) window sources come as two or three aligned words
+// shifted into place; (3) a step whose ready matches are all <= 4 bytes issues four byte writes; (4) places a lane does not
+// own are written to a spare byte behind the window, so the moves are straight-line.
 template <class LT>
 __device__ void resolve_matches(LT& L, const uint8_t* out, uint32_t rb_base, uint32_t total, int lane,
                                 unsigned long long* rounds = nullptr, unsigned long long* coop = nullptr) {
-    for (uint32_t g0 = 0; g0 < total; g0 += 64) {
+    constexpr uint32_t kSpare = sizeof(L.rb) - 4;
+    const uint32_t* rw = reinterpret_cast<const uint32_t*>(L.rb);
+    struct Group {
+        uint32_t dst, len, dist;
+        uint32_t g[3];         // a far source's bytes [srcp & ~3, + 12), requested when the group was loaded
+        bool have, far;
+    };
+    auto load_group = [&](uint32_t g0) {
+        Group G;
         const uint32_t mi = g0 + lane;
-        const bool have = mi < total;
-        const uint32_t dst = have ? L.m_dst[mi] : 0, ld = have ? L.m_ld[mi] : 0;
-        const uint32_t len = ld >> 16, dist = (ld & 0xffffu) + 1;
-        uint64_t pending = __ballot(have);
+        G.have = mi < total;
+        const uint32_t d = G.have ? L.m_dst[mi] : 0, ld = G.have ? L.m_ld[mi] : 0;
+        G.dst = d;
+        G.len = ld >> 16;
+        G.dist = (ld & 0xffffu) + 1;
+        const uint32_t srcp = d - G.dist;
+        G.far = G.have && G.len <= 8 && G.dist >= G.len && srcp < rb_base;     // (short entries only: the others go byte by byte)
+        G.g[0] = G.g[1] = G.g[2] = 0;
+        if (G.far) {
+            // whole words around the source: it ends below the round, inside the file's own area (whose first byte is 16-aligned)
+            const uint32_t* gw = reinterpret_cast<const uint32_t*>(out + (srcp & ~3u));
+            G.g[0] = gw[0];
+            G.g[1] = gw[1];
+            G.g[2] = gw[2];
+        }
+        return G;
+    };
+    Group N = load_group(0);
+    for (uint32_t g0 = 0; g0 < total; g0 += 64) {
+        const Group G = N;
+        if (g0 + 64 < total) N = load_group(g0 + 64);
+        const uint32_t dst = G.dst, len = G.len, dist = G.dist;
+        const uint32_t srcp = dst - dist;
+        uint64_t pending = __ballot(G.have);
         while (pending) {
             const int f = __builtin_ctzll(pending);
             const uint32_t f_dst = __builtin_amdgcn_readlane(dst, f), f_len = __builtin_amdgcn_readlane(len, f),
@@ -368,21 +408,28 @@ __device__ void resolve_matches(LT& L, const uint8_t* out, uint32_t rb_base, uin
                     if (k < f_len) v = window_byte(L, out, f_dst - f_dist + (k % f_dist), rb_base);
                     if (k < f_len) L.rb[f_dst + k - rb_base] = v;
                 }
-                wave_lds_sync();
+                wave_lds_fence();      // (the DS unit runs one wave's instructions in order: the next step's reads see these writes without a drain)
                 pending &= ~(1ull << f);
                 continue;
             }
-            // short matches whose source lies entirely below the first unresolved destination: one per lane, together.
-            // All source bytes are requested before the first is stored (a source in frame memory is a microsecond away:
-            // one wait per round, not one per byte).
-            const bool ready = ((pending >> lane) & 1) && len <= 8 && dist >= len && dst - dist + len <= f_dst;
-            uint8_t tmp[8];
+            // short matches whose source lies entirely below the first unresolved destination: one per lane, together
+            const bool ready = ((pending >> lane) & 1) && len <= 8 && dist >= len && srcp + len <= f_dst;
+            const uint32_t sa = (ready && !G.far) ? srcp - rb_base : 0u, da = ready ? dst - rb_base : 0u, ln = ready ? len : 0u;
+            const uint32_t sh = srcp & 3u;          // (rb_base is a multiple of 4: the same shift in the window and in frame memory)
+            const bool need8 = __ballot(ln > 4u) != 0;
+            uint32_t w0 = rw[sa >> 2], w1 = rw[(sa >> 2) + 1], w2 = need8 ? rw[(sa >> 2) + 2] : 0u;
+            w0 = G.far ? G.g[0] : w0;
+            w1 = G.far ? G.g[1] : w1;
+            w2 = G.far ? G.g[2] : w2;
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
 #pragma unroll
-            for (int k = 0; k < 8; k++) tmp[k] = (ready && (uint32_t)k < len) ? window_byte(L, out, dst - dist + k, rb_base) : (uint8_t)0;
+            for (int k = 0; k < 4; k++) L.rb[(uint32_t)k < ln ? da + k : kSpare] = (uint8_t)(lo >> (8 * k));
+            if (need8) {
+                const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (ready && (uint32_t)k < len) L.rb[dst + k - rb_base] = tmp[k];
-            wave_lds_sync();
+                for (int k = 4; k < 8; k++) L.rb[(uint32_t)k < ln ? da + k : kSpare] = (uint8_t)(hi >> (8 * (k - 4)));
+            }
+            wave_lds_fence();
             pending &= ~__ballot(ready);
         }
     }
@@ -1417,9 +1464,12 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
 // round buffer + match list only (26 KB: six waves per CU where InflateLds' tables and stage left room for four)
 struct LzLds {
     static constexpr uint32_t kIterOut = 8192, kMatchCap = 2048;
+    // earlier output kept in LDS; sources older than that are fetched from frame memory a group of 64 matches ahead
+    // (resolve_matches).  2 KB and 8 KB measured the same once that fetch was off the steps' critical path.
+    static constexpr uint32_t kWin = UCFP_PNG_LZ_WINDOW;
     uint32_t m_dst[kMatchCap];
     uint32_t m_ld[kMatchCap];                             // len << 16 | (dist - 1)
-    uint8_t rb[kHist + kIterOut + 8];
+    alignas(4) uint8_t rb[kWin + kIterOut + 8];
 };
 
 template <class C>
@@ -1440,7 +1490,12 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
     uint32_t tpos = 0, outpos = 0;
     bool bad = false;
     Adler adler;
+#ifdef PNG_PROF
+    unsigned long long _acc[16] = {0};
+#endif
+    PROF_T0();
     while (tpos < ntok && !bad) {
+        PROF_CNT(9, 1);
         // my words, and whether the first of them is the second half of a match that began before them
         const uint32_t w0 = tpos + (uint32_t)lane * kTPL;
         uint32_t wd[kTPL + 1];
@@ -1480,11 +1535,12 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
         const uint32_t cb = wave_incl_scan(nb, lane), cm = wave_incl_scan(nm, lane);
         const bool fits = cb <= C::kIterOut && cm <= C::kMatchCap && outpos + cb <= raw_n;
         const int take = __popcll(__ballot(fits));
+        PROF_ADD(0);      // token words, counts, scans
         if (take == 0) {                      // (a lane's 16 words are at most 16 x 258 bytes: only the image's size can refuse them)
             bad = true;
             break;
         }
-        const uint32_t rb_base = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
+        const uint32_t rb_base = outpos > C::kWin ? (outpos - C::kWin) & ~3u : 0u;
         bool far = false;
         if (lane < take) {
             uint32_t p = outpos + cb - nb, mi = cm - nm, rd = 0, run_len = 0;
@@ -1520,32 +1576,41 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
             break;
         }
         const uint32_t add = __shfl(cb, take - 1, 64), nmt = __shfl(cm, take - 1, 64);
-        resolve_matches(L, out, rb_base, nmt, lane);      // (four groups of 64 entries per step measured slower: 1000 files 217 k -> 144 k images/s --
+        PROF_ADD(1);      // literals and match list
+        PROF_CNT(12, nmt);
+#ifdef PNG_PROF
+        resolve_matches(L, out, rb_base, nmt, lane, &_acc[13], &_acc[14]);
+#else
+        resolve_matches(L, out, rb_base, nmt, lane);
+#endif
+        PROF_ADD(2);      // matches      // (four groups of 64 entries per step measured slower: 1000 files 217 k -> 144 k images/s --
                                                            // the chains are real dependencies: 98 % of a level-1 photograph's bytes come from matches, so a source
                                                            // inside the round lies in an earlier match's destination)
         flush_out(L, out, outpos, outpos + add, rb_base, lane);
         adler.add(add, [&](uint32_t j) { return (uint32_t)L.rb[outpos + j - rb_base]; }, lane);
         __threadfence_block();
         outpos += add;
+        PROF_ADD(3);      // flush + Adler
         {
-            const uint32_t nb2 = outpos > kHist ? (outpos - kHist) & ~3u : 0u;
+            const uint32_t nb2 = outpos > C::kWin ? (outpos - C::kWin) & ~3u : 0u;
             const uint32_t shift = nb2 - rb_base, keep = (outpos - nb2 + 3) / 4;
             if (shift) {
-                uint32_t wv[(kHist + 4) / 4 / 64 + 1];
+                uint32_t wv[(C::kWin + 4) / 4 / 64 + 1];
 #pragma unroll
-                for (int i = 0; i < (int)((kHist + 4) / 4 / 64 + 1); i++) {
+                for (int i = 0; i < (int)((C::kWin + 4) / 4 / 64 + 1); i++) {
                     const uint32_t wi = lane + 64 * i;
                     wv[i] = wi < keep ? *reinterpret_cast<const uint32_t*>(&L.rb[shift + 4 * wi]) : 0u;
                 }
                 wave_lds_sync();
 #pragma unroll
-                for (int i = 0; i < (int)((kHist + 4) / 4 / 64 + 1); i++) {
+                for (int i = 0; i < (int)((C::kWin + 4) / 4 / 64 + 1); i++) {
                     const uint32_t wi = lane + 64 * i;
                     if (wi < keep) *reinterpret_cast<uint32_t*>(&L.rb[4 * wi]) = wv[i];
                 }
                 wave_lds_sync();
             }
         }
+        PROF_ADD(4);      // window slide
         // words consumed: the taken lanes' (a match head in a lane's last word takes its distance from the next lane's first)
         tpos += (uint32_t)take * kTPL;
     }
@@ -1558,6 +1623,10 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
             ((uint32_t)z[e] << 24 | (uint32_t)z[e + 1] << 16 | (uint32_t)z[e + 2] << 8 | z[e + 3]) != adler.value())
             checksum_only = true;
     }
+#ifdef PNG_PROF
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_png_prof[i], _acc[i]);
+#endif
     if (lane == 0) {
         if (bad) info[img].status = UCFP_E_MODALITY;
         else if (checksum_only) info[img].status = UCFP_IMAGE_NEEDS_HOST;

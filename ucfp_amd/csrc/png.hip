@@ -1467,8 +1467,8 @@ struct LzLds {
     // earlier output kept in LDS; sources older than that are fetched from frame memory a group of 64 matches ahead
     // (resolve_matches).  2 KB and 8 KB measured the same once that fetch was off the steps' critical path.
     static constexpr uint32_t kWin = UCFP_PNG_LZ_WINDOW;
-    uint32_t m_dst[kMatchCap];
-    uint32_t m_ld[kMatchCap];                             // len << 16 | (dist - 1)
+    uint32_t m_dst[kMatchCap + 4];                        // (+ a spare slot for the places that list nothing)
+    uint32_t m_ld[kMatchCap + 4];                         // len << 16 | (dist - 1)
     alignas(4) uint8_t rb[kWin + kIterOut + 8];
 };
 
@@ -1493,29 +1493,45 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
 #ifdef PNG_PROF
     unsigned long long _acc[16] = {0};
 #endif
+    // a lane's words of a round: kTPL / 8 16-byte pieces (the token area is padded: reading past ntok stays inside it), the word
+    // before them and the word behind them.  The NEXT round's are requested as soon as this round knows how many lanes it takes:
+    // their round trip (5 k of a round's 54 k cycles) runs under the match resolution.
+    struct Words {
+        uint4 v[kTPL / 8];
+        uint32_t before, after;
+    };
+    auto fetch_words = [&](uint32_t tp) {
+        Words Wd;
+        const uint32_t w0 = tp + (uint32_t)lane * kTPL;
+        Wd.before = w0 > 0 && w0 <= ntok ? tok[w0 - 1] : 0u;
+        const uint4* t4 = reinterpret_cast<const uint4*>(tok + w0);
+#pragma unroll
+        for (uint32_t q = 0; q < kTPL / 8; q++) {
+            Wd.v[q] = make_uint4(0, 0, 0, 0);
+            if (w0 + 8 * q < ntok) Wd.v[q] = t4[q];
+        }
+        Wd.after = w0 + kTPL < ntok ? tok[w0 + kTPL] : 0u;
+        return Wd;
+    };
     PROF_T0();
+    Words Nx = fetch_words(0);
     while (tpos < ntok && !bad) {
         PROF_CNT(9, 1);
         // my words, and whether the first of them is the second half of a match that began before them
         const uint32_t w0 = tpos + (uint32_t)lane * kTPL;
         uint32_t wd[kTPL + 1];
-        const uint32_t before = w0 > 0 && w0 <= ntok ? tok[w0 - 1] : 0u;
-        {
-            // the lane's words as whole 16-byte pieces (the token area is padded: reading past ntok stays inside it)
-            const uint4* t4 = reinterpret_cast<const uint4*>(tok + w0);
+        const Words Cur = Nx;
+        const uint32_t before = Cur.before;
 #pragma unroll
-            for (uint32_t q = 0; q < kTPL / 8; q++) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (w0 + 8 * q < ntok) v = t4[q];
-                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t q = 0; q < kTPL / 8; q++) {
+            const uint32_t x[4] = {Cur.v[q].x, Cur.v[q].y, Cur.v[q].z, Cur.v[q].w};
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    wd[8 * q + 2 * c] = w0 + 8 * q + 2 * c < ntok ? (x[c] & 0xffffu) : 0u;
-                    wd[8 * q + 2 * c + 1] = w0 + 8 * q + 2 * c + 1 < ntok ? (x[c] >> 16) : 0u;
-                }
+            for (int c = 0; c < 4; c++) {
+                wd[8 * q + 2 * c] = w0 + 8 * q + 2 * c < ntok ? (x[c] & 0xffffu) : 0u;
+                wd[8 * q + 2 * c + 1] = w0 + 8 * q + 2 * c + 1 < ntok ? (x[c] >> 16) : 0u;
             }
-            wd[kTPL] = w0 + kTPL < ntok ? tok[w0 + kTPL] : 0u;
         }
+        wd[kTPL] = Cur.after;
         // Matches that follow one another with the SAME distance are one longer match (byte by byte the copy is the same):
         // level-1 streams of photographs are chains of 3-byte matches one pixel back, each depending on the one before --
         // as separate list entries they resolve a handful per step, merged they are periodic runs the whole wave copies.
@@ -1540,33 +1556,30 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
             bad = true;
             break;
         }
+        Nx = fetch_words(tpos + (uint32_t)take * kTPL);
         const uint32_t rb_base = outpos > C::kWin ? (outpos - C::kWin) & ~3u : 0u;
         bool far = false;
-        if (lane < take) {
+        {
+            // straight-line: every lane runs the 32 places; a place that writes nothing writes to a spare byte / spare list slot
+            const bool act = lane < take;
+            constexpr uint32_t kSpareB = sizeof(L.rb) - 4, kSpareM = C::kMatchCap;
             uint32_t p = outpos + cb - nb, mi = cm - nm, rd = 0, run_len = 0;
             bool dn = (before & 0x8000u) != 0;
 #pragma unroll
             for (uint32_t j = 0; j < kTPL; j++) {
-                const bool have = w0 + j < ntok;
+                const bool have = act && w0 + j < ntok;
                 const bool head = have && !dn && (wd[j] & 0x8000u);
                 const bool lit = have && !dn && !(wd[j] & 0x8000u);
-                if (lit) L.rb[p - rb_base] = (uint8_t)wd[j];
-                if (head) {
-                    const uint32_t len = (wd[j] & 0xffu) + 3u, dw = wd[j + 1] + 1u, dist = (wd[j + 1] & 0x7fffu) + 1u;
-                    if (dw != rd) {                       // a new entry (the run before it, if any, is complete)
-                        if (dist > p) far = true;
-                        L.m_dst[mi] = p;
-                        run_len = 0;
-                        mi++;
-                    }
-                    run_len += len;
-                    L.m_ld[mi - 1] = run_len << 16 | (dist - 1u);      // (a 32-word lane holds at most 16 x 258 bytes: 16 bits)
-                    rd = dw;
-                    p += len;
-                } else if (lit) {
-                    p++;
-                    rd = 0;
-                }
+                const uint32_t len = (wd[j] & 0xffu) + 3u, dw = wd[j + 1] + 1u, dist = (wd[j + 1] & 0x7fffu) + 1u;
+                const bool isnew = head && dw != rd;            // a new entry (the run before it, if any, is complete)
+                L.rb[lit ? p - rb_base : kSpareB] = (uint8_t)wd[j];
+                far = far || (isnew && dist > p);
+                L.m_dst[isnew ? mi : kSpareM] = p;
+                mi += isnew ? 1u : 0u;
+                run_len = isnew ? len : run_len + (head ? len : 0u);
+                L.m_ld[head ? mi - 1u : kSpareM] = run_len << 16 | (dist - 1u);      // (a 32-word lane holds at most 16 x 258 bytes: 16 bits)
+                rd = head ? dw : lit ? 0u : rd;
+                p += head ? len : lit ? 1u : 0u;
                 dn = head;
             }
         }

@@ -1175,6 +1175,10 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
     }
     uint32_t bp = 16, outpos = 0, tpos = 0;
     bool last = false;
+#ifdef PNG_PROF
+    unsigned long long _acc[16] = {0};
+#endif
+    PROF_T0();
     while (!bad && !last) {
         // ---- block header and tables: wave 0, from the first 192 words behind bp; the others wait
         const uint32_t hs0 = stage_fill(bp, 192 < LT::kStageWords ? 192 : LT::kStageWords);
@@ -1336,9 +1340,11 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
             continue;
         }
         bp = bp_sym;
+        PROF_ADD(0);      // header + tables
         // ---- the block's symbols, one speculation round of T subsequences after the other ----
         bool eob = false;
         while (!eob && !bad) {
+            PROF_CNT(9, 1);
             if (tid == 0) L.bc[6] = L.bc[7] = 0;     // (read for the last time two barriers ago; the stage fill's barrier publishes it)
             const uint32_t s0 = stage_fill(bp, LT::kStageWords);
             const uint32_t r0 = bp - s0;
@@ -1347,6 +1353,7 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
             cache.clear();
             Parse2 P{vbase, vbase, 0, 0};
             uint32_t start = vbase;
+            PROF_ADD(1);  // stage
             if (warm) {   // warm-up through the predecessor's subsequence (see png_inflate_kernel)
                 // (warm = 2 / 4: only the last half / quarter of it -- 1000 files x 4 waves 186 k / 176 k images/s against 217 k; warm = 3: the
                 // two subsequences before mine)
@@ -1355,7 +1362,9 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
                 if (tid > 0 && !Wm.stopped()) start = Wm.exit;
             }
             uint32_t nvalid = 0;
+            PROF_ADD(2);  // warm-up
             for (uint32_t it = 0;; it++) {
+                PROF_CNT(10, 1);
                 const uint32_t par = it & 1u;
                 const bool skip = start < vbase;
                 bool miss = !skip && !cache.find(start, &P);
@@ -1407,17 +1416,21 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
                     break;
                 }
             }
+            PROF_ADD(3);  // chain iterations
+            PROF_CNT(11, nvalid);
             // ---- the confirmed prefix: positions of its bytes and token words
             const bool in = (uint32_t)tid < nvalid;
             uint64_t tot;
             const uint64_t inc = wg_scan(in ? ((uint64_t)P.ntok << 32 | P.nbytes()) : 0ull, tot, 0);
             const uint32_t cb = (uint32_t)inc, ct = (uint32_t)(inc >> 32);
             const bool fits = in && outpos + cb <= raw_n;
+            PROF_ADD(4);  // scan
             // (measured and dropped: counted parses that also record their tokens in per-thread scratch, the accepted parse then
             // copied instead of decoded once more -- the recording's stores cost more than the decode they save: 1000 files 216 k ->
             // 202 k images/s, 8000 files 300 k -> 282 k)
             bool far = false;
             if (fits) far = parse_tok<true>(L, P.start, limit, outpos + cb - P.nbytes(), tok + tpos + (ct - P.ntok)).err() && !P.err();
+            PROF_ADD(5);  // emit
             // the last subsequence taken decides how the round ends
             const uint64_t fm = __ballot(fits);
             const bool is_end = fits && (lane == 63 ? true : !((fm >> (lane + 1)) & 1));      // last fitting lane of this wave
@@ -1449,9 +1462,14 @@ __global__ __launch_bounds__(64 * W) void png_huff_kernel(const uint8_t* __restr
             bp = s0 + ex_bits;
             if ((endf & 2u) || bp > total_bits) bad = true;
             eob = endf & 1u;
+            PROF_ADD(6);  // round end
         }
     }
     if (!bad && outpos != raw_n) bad = true;
+#if defined(PNG_PROF) && defined(PNG_PROF_HUFF)      // (the LZ pass reports into the same slots: one of the two per build)
+    if (tid == 0)
+        for (int i = 0; i < 12; i++) atomicAdd(&g_png_prof[i], _acc[i]);
+#endif
     if (tid == 0) {
         if (bad) info[img].status = UCFP_E_MODALITY;
         tinfo[img].ntok = tpos;
@@ -1636,7 +1654,7 @@ __global__ __launch_bounds__(64) void png_lz_kernel(const uint8_t* __restrict__ 
             ((uint32_t)z[e] << 24 | (uint32_t)z[e + 1] << 16 | (uint32_t)z[e + 2] << 8 | z[e + 3]) != adler.value())
             checksum_only = true;
     }
-#ifdef PNG_PROF
+#if defined(PNG_PROF) && !defined(PNG_PROF_HUFF)
     if (lane == 0)
         for (int i = 0; i < 16; i++) atomicAdd(&g_png_prof[i], _acc[i]);
 #endif

@@ -1083,30 +1083,35 @@ __device__ __forceinline__ Parse2 parse_tok(LT& L, uint32_t start, uint32_t limi
     return Parse2{start, pos, nb | nm << 17 | flags << 30, nt};
 }
 
+// The parses a lane has made in this round, by start position (see ParseCache).  Four register vectors: as an array of structs
+// indexed by `next` (or as scalars / structs under selects) the compiler keeps it in scratch memory -- 80-112 bytes per lane and a
+// round trip to memory at every find / put.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct ParseCache2 {
-    static constexpr int kWays = 4;
-    Parse2 way[kWays];
-    int next;
+    u32x4 s, e, p, n;
+    uint32_t next;
     __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int i = 0; i < kWays; i++) way[i] = Parse2{0xffffffffu, 0, 0, 0};
+        s = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        e = p = n = u32x4{0, 0, 0, 0};
         next = 0;
     }
     __device__ __forceinline__ bool find(uint32_t start, Parse2* out) const {
-        bool hit = false;
-#pragma unroll
-        for (int i = 0; i < kWays; i++)
-            if (way[i].start == start) {
-                *out = way[i];
-                hit = true;
-            }
+        const bool h0 = s.x == start, h1 = s.y == start, h2 = s.z == start, h3 = s.w == start;
+        const bool hit = h0 || h1 || h2 || h3;
+        if (hit) {
+            out->start = start;
+            out->exit = h0 ? e.x : h1 ? e.y : h2 ? e.z : e.w;
+            out->packed = h0 ? p.x : h1 ? p.y : h2 ? p.z : p.w;
+            out->ntok = h0 ? n.x : h1 ? n.y : h2 ? n.z : n.w;
+        }
         return hit;
     }
-    __device__ __forceinline__ void put(const Parse2& p) {
-#pragma unroll
-        for (int i = 0; i < kWays; i++)
-            if (next == i) way[i] = p;
-        next = (next + 1) & (kWays - 1);
+    __device__ __forceinline__ void put(const Parse2& q) {
+        s[next] = q.start;
+        e[next] = q.exit;
+        p[next] = q.packed;
+        n[next] = q.ntok;
+        next = (next + 1) & 3u;
     }
 };
 

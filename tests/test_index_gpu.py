@@ -828,6 +828,90 @@ def test_cosine_pruned_pass(gpu_ctx, n, dim, nq, k):
     ix.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dim,nq,k", [(140_001, 768, 64, 10), (131_073, 384, 49, 33), (150_000, 128, 57, 64),
+                                        (133_000, 1024, 50, 3), (140_016, 256, 48, 33), (131_072, 1152, 30, 10)])
+def test_cosine_f16_minima(gpu_ctx, n, dim, nq, k):
+    """5 .. 64 queries over rows whose dim is a multiple of 128: the chunk minima come from the f16 matrix pipe
+    (cosine_mins_f16), approximate within cosine_mins_eps; the thresholds are widened by it and the listed chunks' exact keys
+    decide.  Near-ties far inside that margin (a cluster of rows whose scores differ by 1e-6 .. 1e-3), rows of tiny and of
+    huge magnitude, rows with a few large and many f16-subnormal components, zero rows; the answer must equal the f32
+    minima's (UCFP_COSINE_NO_F16) bit for bit up to 48 queries (the same exact list pass), and the float64 reference always."""
+    import os
+    from ucfp_amd import index
+    rng = np.random.default_rng(n + dim + nq)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[rng.integers(0, n, 9)] = 0.0
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    for j in range(0, min(nq, 6)):          # a cluster around the query: 120 rows with scores 1 - O(noise^2), noise 1e-3 .. 5e-2
+        for t, pos in enumerate(rng.integers(0, n, 120)):
+            rows[pos] = queries[j] + (1e-3 + 4e-4 * t) * rng.standard_normal(dim).astype(np.float32)
+    rows[rng.integers(0, n, 50)] *= np.float32(1e-12)      # tiny rows, huge rows: same scores
+    rows[rng.integers(0, n, 50)] *= np.float32(1e12)
+    spiky = rng.integers(0, n, 200)                          # a few large components, the rest subnormal as f16 after scaling
+    rows[spiky] *= np.float32(1e-6)
+    rows[spiky, :4] = rng.standard_normal((200, 4)).astype(np.float32)
+    queries[6 % nq, 4:] *= np.float32(1e-6)
+    ids = rng.permutation(n).astype(np.uint64) * np.uint64(3) + np.uint64(7)
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, g_key, g_c = ix.search(0, queries, k)
+    _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+    for env in ("UCFP_COSINE_NO_F16", "UCFP_COSINE_PRUNE_FALLBACK"):
+        os.environ[env] = "1"
+        try:
+            d_ids, d_sc, d_key, d_c = ix.search(0, queries, k)
+        finally:
+            del os.environ[env]
+        if nq <= 48:
+            assert np.array_equal(g_c, d_c) and np.array_equal(g_ids, d_ids) and np.array_equal(g_sc, d_sc), env
+        else:
+            _check_cosine_against_f64(d_ids, d_sc, d_c, ids, rows, queries, k)
+    ix.close()
+
+
+@pytest.mark.gpu
+def test_cosine_f16_minima_out_of_range_norms_fall_back(gpu_ctx):
+    """A row or a query whose f32 norm is not a finite number in [1e-30, 1e30] (components around 1e20 and above: the sum of
+    squares overflows) cannot be scaled into f16 with a bounded error: the f16 pass raises the fallback flag and the dense pass
+    answers -- whatever the f32 arithmetic makes of such rows, with or without the f16 minima."""
+    import os
+    from ucfp_amd import index
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 140_000, 256, 20, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    rows[99_999] = queries[5] * np.float32(3e-15)           # fine: norm ~ 5e-14
+    ids = np.arange(n, dtype=np.uint64) + np.uint64(10)
+
+    def both(ix, q):
+        g = ix.search(0, q, k)
+        os.environ["UCFP_COSINE_NO_F16"] = "1"
+        try:
+            d = ix.search(0, q, k)
+        finally:
+            del os.environ["UCFP_COSINE_NO_F16"]
+        assert np.array_equal(g[3], d[3]) and np.array_equal(g[0], d[0]) and np.array_equal(g[1], d[1], equal_nan=True)
+        return g
+
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = both(ix, queries)
+    _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+    assert g_ids[5, 0] == 99_999 + 10
+    q2 = queries.copy()
+    q2[7] *= np.float32(1e25)                               # |q| = inf in f32
+    both(ix, q2)
+    ix.close()
+    rows[1234] = queries[3] * np.float32(1e25)              # |v| = inf in f32
+    rows[77] = queries[4] * np.float32(1e18)                # |v| ~ 1.6e19: in range
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g_ids, g_sc, _, g_c = both(ix, queries)
+    assert g_ids[4, 0] == 77 + 10
+    ix.close()
+
+
 def test_hamming_few_tiles_pipeline_drain(gpu_ctx, oracle):
     """Batches of up to 256 queries run the matrix-core filter as ONE pipeline across code steps (hamming_scan_mfma, stream
     path) whose last fold happens in a drain step per wave.  Tie-heavy data makes nearly every step a suspect, so every

@@ -197,7 +197,18 @@ struct CosinePrunePlan {
 };
 constexpr uint32_t kPruneCand = 2048;   // chunks per query at or below the waves' bound, ranked exactly
 bool cosine_prune_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k);
-CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k);
+CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k, bool approx = false);
+// the minima through the f16 matrix pipe (cosine.hip cosine_mins_f16): approximate within cosine_mins_eps(dim) of the exact
+// score, 5 .. 64 queries per pass; the prune kernels take the same eps; *flag raised when a norm or a score leaves the range
+// the bound holds in.  image: nq x dim halves, written with the norms by launch_cosine_norms_image
+float cosine_mins_eps(uint32_t dim);
+uint32_t cosine_list_queries(uint32_t dim);   // queries one exact list pass holds
+bool cosine_mins_f16_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k);
+int launch_cosine_norms_image(const float* queries, size_t nq, uint32_t dim, float* norms, void* image, uint32_t* flag,
+                              hipStream_t stream);
+int launch_cosine_mins_f16(const float* rows, const float* norms, size_t n, uint32_t dim, const void* image, const float* qnorm,
+                           uint32_t nq_pass, const CosinePrunePlan& p, uint32_t* mins, uint32_t* wmin, uint32_t* flag,
+                           hipStream_t stream);
 int launch_cosine_keys_dense_mfma(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                                   const float* qnorm, uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag,
                                   hipStream_t stream);
@@ -206,13 +217,15 @@ int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uin
                             hipStream_t stream);
 int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                             const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, const void* list,
-                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream);
+                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream,
+                            uint32_t q_base = 0);
 // bound[q] = k-th smallest wave minimum -> cand[q] = (minimum, chunk) of the chunks at or below it -> tau[q] = k-th smallest chunk
 // minimum; list = (query, chunk) of every chunk whose minimum is <= tau[q]; qrange[q] = (first entry, entries); *nlist = entries
 // in all; *flag raised when a query lists more than capq chunks or has no threshold.  ws: bound[nq] ccnt[nq] cand[nq][kPruneCand] x 8 B
 size_t prune_tau_ws_bytes(uint32_t nq);
 int launch_prune_tau(const uint32_t* mins, const uint32_t* wmin, const CosinePrunePlan& p, uint32_t nq, uint32_t k, uint8_t* ws,
-                     uint32_t* tau, void* list, uint32_t* nlist, void* qrange, uint32_t* flag, hipStream_t stream);
+                     uint32_t* tau, void* list, uint32_t* nlist, void* qrange, uint32_t* flag, hipStream_t stream,
+                     float eps = 0.f);   // eps: the minima are within eps of the exact scores (topk.hip relax_key)
 // best k by (key, id) of the listed chunks' keys <= tau[q]; does nothing once *flag is raised (and raises it if its own list overflows)
 int launch_prune_final(const uint32_t* ckeys, const CosinePrunePlan& p, const void* list, const void* qrange,
                        const uint32_t* tau, const uint64_t* ids, size_t n, uint32_t nq, uint32_t k, uint64_t* out_ids,

@@ -150,6 +150,8 @@ struct CosinePrune {
     const uint2* list;       // kKeysList: (query, chunk) entries
     const uint32_t* nlist;   // their number (device word)
     uint32_t* ckeys;         // kKeysList: [entry][1 << cs_shift]
+    uint32_t q_base;         // kKeysList: the pass's first query within the batch the list numbers (a batch above the LDS image's
+                             // 16 G queries is listed once and rescored in slices)
 };
 
 // Query image [nrows][qstride] in LDS from queries[nq_pass][dim] (16-byte aligned, dim % 4 == 0), zero-filled past dim and
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
                         m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
                         mq[r] = m;
                         wave_min[g][r] = min(wave_min[g][r], m);
-                    } else if (qt == qe) {
+                    } else if (qt + pr.q_base == qe) {
                         pr.ckeys[((it >> tsh) << pr.cs_shift) + ((it & (((size_t)1 << tsh) - 1)) << 4) + nn] = key;
                     }
                 }
@@ -357,6 +359,203 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
             for (int r = 0; r < 4; r++)
                 pr.wmin[(size_t)(g * 16 + 4 * q4 + r) * ((size_t)gridDim.x * kCW) + (size_t)blockIdx.x * kCW + wave] = wave_min[g][r];
     }
+}
+
+// ---- the minima of 5 .. 64 queries through the f16 matrix pipe (round 4) -----------------------------------------------
+// The chunk minima only steer the pruning (which ~k chunks get their exact keys computed by the kKeysList pass above), so they
+// need not be exact -- they need an error BOUND.  cosine_mins_f16 computes score~ = sum_i fl16(q_i / |q|) fl16(v_i / |v|) with
+// v_mfma_f32_16x16x32_f16 (16 cycles for 8192 products; the f32 tile takes 32 cycles for 1024), f32 accumulation:
+//   |score~ - score| <= 2^-10 (1 + 2^-11) sum |q^_i v^_i|   (two roundings to 11 bits, round to nearest even; <= 2^-10 by Cauchy-Schwarz)
+//                     + 2^-25 (sum |q^_i| + sum |v^_i|)     (f16 subnormals: elements below 2^-14, absolute error 2^-25)
+//                     + dim 2^-24                            (f32 accumulation, here and in the exact kernel)
+// cosine_mins_eps(dim) rounds that up; the prune kernels widen their thresholds by it (topk.hip `eps`): every row that can be
+// among the exact k best lies in a listed chunk, and the listed chunks' exact keys decide.  A row or query whose norm is
+// outside [1e-30, 1e30] (the reciprocal would leave the normal f32 range) or whose approximate score is not finite raises
+// the fallback flag: the dense pass answers.  The pass reads the rows exactly as the f32 tile does (16 rows x 64 B per wave
+// load) and is bound by that stream at every batch size it takes: 64 queries cost 4 matrix instructions of 16 cycles and
+// 8 conversions per 32-float step against 2 KiB of rows.
+// Query image: f16, normalised, in the order the B-side loads deliver the rows' floats -- lane (row, q4) of step s holds floats
+// 32 s + 4 q4 .. + 3 and 32 s + 16 + 4 q4 .. + 3 -- written once per search by cosine_norms_image, copied to LDS by every
+// workgroup with a row stride of dim halves + 16 B (ds_read_b128 conflict-free).
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool norm_in_range(float v) { return v >= 1e-30f && v <= 1e30f; }
+
+// one wave per query: |q| exactly as cosine_norms computes it, and the query's row of the f16 image (dim % 32 == 0)
+__global__ __launch_bounds__(256) void cosine_norms_image(const float* __restrict__ queries, size_t nq, uint32_t dim,
+                                                          float* __restrict__ norms, _Float16* __restrict__ image,
+                                                          uint32_t* __restrict__ flag) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= nq) return;
+    const float* v = queries + row * dim;
+    float acc = 0.f;
+    for (uint32_t i = lane; i < dim; i += 64) acc = fmaf(v[i], v[i], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    const float qn = sqrtf(acc);
+    if (lane == 0) {
+        norms[row] = qn;
+        if (qn != 0.f && !norm_in_range(qn)) *flag = 1;   // (NaN too)
+    }
+    const float s = norm_in_range(qn) ? 1.0f / qn : 0.f;
+    for (uint32_t c = 4 * lane; c < dim; c += 256) {
+        const f32x4v x = *reinterpret_cast<const f32x4v*>(v + c);
+        f16x4v h;
+#pragma unroll
+        for (int e = 0; e < 4; e++) h[e] = (_Float16)(x[e] * s);
+        const uint32_t st = c >> 5, r = c & 31u;
+        *reinterpret_cast<f16x4v*>(image + row * dim + st * 32 + ((r & 15u) >> 2) * 8 + (r >> 4) * 4) = h;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(kCW * 64) void cosine_mins_f16(const float* __restrict__ rows, const float* __restrict__ norms,
+                                                            size_t n, uint32_t dim, const _Float16* __restrict__ image,
+                                                            const float* __restrict__ qnorm, uint32_t nq_pass,
+                                                            uint32_t* __restrict__ flag, CosinePrune pr) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t qimg[];   // [16 G][dim halves + 16 B]
+    const uint32_t stride = dim * 2 + 16;
+    {   // the image: 16-byte pieces, all of a thread's loads requested before its first store
+        const uint32_t ppr = dim / 8, total = 16u * G * ppr;
+        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 4 * kCW * 64) {
+            uint4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * kCW * 64, qt = i / ppr;
+                t[u] = make_uint4(0, 0, 0, 0);
+                if (i < total && qt < nq_pass) t[u] = *reinterpret_cast<const uint4*>(image + (size_t)i * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * kCW * 64, qt = i / ppr;
+                if (i < total) *reinterpret_cast<uint4*>(qimg + qt * stride + (i - qt * ppr) * 16) = t[u];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nn = lane & 15, q4 = lane >> 4;
+    const size_t tiles = (n + 15) / 16;
+    float qnr[G][4];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t qt = g * 16 + 4 * q4 + r;
+            qnr[g][r] = qt < nq_pass ? qnorm[qt] : 0.f;
+        }
+    constexpr int U = 8;       // float4s per buffer: this lane's 32 floats of a 128-float block of its row = 4 matrix steps
+    f32x4v xa[U], xb[U];
+    const size_t tstep = (size_t)gridDim.x * kCW;
+    auto row_ptr = [&](size_t t) {
+        const size_t r = t * 16 + nn;
+        return rows + (r < n ? r : 0) * (size_t)dim + 4 * q4;   // dead rows read row 0; their results are not used
+    };
+    auto load_block = [&](f32x4v (&x)[U], const float* __restrict__ v, uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v + c0 + 16 * u));
+    };
+    const uint8_t* __restrict__ qlane = qimg + (size_t)nn * stride + q4 * 16;
+    auto load_q = [&](f16x8v (&qv)[G], uint32_t step) {
+#pragma unroll
+        for (int g = 0; g < G; g++) qv[g] = *reinterpret_cast<const f16x8v*>(qlane + (size_t)g * 16 * stride + step * 64);
+    };
+    size_t it = (size_t)blockIdx.x * kCW + wave;
+    uint32_t wave_min[G][4];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) wave_min[g][r] = 0xffffffffu;
+    float vn_next = 0.f;
+    if (it < tiles) {
+        load_block(xa, row_ptr(it), 0);
+        vn_next = norms[it * 16 + nn < n ? it * 16 + nn : 0];
+    }
+    bool bad = false;
+    __syncthreads();   // the query image is complete
+    for (; it < tiles; it += tstep) {
+        const size_t tile_next = it + tstep;
+        const size_t row = it * 16 + nn;
+        const bool live = row < n;
+        const float* __restrict__ v = row_ptr(it);
+        const float vn = vn_next;
+        const bool scored = live && vn != 0.f;
+        if (scored && !norm_in_range(vn)) bad = true;
+        const float sv = scored && norm_in_range(vn) ? 1.0f / vn : 0.f;
+        f32x4v acc[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        f16x8v qA[G], qB[G];
+        load_q(qA, 0);
+        auto operand = [&](const f32x4v& lo, const f32x4v& hi) {
+            f16x8v b;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                b[e] = (_Float16)(lo[e] * sv);
+                b[4 + e] = (_Float16)(hi[e] * sv);
+            }
+            return b;
+        };
+        auto consume = [&](const f32x4v (&x)[U], uint32_t step0) {
+#pragma unroll
+            for (int u = 0; u < U; u += 4) {
+                load_q(qB, step0 + u / 2 + 1);
+                const f16x8v b0 = operand(x[u], x[u + 1]);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qA[g], b0, acc[g], 0, 0, 0);
+                load_q(qA, step0 + u / 2 + 2);     // (one step past the row's end at the very last: inside the image's slack, unused)
+                const f16x8v b1 = operand(x[u + 2], x[u + 3]);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qB[g], b1, acc[g], 0, 0, 0);
+            }
+        };
+        for (uint32_t c0 = 0; c0 < dim; c0 += 256) {
+            const bool second = c0 + 128 < dim;   // wave-uniform: dim is a multiple of 128
+            if (second) load_block(xb, v, c0 + 128);
+            consume(xa, c0 / 32);
+            if (c0 + 256 < dim) {
+                load_block(xa, v, c0 + 256);
+            } else if (tile_next < tiles) {       // xa is free: the next tile's first block travels during the rest
+                load_block(xa, row_ptr(tile_next), 0);
+                vn_next = norms[tile_next * 16 + nn < n ? tile_next * 16 + nn : 0];
+            }
+            if (second) consume(xb, c0 / 32 + 4);
+        }
+        // D: col = lane & 15 = row in tile, row = 4 (lane >> 4) + reg = query in group
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            uint32_t mq[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t key = 0xffffffffu;
+                if (scored && qnr[g][r] != 0.f) {
+                    const float sc = acc[g][r];
+                    if (!(fabsf(sc) <= 2.0f)) bad = true;
+                    key = score_to_key(sc);
+                }
+                uint32_t m = key;
+                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));   // row_ror:8
+                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));   // row_ror:4
+                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));   // row_ror:2
+                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
+                mq[r] = m;
+                wave_min[g][r] = min(wave_min[g][r], m);
+            }
+            if (nn == 0)
+                *reinterpret_cast<uint4*>(pr.mins + it * (16 * G) + g * 16 + 4 * q4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
+        }
+    }
+    if (nn == 0) {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                pr.wmin[(size_t)(g * 16 + 4 * q4 + r) * ((size_t)gridDim.x * kCW) + (size_t)blockIdx.x * kCW + wave] = wave_min[g][r];
+    }
+    if (__any(bad) && lane == 0) *flag = 1;
 }
 
 // ---- 5 .. 48 queries: the row stream through v_mfma_f32_4x4x1_16B_f32 ------------------------------------------
@@ -991,7 +1190,49 @@ bool cosine_prune_ok(const float* rows, uint32_t dim, const float* queries, uint
     return nq_pass > 4 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32) && mfma_ok(rows, dim) &&
            nq_pass <= (uint32_t)16 * mfma_groups(dim) && !gemm_path(rows, dim, queries, nq_pass);
 }
-CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k) {
+// ---- the f16 minima (cosine_mins_f16) ----
+float cosine_mins_eps(uint32_t dim) { return 9.9e-4f + 1.25e-7f * (float)dim; }   // the bound derived at the kernel, rounded up
+uint32_t cosine_list_queries(uint32_t dim) { return (uint32_t)16 * (uint32_t)mfma_groups(dim); }
+bool cosine_mins_f16_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k) {
+    if (!(nq_pass > 4 && nq_pass <= 64 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32))) return false;
+    if (dim % 128 != 0 || !mfma_ok(rows, dim) || (reinterpret_cast<uintptr_t>(queries) & 15u) != 0) return false;
+    const uint32_t G = (nq_pass + 15) / 16;
+    if ((size_t)16 * G * ((size_t)dim * 2 + 16) + 64 > 156u * 1024u) return false;
+    // a batch above the exact list pass's image is rescored in slices and falls back to the GEMM's dense keys
+    return nq_pass <= cosine_list_queries(dim) || gemm_path(rows, dim, queries, nq_pass);
+}
+int launch_cosine_norms_image(const float* queries, size_t nq, uint32_t dim, float* norms, void* image, uint32_t* flag,
+                              hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(cosine_norms_image, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, queries, nq, dim, norms,
+                       reinterpret_cast<_Float16*>(image), flag);
+    return 0;
+}
+int launch_cosine_mins_f16(const float* rows, const float* norms, size_t n, uint32_t dim, const void* image, const float* qnorm,
+                           uint32_t nq_pass, const CosinePrunePlan& p, uint32_t* mins, uint32_t* wmin, uint32_t* flag,
+                           hipStream_t stream) {
+    CosinePrune pr{};
+    pr.mins = mins;
+    pr.wmin = wmin;
+    pr.qpad = p.qpad;
+    pr.cs_shift = p.cs_shift;
+    const int G = (int)((nq_pass + 15) / 16);
+    const size_t lds = (size_t)16 * G * ((size_t)dim * 2 + 16) + 64;   // + slack for the operand prefetch past the last row
+    const unsigned grid = p.waves / kCW;
+    auto go = [&](auto kern) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kCW * 64), lds, stream, rows, norms, n, dim,
+                           reinterpret_cast<const _Float16*>(image), qnorm, nq_pass, flag, pr);
+    };
+    if (G == 1) go(cosine_mins_f16<1>);
+    else if (G == 2) go(cosine_mins_f16<2>);
+    else if (G == 3) go(cosine_mins_f16<3>);
+    else go(cosine_mins_f16<4>);
+    return 0;
+}
+
+CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k, bool approx) {
     CosinePrunePlan p;
     p.cs_shift = 4;                                              // a chunk = a 16-row tile
     p.qpad = 16u * ((nq_pass + 15) / 16);
@@ -1001,6 +1242,7 @@ CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k) {
     p.waves = grid * kCW;
     p.capq = (2 * k + 31) & ~31u;                                // chunks listed per query: k of them beat the threshold, ties add a few
     if (p.capq < 32) p.capq = 32;
+    if (approx) p.capq = (3 * k + 63) & ~31u;                    // ... and the chunks inside the widened threshold's margin
     return p;
 }
 int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
@@ -1016,8 +1258,10 @@ int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uin
 }
 int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                             const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, const void* list,
-                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream) {
+                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream,
+                            uint32_t q_base) {
     CosinePrune pr{};
+    pr.q_base = q_base;
     pr.cs_shift = p.cs_shift;
     pr.qpad = p.qpad;
     pr.list = reinterpret_cast<const uint2*>(list);

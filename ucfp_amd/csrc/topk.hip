@@ -518,8 +518,23 @@ __global__ __launch_bounds__(256) void select_pruned_u32(const uint32_t* __restr
 // (A workgroup per query that reads its own column of the minima is bound by its CU's address path, one line per lane: 80 us
 // at 16 queries, 165 at 32; a radix select over all minima serialises on one histogram bin, cosine keys share their leading
 // bytes: 51 us.)
+// Minima that are approximate within eps of the exact score (cosine.hip cosine_mins_f16): a threshold taken from them is
+// widened by eps where it bounds EXACT keys from above (k chunks hold a row whose exact score is at least score(threshold) -
+// eps) and by 2 eps where it selects chunks by their APPROXIMATE minima (a row that good scores at least score - 2 eps
+// approximately).  eps = 0: the minima are exact and nothing moves.  Keys are the inverted order image of the f32 score.
+__device__ __forceinline__ uint32_t relax_key(uint32_t key, float d) {
+    if (d == 0.f || key == 0xffffffffu) return key;
+    uint32_t u = ~key;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    const float s = __uint_as_float(u) - d;
+    uint32_t v = __float_as_uint(s);
+    v = (v & 0x80000000u) ? ~v : (v | 0x80000000u);
+    const uint32_t r = ~v;
+    return r < key ? key : r;      // (never tighter)
+}
+
 __global__ __launch_bounds__(256) void prune_bound_kernel(const uint32_t* __restrict__ wmin, uint32_t waves, uint32_t k,
-                                                          uint32_t* __restrict__ bound, uint32_t* __restrict__ ccnt) {
+                                                          uint32_t* __restrict__ bound, uint32_t* __restrict__ ccnt, float eps) {
     // 256 threads (k <= 64 < 256): 1024 of them ranking 1024 minima against each other took 46 us on their one CU
     __shared__ __attribute__((aligned(16))) uint32_t s_tmin[256];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -537,7 +552,7 @@ __global__ __launch_bounds__(256) void prune_bound_kernel(const uint32_t* __rest
         rank += (o.z < m || (o.z == m && u + 2 < tid)) ? 1u : 0u;
         rank += (o.w < m || (o.w == m && u + 3 < tid)) ? 1u : 0u;
     }
-    if (rank == k - 1) bound[q] = m;   // 0xffffffff: fewer than k threads saw a scored row -- no threshold
+    if (rank == k - 1) bound[q] = relax_key(m, 2.f * eps);   // 0xffffffff: fewer than k threads saw a scored row -- no threshold
 }
 
 // thread = four consecutive queries of one chunk (a uint4 of mins[chunk][qpad]; qpad is a multiple of 16)
@@ -568,7 +583,7 @@ __global__ __launch_bounds__(256) void prune_tau_kernel(const uint32_t* __restri
                                                         const uint2* __restrict__ cand, uint32_t k, uint32_t capq,
                                                         uint32_t* __restrict__ tau_out, uint2* __restrict__ list,
                                                         uint32_t* __restrict__ nlist, uint2* __restrict__ qrange,
-                                                        uint32_t* __restrict__ flag) {
+                                                        uint32_t* __restrict__ flag, float eps) {
     __shared__ uint32_t s_ck[kPruneCand], s_cc[kPruneCand];
     __shared__ uint32_t s_tau, s_cnt, s_put, s_base;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -596,7 +611,8 @@ __global__ __launch_bounds__(256) void prune_tau_kernel(const uint32_t* __restri
         if (rank == k - 1) s_tau = v;
     }
     __syncthreads();
-    const uint32_t tau = s_tau;
+    const uint32_t tau_exact = relax_key(s_tau, eps);      // bounds the k-th best exact key
+    const uint32_t tau = relax_key(s_tau, 2.f * eps);      // selects chunks by their (approximate) minima
     for (uint32_t e = tid; e < cn; e += 256)
         if (s_ck[e] <= tau) atomicAdd(&s_cnt, 1u);
     __syncthreads();
@@ -604,14 +620,14 @@ __global__ __launch_bounds__(256) void prune_tau_kernel(const uint32_t* __restri
     if (total > capq) {           // ties in bulk at the threshold: the dense path prunes them while it gathers
         if (tid == 0) {
             *flag = 1;
-            tau_out[q] = tau;
+            tau_out[q] = tau_exact;
             qrange[q] = make_uint2(0, 0);
         }
         return;
     }
     if (tid == 0) {
         s_base = atomicAdd(nlist, total);
-        tau_out[q] = tau;
+        tau_out[q] = tau_exact;
     }
     __syncthreads();
     const uint32_t base = s_base;
@@ -686,12 +702,12 @@ __global__ __launch_bounds__(256) void prune_final_kernel(const uint32_t* __rest
 
 size_t prune_tau_ws_bytes(uint32_t nq) { return (size_t)nq * 8 + 256 + (size_t)nq * kPruneCand * 8; }
 int launch_prune_tau(const uint32_t* mins, const uint32_t* wmin, const CosinePrunePlan& p, uint32_t nq, uint32_t k, uint8_t* ws,
-                     uint32_t* tau, void* list, uint32_t* nlist, void* qrange, uint32_t* flag, hipStream_t stream) {
+                     uint32_t* tau, void* list, uint32_t* nlist, void* qrange, uint32_t* flag, hipStream_t stream, float eps) {
     if (nq == 0) return 0;
     uint32_t* bound = reinterpret_cast<uint32_t*>(ws);
     uint32_t* ccnt = bound + nq;
     uint2* cand = reinterpret_cast<uint2*>(ws + (((size_t)nq * 8 + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(prune_bound_kernel, dim3(nq), dim3(256), 0, stream, wmin, p.waves, k, bound, ccnt);
+    hipLaunchKernelGGL(prune_bound_kernel, dim3(nq), dim3(256), 0, stream, wmin, p.waves, k, bound, ccnt, eps);
     const size_t units = (size_t)p.nchunks * (p.qpad / 4);
     unsigned grid = (unsigned)((units + 255) / 256);
     if (grid > 256 * 8) grid = 256 * 8;
@@ -699,7 +715,7 @@ int launch_prune_tau(const uint32_t* mins, const uint32_t* wmin, const CosinePru
                        (const uint32_t*)bound, ccnt, cand);
     hipLaunchKernelGGL(prune_tau_kernel, dim3(nq), dim3(256), 0, stream, (const uint32_t*)bound, (const uint32_t*)ccnt,
                        (const uint2*)cand, k, p.capq, tau, reinterpret_cast<uint2*>(list), nlist,
-                       reinterpret_cast<uint2*>(qrange), flag);
+                       reinterpret_cast<uint2*>(qrange), flag, eps);
     return 0;
 }
 int launch_prune_final(const uint32_t* ckeys, const CosinePrunePlan& p, const void* list, const void* qrange,

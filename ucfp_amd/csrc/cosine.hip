@@ -417,8 +417,9 @@ __global__ __launch_bounds__(kCW * 64) void cosine_mins_f16(const float* __restr
                                                             size_t n, uint32_t dim, const _Float16* __restrict__ image,
                                                             const float* __restrict__ qnorm, uint32_t nq_pass,
                                                             uint32_t* __restrict__ flag, CosinePrune pr) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t qimg[];   // [16 G][dim halves + 16 B]
+    extern __shared__ __attribute__((aligned(16))) uint8_t qimg[];   // [16 G][dim halves + 16 B], 64 B of slack, [wave][16][272 B] stage
     const uint32_t stride = dim * 2 + 16;
+    const uint32_t stage_off = 16u * G * stride + 64;
     {   // the image: 16-byte pieces, all of a thread's loads requested before its first store
         const uint32_t ppr = dim / 8, total = 16u * G * ppr;
         for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 4 * kCW * 64) {
@@ -447,106 +448,132 @@ __global__ __launch_bounds__(kCW * 64) void cosine_mins_f16(const float* __restr
             const uint32_t qt = g * 16 + 4 * q4 + r;
             qnr[g][r] = qt < nq_pass ? qnorm[qt] : 0.f;
         }
-    constexpr int U = 8;       // float4s per buffer: this lane's 32 floats of a 128-float block of its row = 4 matrix steps
-    f32x4v xa[U], xb[U];
+    // A wave's work is ONE stream of blocks (a block = 64 floats of the 16 rows of a tile = 4 KiB = 2 matrix steps), tile after
+    // tile.  The rows are LOADED coalesced -- a wave load is 4 rows x 256 contiguous bytes, lane = (row in 4, 16-byte piece) --
+    // and reach the matrix operand's layout (lane = (row in 16, k group)) through a 4.25 KiB stage per wave in LDS: written as
+    // loaded (a quarter wave = one row's 256 B), read back as two 16-byte pieces per lane and step with a row stride of 272 B
+    // (16 rows at one piece: 16 different bank groups).  Loaded straight into the operand layout (16 rows x 64 B per wave
+    // load, every quarter wave touching 16 lines) the pass measured 0.55 ms per million 768-d rows whatever it computed; the
+    // same bytes coalesced, 0.43.  LDS executes a wave's instructions in order, so the stage needs no barrier and no second
+    // buffer; four register buffers keep three blocks (12 KiB per wave) in flight.  Every refill is unconditional (past the
+    // end of the wave's work it reads the last tile again, into a buffer nobody uses): with loads under branches the compiler
+    // has to wait for the counter's worst case at every join, which drains the queue.
+    constexpr int R = 4, U = 4;
+    f32x4v x[R][U];
+    float nx[R];                               // the norm of this lane's operand row (row nn of the block's tile), loaded with the block
     const size_t tstep = (size_t)gridDim.x * kCW;
-    auto row_ptr = [&](size_t t) {
-        const size_t r = t * 16 + nn;
-        return rows + (r < n ? r : 0) * (size_t)dim + 4 * q4;   // dead rows read row 0; their results are not used
-    };
-    auto load_block = [&](f32x4v (&x)[U], const float* __restrict__ v, uint32_t c0) {
-#pragma unroll
-        for (int u = 0; u < U; u++) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(v + c0 + 16 * u));
-    };
+    const uint32_t nblk = dim / 64;
     const uint8_t* __restrict__ qlane = qimg + (size_t)nn * stride + q4 * 16;
+    uint8_t* __restrict__ stage = qimg + stage_off + (size_t)wave * (16 * 272);
+    uint8_t* __restrict__ st_wr = stage + (lane >> 4) * 272 + (lane & 15) * 16;      // + u * 4 * 272
+    const uint8_t* __restrict__ st_rd = stage + nn * 272 + q4 * 16;                   // + (8 s + 4 h) * 16
     auto load_q = [&](f16x8v (&qv)[G], uint32_t step) {
 #pragma unroll
         for (int g = 0; g < G; g++) qv[g] = *reinterpret_cast<const f16x8v*>(qlane + (size_t)g * 16 * stride + step * 64);
     };
-    size_t it = (size_t)blockIdx.x * kCW + wave;
+    size_t ld_tile = (size_t)blockIdx.x * kCW + wave;      // the position the next refill reads
+    uint32_t ld_blk = 0;
+    auto refill = [&](f32x4v (&xr)[U], float& nr) {
+        const size_t t = ld_tile < tiles ? ld_tile : tiles - 1;
+        const size_t rn = t * 16 + nn < n ? t * 16 + nn : n - 1;
+        nr = norms[rn];                            // FIRST: a tile's first multiply waits for it, and must not wait for the data behind it
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t r0 = t * 16 + 4 * u + (lane >> 4);
+            const size_t r = r0 < n ? r0 : n - 1;     // dead rows read the last row; their results are not used
+            xr[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(rows + r * (size_t)dim + 64 * ld_blk + 4 * (lane & 15)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (++ld_blk == nblk) {
+            ld_blk = 0;
+            ld_tile += tstep;
+        }
+    };
     uint32_t wave_min[G][4];
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
         for (int r = 0; r < 4; r++) wave_min[g][r] = 0xffffffffu;
-    float vn_next = 0.f;
-    if (it < tiles) {
-        load_block(xa, row_ptr(it), 0);
-        vn_next = norms[it * 16 + nn < n ? it * 16 + nn : 0];
-    }
+    size_t it = ld_tile;                                    // the position being consumed
+    uint32_t blk = 0;
+#pragma unroll
+    for (int b = 0; b < R; b++) refill(x[b], nx[b]);
     bool bad = false;
     __syncthreads();   // the query image is complete
-    for (; it < tiles; it += tstep) {
-        const size_t tile_next = it + tstep;
-        const size_t row = it * 16 + nn;
-        const bool live = row < n;
-        const float* __restrict__ v = row_ptr(it);
-        const float vn = vn_next;
-        const bool scored = live && vn != 0.f;
-        if (scored && !norm_in_range(vn)) bad = true;
-        const float sv = scored && norm_in_range(vn) ? 1.0f / vn : 0.f;
-        f32x4v acc[G];
+    f32x4v acc[G];
+    f16x8v qA[G], qB[G];
+    load_q(qA, 0);
+    float sv = 0.f;
+    bool scored = false;
+    auto block = [&](f32x4v (&xr)[U], float& nr) {
+        if (blk == 0) {            // wave-uniform: a tile begins
+            const bool live = it * 16 + nn < n;
+            scored = live && nr != 0.f;
+            if (scored && !norm_in_range(nr)) bad = true;
+            sv = scored && norm_in_range(nr) ? 1.0f / nr : 0.f;
 #pragma unroll
-        for (int g = 0; g < G; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        f16x8v qA[G], qB[G];
-        load_q(qA, 0);
+            for (int g = 0; g < G; g++) acc[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) *reinterpret_cast<f32x4v*>(st_wr + u * (4 * 272)) = xr[u];
+        refill(xr, nr);
+        // (aligned register pairs spelled out: left to itself the vectoriser pairs elements 1-2 and 3-0 of neighbouring pieces and
+        // repacks every register with a move)
+        const f32x2v sv2 = f32x2v{sv, sv};
         auto operand = [&](const f32x4v& lo, const f32x4v& hi) {
-            f16x8v b;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                b[e] = (_Float16)(lo[e] * sv);
-                b[4 + e] = (_Float16)(hi[e] * sv);
-            }
-            return b;
+            const f16x2v h0 = __builtin_convertvector(__builtin_shufflevector(lo, lo, 0, 1) * sv2, f16x2v);
+            const f16x2v h1 = __builtin_convertvector(__builtin_shufflevector(lo, lo, 2, 3) * sv2, f16x2v);
+            const f16x2v h2 = __builtin_convertvector(__builtin_shufflevector(hi, hi, 0, 1) * sv2, f16x2v);
+            const f16x2v h3 = __builtin_convertvector(__builtin_shufflevector(hi, hi, 2, 3) * sv2, f16x2v);
+            const f16x4v l = __builtin_shufflevector(h0, h1, 0, 1, 2, 3), h = __builtin_shufflevector(h2, h3, 0, 1, 2, 3);
+            return __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-        auto consume = [&](const f32x4v (&x)[U], uint32_t step0) {
+        const f32x4v l0 = *reinterpret_cast<const f32x4v*>(st_rd), h0 = *reinterpret_cast<const f32x4v*>(st_rd + 64);
+        const f32x4v l1 = *reinterpret_cast<const f32x4v*>(st_rd + 128), h1 = *reinterpret_cast<const f32x4v*>(st_rd + 192);
+        const uint32_t step0 = blk * 2;
+        const uint32_t next0 = blk + 1 == nblk ? 0u : step0 + 2;      // the first step of the stream's next block
+        load_q(qB, step0 + 1);
+        const f16x8v b0 = operand(l0, h0);
 #pragma unroll
-            for (int u = 0; u < U; u += 4) {
-                load_q(qB, step0 + u / 2 + 1);
-                const f16x8v b0 = operand(x[u], x[u + 1]);
+        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qA[g], b0, acc[g], 0, 0, 0);
+        load_q(qA, next0);
+        const f16x8v b1 = operand(l1, h1);
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qA[g], b0, acc[g], 0, 0, 0);
-                load_q(qA, step0 + u / 2 + 2);     // (one step past the row's end at the very last: inside the image's slack, unused)
-                const f16x8v b1 = operand(x[u + 2], x[u + 3]);
+        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qB[g], b1, acc[g], 0, 0, 0);
+        if (++blk == nblk) {       // wave-uniform: the tile is complete
+            blk = 0;
+            // D: col = lane & 15 = row in tile, row = 4 (lane >> 4) + reg = query in group
+            if (it < tiles) {
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qB[g], b1, acc[g], 0, 0, 0);
-            }
-        };
-        for (uint32_t c0 = 0; c0 < dim; c0 += 256) {
-            const bool second = c0 + 128 < dim;   // wave-uniform: dim is a multiple of 128
-            if (second) load_block(xb, v, c0 + 128);
-            consume(xa, c0 / 32);
-            if (c0 + 256 < dim) {
-                load_block(xa, v, c0 + 256);
-            } else if (tile_next < tiles) {       // xa is free: the next tile's first block travels during the rest
-                load_block(xa, row_ptr(tile_next), 0);
-                vn_next = norms[tile_next * 16 + nn < n ? tile_next * 16 + nn : 0];
-            }
-            if (second) consume(xb, c0 / 32 + 4);
-        }
-        // D: col = lane & 15 = row in tile, row = 4 (lane >> 4) + reg = query in group
+                for (int g = 0; g < G; g++) {
+                    uint32_t mq[4];
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            uint32_t mq[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                uint32_t key = 0xffffffffu;
-                if (scored && qnr[g][r] != 0.f) {
-                    const float sc = acc[g][r];
-                    if (!(fabsf(sc) <= 2.0f)) bad = true;
-                    key = score_to_key(sc);
+                    for (int r = 0; r < 4; r++) {
+                        uint32_t key = 0xffffffffu;
+                        if (scored && qnr[g][r] != 0.f) {
+                            const float sc = acc[g][r];
+                            if (!(fabsf(sc) <= 2.0f)) bad = true;
+                            key = score_to_key(sc);
+                        }
+                        uint32_t m = key;
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));   // row_ror:8
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));   // row_ror:4
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));   // row_ror:2
+                        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
+                        mq[r] = m;
+                        wave_min[g][r] = min(wave_min[g][r], m);
+                    }
+                    if (nn == 0)
+                        *reinterpret_cast<uint4*>(pr.mins + it * (16 * G) + g * 16 + 4 * q4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
                 }
-                uint32_t m = key;
-                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));   // row_ror:8
-                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));   // row_ror:4
-                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x122, 0xf, 0xf, false));   // row_ror:2
-                m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
-                mq[r] = m;
-                wave_min[g][r] = min(wave_min[g][r], m);
             }
-            if (nn == 0)
-                *reinterpret_cast<uint4*>(pr.mins + it * (16 * G) + g * 16 + 4 * q4) = make_uint4(mq[0], mq[1], mq[2], mq[3]);
+            it += tstep;
         }
+    };
+    while (it < tiles) {       // (past the wave's last tile: blocks of the last tile again, multiplied and dropped)
+#pragma unroll
+        for (int b = 0; b < R; b++) block(x[b], nx[b]);
     }
     if (nn == 0) {
 #pragma unroll
@@ -1195,9 +1222,9 @@ float cosine_mins_eps(uint32_t dim) { return 9.9e-4f + 1.25e-7f * (float)dim; } 
 uint32_t cosine_list_queries(uint32_t dim) { return (uint32_t)16 * (uint32_t)mfma_groups(dim); }
 bool cosine_mins_f16_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k) {
     if (!(nq_pass > 4 && nq_pass <= 64 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32))) return false;
-    if (dim % 128 != 0 || !mfma_ok(rows, dim) || (reinterpret_cast<uintptr_t>(queries) & 15u) != 0) return false;
+    if (dim % 64 != 0 || !mfma_ok(rows, dim) || (reinterpret_cast<uintptr_t>(queries) & 15u) != 0) return false;
     const uint32_t G = (nq_pass + 15) / 16;
-    if ((size_t)16 * G * ((size_t)dim * 2 + 16) + 64 > 156u * 1024u) return false;
+    if ((size_t)16 * G * ((size_t)dim * 2 + 16) + 64 + (size_t)kCW * 16 * 272 > 158u * 1024u) return false;
     // a batch above the exact list pass's image is rescored in slices and falls back to the GEMM's dense keys
     return nq_pass <= cosine_list_queries(dim) || gemm_path(rows, dim, queries, nq_pass);
 }
@@ -1217,7 +1244,7 @@ int launch_cosine_mins_f16(const float* rows, const float* norms, size_t n, uint
     pr.qpad = p.qpad;
     pr.cs_shift = p.cs_shift;
     const int G = (int)((nq_pass + 15) / 16);
-    const size_t lds = (size_t)16 * G * ((size_t)dim * 2 + 16) + 64;   // + slack for the operand prefetch past the last row
+    const size_t lds = (size_t)16 * G * ((size_t)dim * 2 + 16) + 64 + (size_t)kCW * 16 * 272;   // image, slack for the operand prefetch past the last row, stages
     const unsigned grid = p.waves / kCW;
     auto go = [&](auto kern) {
         if (lds > 48 * 1024)
@@ -1238,7 +1265,12 @@ CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k, bool a
     p.qpad = 16u * ((nq_pass + 15) / 16);
     p.nchunks = (uint32_t)(((n - 1) >> p.cs_shift) + 1);
     unsigned grid = (unsigned)(((size_t)p.nchunks + kCW - 1) / kCW);   // as launch_mfma sizes it
-    if (grid > 256 * 4) grid = 256 * 4;
+    unsigned cap = 256 * 4;
+    if (const char* e = approx ? getenv("UCFP_COSINE_MINS_GRID") : nullptr) {   // measurement: workgroups of the f16 minima pass
+        const int v = atoi(e);
+        if (v >= 1 && v <= 1024) cap = (unsigned)v;
+    }
+    if (grid > cap) grid = cap;
     p.waves = grid * kCW;
     p.capq = (2 * k + 31) & ~31u;                                // chunks listed per query: k of them beat the threshold, ties add a few
     if (p.capq < 32) p.capq = 32;

@@ -1099,7 +1099,7 @@ def bench_cosine(args, rank, world, dev, ctx):
     ix = index.DeviceIndex(index.COSINE_F32, dim, index.APPEND_ONLY, ctx)
     ix.append_dev(0, ids.data_ptr(), rows.data_ptr(), n, stream)
     out = {}
-    for nq in (1, 16, 32, 48, 256):
+    for nq in (1, 16, 32, 48, 64, 256):
         q = torch.randn((nq, dim), dtype=torch.float32, device=dev, generator=g)
         o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
         o_sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
@@ -1133,16 +1133,13 @@ def bench_cosine(args, rank, world, dev, ctx):
             del ref
         ok_all = ok_all and worst < 1e-5
         del rn
-        # 1 / 16 queries read the rows once per pass: HBM-bound; the 256-query pass is one f32 GEMM: MFMA-bound
-        # (157.3 TF dense f32 matrix peak, MI355X_MICROARCH.md); whole search = keys + selection
-        if nq <= 48:     # one pass over the rows (5 .. 48 queries: no key matrix, cosine.hip CosinePrune)
-            roof = {"bound": "hbm", "achieved": n * dim * 4 / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": n * dim * 4 / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes": "4 x dim x rows per pass (SURVEY 8d)"}
-        else:
-            fl = 2.0 * n * dim * nq
-            roof = {"bound": "mfma", "achieved": fl / (ms / 1e3) / 1e12, "peak": 157.3, "unit": "TFLOP/s (f32 MFMA)",
-                    "frac": fl / (ms / 1e3) / 1e12 / 157.3, "flops": "2 x dim x rows x queries"}
+        # every batch reads the rows once per pass of at most 64 queries (round 4: the chunk minima of 2 .. 64 queries come
+        # from the f16 matrix pipe, cosine.hip cosine_mins_f16, and only the listed chunks are rescored in f32): HBM-bound at
+        # every batch size; whole search = minima + thresholds + exact keys of the listed chunks + selection
+        passes = (nq + 63) // 64
+        roof = {"bound": "hbm", "achieved": passes * n * dim * 4 / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": passes * n * dim * 4 / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "passes": passes,
+                "algorithmic_bytes": "4 x dim x rows per pass of <= 64 queries (SURVEY 8d)"}
         out[f"batch{nq}"] = {"ms": ms, "qps": nq / ms * 1e3, "all_answers_match_torch_within_1e-5": ok_all,
                              "max_abs_score_diff": worst, "roofline": roof}
         if nq == 256:

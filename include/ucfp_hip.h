@@ -441,6 +441,9 @@ int ucfp_lsh_query_dev(ucfp_lsh* lsh, const uint8_t* d_query_records, size_t nq,
  * rayon's split, i.e. unspecified).  Hamming: distance d = popcount(q ^ x), score = 1 - d/64
  * so that "higher is better" holds (src/core/mod.rs:113-115).  Cosine: score =
  * dot/(|q||v|); zero-norm rows are skipped, a zero-norm query yields no hits (:283-286,:328-330).
+ * Every reported cosine score is an f32 dot product; where a batch is steered by f16 matrix-core arithmetic (the chunk
+ * minima of 2 .. 64 queries per pass, round 4) that arithmetic only selects WHICH chunks of rows get their exact scores
+ * computed, under a proven error bound -- it never reaches an answer.
  */
 typedef struct ucfp_index ucfp_index;
 

@@ -269,6 +269,7 @@ def _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k):
 def test_cosine_filtered_batch_pass(gpu_ctx, nq, k):
     """Batches over a shard of >= 2^18 rows take the thresholded GEMM pass (sample answer -> per-query threshold ->
     candidate lists); 300 queries are a full pass of 256 and a short one that goes the dense way."""
+    import os
     from ucfp_amd import index
     n, dim = 300_000, 64
     rng = np.random.default_rng(nq * 31 + k)
@@ -281,6 +282,12 @@ def test_cosine_filtered_batch_pass(gpu_ctx, nq, k):
     ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
     ix.upsert(0, ids, rows)
     g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+    os.environ["UCFP_COSINE_NO_F16"] = "1"       # (dim 64 takes the f16 minima otherwise)
+    try:
+        g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+    finally:
+        del os.environ["UCFP_COSINE_NO_F16"]
     _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
     ix.close()
 
@@ -829,12 +836,14 @@ def test_cosine_pruned_pass(gpu_ctx, n, dim, nq, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,dim,nq,k", [(140_001, 768, 64, 10), (131_073, 384, 49, 33), (150_000, 128, 57, 64),
-                                        (133_000, 1024, 50, 3), (140_016, 256, 48, 33), (131_072, 1152, 30, 10)])
-def test_cosine_f16_minima(gpu_ctx, n, dim, nq, k):
+@pytest.mark.parametrize("n,dim,nq,k,cluster", [(140_001, 768, 64, 10, 120), (131_073, 384, 49, 33, 40), (150_000, 128, 57, 64, 30),
+                                                (133_000, 1024, 50, 3, 25), (140_016, 256, 48, 33, 120), (131_072, 1152, 30, 10, 30),
+                                                (140_000, 192, 130, 10, 30), (262_144, 64, 300, 5, 20)])
+def test_cosine_f16_minima(gpu_ctx, n, dim, nq, k, cluster):
     """5 .. 64 queries over rows whose dim is a multiple of 128: the chunk minima come from the f16 matrix pipe
     (cosine_mins_f16), approximate within cosine_mins_eps; the thresholds are widened by it and the listed chunks' exact keys
-    decide.  Near-ties far inside that margin (a cluster of rows whose scores differ by 1e-6 .. 1e-3), rows of tiny and of
+    decide; batches above 64 queries go in passes.  Near-ties far inside that margin (a cluster of rows whose scores differ
+    by 1e-6 .. 1e-3: small clusters fit the chunk lists, 120 rows overflow them and the gated dense pass answers), rows of tiny and of
     huge magnitude, rows with a few large and many f16-subnormal components, zero rows; the answer must equal the f32
     minima's (UCFP_COSINE_NO_F16) bit for bit up to 48 queries (the same exact list pass), and the float64 reference always."""
     import os
@@ -844,8 +853,8 @@ def test_cosine_f16_minima(gpu_ctx, n, dim, nq, k):
     rows[rng.integers(0, n, 9)] = 0.0
     queries = rng.standard_normal((nq, dim)).astype(np.float32)
     for j in range(0, min(nq, 6)):          # a cluster around the query: 120 rows with scores 1 - O(noise^2), noise 1e-3 .. 5e-2
-        for t, pos in enumerate(rng.integers(0, n, 120)):
-            rows[pos] = queries[j] + (1e-3 + 4e-4 * t) * rng.standard_normal(dim).astype(np.float32)
+        for t, pos in enumerate(rng.integers(0, n, cluster)):
+            rows[pos] = queries[j] + (1e-3 + 4e-4 * t * (120 / cluster)) * rng.standard_normal(dim).astype(np.float32)
     rows[rng.integers(0, n, 50)] *= np.float32(1e-12)      # tiny rows, huge rows: same scores
     rows[rng.integers(0, n, 50)] *= np.float32(1e12)
     spiky = rng.integers(0, n, 200)                          # a few large components, the rest subnormal as f16 after scaling

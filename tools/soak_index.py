@@ -83,7 +83,7 @@ def main():
             ix.close()
         else:
             n = int(rng.choice([900, 5000, 40_000, 270_000, 600_000]))
-            dim = int(rng.choice([32, 64, 100, 256, 384, 512, 768, 1024]))
+            dim = int(rng.choice([32, 64, 100, 128, 192, 256, 384, 512, 640, 768, 1024]))
             nq = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 17, 33, 40, 48, 49, 130, 300]))
             k = int(rng.choice([1, 10, 20, 50, 64]))
             if n * dim > 250_000_000:
@@ -93,6 +93,15 @@ def main():
             rows = torch.randn((n, dim), dtype=torch.float32, device=dev, generator=g)
             ids = torch.randperm(n, device=dev, generator=g).to(torch.int64)
             q = torch.randn((nq, dim), dtype=torch.float32, device=dev, generator=g)
+            if rng.random() < 0.5:      # clusters of near-matches around some queries (scores 1 - O(noise^2)): inside the f16 minima's margin
+                for j in rng.integers(0, nq, int(rng.integers(1, 5))):
+                    m = int(rng.choice([5, 30, 200]))
+                    pos = torch.from_numpy(rng.integers(0, n, m)).to(dev)
+                    noise = float(rng.choice([1e-3, 1e-2, 5e-2]))
+                    rows[pos] = q[int(j)][None, :] + noise * torch.randn((m, dim), dtype=torch.float32, device=dev, generator=g)
+            if rng.random() < 0.3:      # rows of very different magnitudes: the scores do not change
+                pos = torch.from_numpy(rng.integers(0, n, 64)).to(dev)
+                rows[pos] *= float(rng.choice([1e-9, 1e-4, 1e6, 1e11]))
             ix = index.DeviceIndex(index.COSINE_F32, dim, index.APPEND_ONLY, ctx)
             ix.append_dev(0, ids.data_ptr(), rows.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
             o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)

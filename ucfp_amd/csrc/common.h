@@ -204,8 +204,8 @@ CosinePrunePlan cosine_prune_plan(size_t n, uint32_t nq_pass, uint32_t k, bool a
 float cosine_mins_eps(uint32_t dim);
 uint32_t cosine_list_queries(uint32_t dim);   // queries one exact list pass holds
 bool cosine_mins_f16_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k);
-int launch_cosine_norms_image(const float* queries, size_t nq, uint32_t dim, float* norms, void* image, uint32_t* flag,
-                              hipStream_t stream);
+int launch_cosine_norms_image(const float* queries, size_t nq, uint32_t dim, float* norms, void* image, uint32_t* zero2,
+                              hipStream_t stream);   // zero2: two words the kernel zeroes (the pass's flag and list counter)
 int launch_cosine_mins_f16(const float* rows, const float* norms, size_t n, uint32_t dim, const void* image, const float* qnorm,
                            uint32_t nq_pass, const CosinePrunePlan& p, uint32_t* mins, uint32_t* wmin, uint32_t* flag,
                            hipStream_t stream);
@@ -217,8 +217,7 @@ int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uin
                             hipStream_t stream);
 int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                             const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, const void* list,
-                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream,
-                            uint32_t q_base = 0);
+                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream);
 // bound[q] = k-th smallest wave minimum -> cand[q] = (minimum, chunk) of the chunks at or below it -> tau[q] = k-th smallest chunk
 // minimum; list = (query, chunk) of every chunk whose minimum is <= tau[q]; qrange[q] = (first entry, entries); *nlist = entries
 // in all; *flag raised when a query lists more than capq chunks or has no threshold.  ws: bound[nq] ccnt[nq] cand[nq][kPruneCand] x 8 B

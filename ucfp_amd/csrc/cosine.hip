@@ -150,8 +150,8 @@ struct CosinePrune {
     const uint2* list;       // kKeysList: (query, chunk) entries
     const uint32_t* nlist;   // their number (device word)
     uint32_t* ckeys;         // kKeysList: [entry][1 << cs_shift]
-    uint32_t q_base;         // kKeysList: the pass's first query within the batch the list numbers (a batch above the LDS image's
-                             // 16 G queries is listed once and rescored in slices)
+    uint32_t slices;         // kKeysList: a batch above the LDS image's 16 G queries is listed once and rescored in `slices`
+    uint32_t slice_q;        //            slices of slice_q queries by ONE launch (0 / 1: the whole batch is one image)
 };
 
 // Query image [nrows][qstride] in LDS from queries[nq_pass][dim] (16-byte aligned, dim % 4 == 0), zero-filled past dim and
@@ -195,11 +195,29 @@ constexpr int kCW = 8;    // waves per workgroup (one workgroup per CU: the quer
 template <int G, bool FULL, int MODE>
 __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __restrict__ rows,
                                                         const float* __restrict__ norms, size_t n, uint32_t dim,
-                                                        const float* __restrict__ queries,
-                                                        const float* __restrict__ qnorm, uint32_t nq_pass,
+                                                        const float* __restrict__ queries_all,
+                                                        const float* __restrict__ qnorm_all, uint32_t nq_all,
                                                         uint32_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ run_flag, CosinePrune pr) {
     if (run_flag && (MODE == kKeysList ? *run_flag != 0 : *run_flag == 0)) return;   // as in cosine_keys_blocks
+    // kKeysList over a batch above the image's 16 G queries: `slices` query slices in ONE launch, workgroup b takes slice
+    // b % slices (every slice walks the whole list and stores its own queries' entries); workgroups beyond the list leave
+    // before they fill an image (the launch is sized for the longest list the pass can produce).
+    uint32_t bid = blockIdx.x, nblocks = gridDim.x, q_base = 0, nq_pass = nq_all;
+    const float* __restrict__ queries = queries_all;
+    const float* __restrict__ qnorm = qnorm_all;
+    if (MODE == kKeysList) {
+        if (pr.slices > 1) {
+            const uint32_t sl = bid % pr.slices;
+            bid /= pr.slices;
+            nblocks /= pr.slices;
+            q_base = sl * pr.slice_q;
+            nq_pass = nq_all - q_base < pr.slice_q ? nq_all - q_base : pr.slice_q;
+            queries += (size_t)q_base * dim;
+            qnorm += q_base;
+        }
+        if ((size_t)bid * kCW >= (size_t)*pr.nlist) return;   // workgroup-uniform, before any barrier
+    }
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [16*G][dim16 + 4]
     const uint32_t dim16 = (dim + 15) & ~15u;
     const uint32_t qstride = dim16 + 4;
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
     // chunks of the NEXT tile are requested before this tile's epilogue.
     constexpr int U = 8;
     float4 xa[U], xb[U];
-    const size_t tstep = (size_t)gridDim.x * kCW;
+    const size_t tstep = (size_t)nblocks * kCW;
     auto row_ptr = [&](size_t t) {
         const size_t r = t * 16 + nn;
         return rows + (r < n ? r : 0) * (size_t)dim;   // dead rows read row 0; their results are not stored
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
         const size_t t = ((size_t)pr.list[it >> tsh].y << tsh) + (it & (((size_t)1 << tsh) - 1));
         return t < tiles ? t : tiles - 1;   // a chunk's tiles past the last row: recompute the last tile, nobody reads the keys
     };
-    size_t it = (size_t)blockIdx.x * kCW + wave;
+    size_t it = (size_t)bid * kCW + wave;
     uint32_t wave_min[G][4];   // kKeysMins: smallest key per result slot over this wave's tiles
 #pragma unroll
     for (int g = 0; g < G; g++)
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(kCW * 64) void cosine_keys_mfma(const float* __rest
                         m = min(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x121, 0xf, 0xf, false));   // row_ror:1
                         mq[r] = m;
                         wave_min[g][r] = min(wave_min[g][r], m);
-                    } else if (qt + pr.q_base == qe) {
+                    } else if (qt < nq_pass && qt + q_base == qe) {   // (qt < nq_pass: the image's padding rows belong to the next slice)
                         pr.ckeys[((it >> tsh) << pr.cs_shift) + ((it & (((size_t)1 << tsh) - 1)) << 4) + nn] = key;
                     }
                 }
@@ -387,7 +405,8 @@ __device__ __forceinline__ bool norm_in_range(float v) { return v >= 1e-30f && v
 // one wave per query: |q| exactly as cosine_norms computes it, and the query's row of the f16 image (dim % 32 == 0)
 __global__ __launch_bounds__(256) void cosine_norms_image(const float* __restrict__ queries, size_t nq, uint32_t dim,
                                                           float* __restrict__ norms, _Float16* __restrict__ image,
-                                                          uint32_t* __restrict__ flag) {
+                                                          uint32_t* __restrict__ zero2) {
+    if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0;   // the pass's flag and list counter (saves a memset launch)
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= nq) return;
@@ -397,11 +416,8 @@ __global__ __launch_bounds__(256) void cosine_norms_image(const float* __restric
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     const float qn = sqrtf(acc);
-    if (lane == 0) {
-        norms[row] = qn;
-        if (qn != 0.f && !norm_in_range(qn)) *flag = 1;   // (NaN too)
-    }
-    const float s = norm_in_range(qn) ? 1.0f / qn : 0.f;
+    if (lane == 0) norms[row] = qn;
+    const float s = norm_in_range(qn) ? 1.0f / qn : 0.f;   // (out of range, NaN: cosine_mins_f16 raises the fallback flag)
     for (uint32_t c = 4 * lane; c < dim; c += 256) {
         const f32x4v x = *reinterpret_cast<const f32x4v*>(v + c);
         f16x4v h;
@@ -448,6 +464,11 @@ __global__ __launch_bounds__(kCW * 64) void cosine_mins_f16(const float* __restr
             const uint32_t qt = g * 16 + 4 * q4 + r;
             qnr[g][r] = qt < nq_pass ? qnorm[qt] : 0.f;
         }
+    bool bad = false;
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) bad |= qnr[g][r] != 0.f && !norm_in_range(qnr[g][r]);   // (NaN too)
     // A wave's work is ONE stream of blocks (a block = 64 floats of the 16 rows of a tile = 4 KiB = 2 matrix steps), tile after
     // tile.  The rows are LOADED coalesced -- a wave load is 4 rows x 256 contiguous bytes, lane = (row in 4, 16-byte piece) --
     // and reach the matrix operand's layout (lane = (row in 16, k group)) through a 4.25 KiB stage per wave in LDS: written as
@@ -499,7 +520,6 @@ __global__ __launch_bounds__(kCW * 64) void cosine_mins_f16(const float* __restr
     uint32_t blk = 0;
 #pragma unroll
     for (int b = 0; b < R; b++) refill(x[b], nx[b]);
-    bool bad = false;
     __syncthreads();   // the query image is complete
     f32x4v acc[G];
     f16x8v qA[G], qB[G];
@@ -1221,18 +1241,18 @@ bool cosine_prune_ok(const float* rows, uint32_t dim, const float* queries, uint
 float cosine_mins_eps(uint32_t dim) { return 9.9e-4f + 1.25e-7f * (float)dim; }   // the bound derived at the kernel, rounded up
 uint32_t cosine_list_queries(uint32_t dim) { return (uint32_t)16 * (uint32_t)mfma_groups(dim); }
 bool cosine_mins_f16_ok(const float* rows, uint32_t dim, const float* queries, uint32_t nq_pass, size_t n, uint32_t k) {
-    if (!(nq_pass > 4 && nq_pass <= 64 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32))) return false;
+    if (!(nq_pass > 1 && nq_pass <= 64 && k >= 1 && k <= 64 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 32))) return false;
     if (dim % 64 != 0 || !mfma_ok(rows, dim) || (reinterpret_cast<uintptr_t>(queries) & 15u) != 0) return false;
     const uint32_t G = (nq_pass + 15) / 16;
     if ((size_t)16 * G * ((size_t)dim * 2 + 16) + 64 + (size_t)kCW * 16 * 272 > 158u * 1024u) return false;
     // a batch above the exact list pass's image is rescored in slices and falls back to the GEMM's dense keys
     return nq_pass <= cosine_list_queries(dim) || gemm_path(rows, dim, queries, nq_pass);
 }
-int launch_cosine_norms_image(const float* queries, size_t nq, uint32_t dim, float* norms, void* image, uint32_t* flag,
+int launch_cosine_norms_image(const float* queries, size_t nq, uint32_t dim, float* norms, void* image, uint32_t* zero2,
                               hipStream_t stream) {
     if (nq == 0) return 0;
     hipLaunchKernelGGL(cosine_norms_image, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, queries, nq, dim, norms,
-                       reinterpret_cast<_Float16*>(image), flag);
+                       reinterpret_cast<_Float16*>(image), zero2);
     return 0;
 }
 int launch_cosine_mins_f16(const float* rows, const float* norms, size_t n, uint32_t dim, const void* image, const float* qnorm,
@@ -1290,16 +1310,39 @@ int launch_cosine_keys_mins(const float* rows, const float* norms, size_t n, uin
 }
 int launch_cosine_keys_list(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries,
                             const float* qnorm, uint32_t nq_pass, const CosinePrunePlan& p, const void* list,
-                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream,
-                            uint32_t q_base) {
+                            const uint32_t* nlist, uint32_t* ckeys, const uint32_t* fallback_flag, hipStream_t stream) {
     CosinePrune pr{};
-    pr.q_base = q_base;
     pr.cs_shift = p.cs_shift;
     pr.qpad = p.qpad;
     pr.list = reinterpret_cast<const uint2*>(list);
     pr.nlist = nlist;
     pr.ckeys = ckeys;
-    launch_mfma<kKeysList>(rows, norms, n, dim, queries, qnorm, nq_pass, nullptr, fallback_flag, stream, pr);
+    const uint32_t per = cosine_list_queries(dim);
+    pr.slices = (nq_pass + per - 1) / per;
+    pr.slice_q = (nq_pass + pr.slices - 1) / pr.slices;
+    const int G = (int)((pr.slice_q + 15) / 16);
+    const uint32_t dim16 = (dim + 15) & ~15u;
+    const size_t lds = (size_t)16 * G * (dim16 + 4) * sizeof(float) + 64;
+    // sized for the longest list the pass can produce (capq chunks per query, one tile per wave)
+    unsigned grid = (unsigned)(((size_t)nq_pass * p.capq + kCW - 1) / kCW);
+    if (grid > 1024) grid = 1024;
+    grid *= pr.slices;
+    auto go = [&](auto kern) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kCW * 64), lds, stream, rows, norms, n, dim, queries, qnorm, nq_pass,
+                           (uint32_t*)nullptr, fallback_flag, pr);
+    };
+    const bool full = dim % 256 == 0;
+    if (full) {
+        if (G == 1) go(cosine_keys_mfma<1, true, kKeysList>);
+        else if (G == 2) go(cosine_keys_mfma<2, true, kKeysList>);
+        else go(cosine_keys_mfma<3, true, kKeysList>);
+    } else {
+        if (G == 1) go(cosine_keys_mfma<1, false, kKeysList>);
+        else if (G == 2) go(cosine_keys_mfma<2, false, kKeysList>);
+        else go(cosine_keys_mfma<3, false, kKeysList>);
+    }
     return 0;
 }
 // the dense keys of the same kernel (the gated fallback of the pass above: same arithmetic, so the answer does not depend on

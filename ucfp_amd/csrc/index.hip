@@ -240,7 +240,6 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     if (chunk < (size_t)qpp) chunk = qpp;
     if (chunk > 32768) chunk = 32768;  // queries ride on gridDim.y of the select kernel
     if (chunk > nq) chunk = nq;
-    auto qc_all_in_one = [](size_t total, size_t per_chunk) { return total <= per_chunk; };
     ucfp::SelectPlan sp = ucfp::select_plan(n, (uint32_t)chunk);
     size_t off = 0;
     const size_t o_qn = off;
@@ -286,9 +285,10 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
     // (only when the call can take that pass: one pass of <= 48 queries; 12 bytes per row)
     // round 4: the minima of 5 .. 64 queries come from the f16 matrix pipe where the shape allows (cosine_mins_f16: within
     // cosine_mins_eps of the exact score, the thresholds widened by as much), else from the f32 tile (<= 48 queries)
-    const bool prune_f16 = nq <= 64 && !getenv("UCFP_COSINE_NO_F16") &&
+    // (larger batches: passes of at most 64 queries, each its own chain)
+    const bool prune_f16 = !getenv("UCFP_COSINE_NO_F16") &&
                            ucfp::cosine_mins_f16_ok(reinterpret_cast<const float*>(s->rows), dim,
-                                                    reinterpret_cast<const float*>(d_queries), (uint32_t)nq, n, k);
+                                                    reinterpret_cast<const float*>(d_queries), (uint32_t)(nq < 64 ? nq : 64), n, k);
     const bool may_prune = prune_f16 || (nq <= 48 && nq <= (size_t)qpp &&
                                          ucfp::cosine_prune_ok(reinterpret_cast<const float*>(s->rows), dim,
                                                                reinterpret_cast<const float*>(d_queries), (uint32_t)nq, n, k));
@@ -340,42 +340,46 @@ int search_shard_dev(ucfp_index* ix, const Shard* s, const void* d_queries, size
         ucfp::launch_select_topk_u32(keymat, s->ids, m, pl, cnt, k, pid, pk, pc, st, run_flag);
         ucfp::launch_topk_merge_tree_u32(pid, pk, pl.slices, cnt, k, tid, tk, o_ids, o_keys, o_cnt, st, run_flag);
     };
-    if (prune_f16) {
-        HIP_TRY(hipMemsetAsync(w + o_pflag, 0, 8, st));
-        if (getenv("UCFP_COSINE_PRUNE_FALLBACK")) HIP_TRY(hipMemsetAsync(w + o_pflag, 1, 1, st));   // tests: the gated dense pass answers
-        ucfp::launch_cosine_norms_image(q, nq, dim, qn, w + o_qimg, reinterpret_cast<uint32_t*>(w + o_pflag), st);
-    } else {
-        ucfp::launch_cosine_norms(q, nq, dim, qn, st);
-    }
-    for (size_t q0 = 0; q0 < nq; q0 += chunk) {
-        if (prune_f16 && qc_all_in_one(nq, chunk)) {
-            // one pass of 5 .. 64 queries: approximate minima -> widened thresholds -> ~k listed chunks per query -> their EXACT
-            // keys (the f32 tile's list pass, in slices of the queries its LDS image holds) -> answer.  The dense pass and its
-            // selection follow, gated on the flag.
-            const uint32_t np = (uint32_t)nq;
-            const ucfp::CosinePrunePlan pp = ucfp::cosine_prune_plan(n, np, k, true);
-            const float eps = ucfp::cosine_mins_eps(dim);
-            uint32_t* pflag = reinterpret_cast<uint32_t*>(w + o_pflag);
-            uint32_t* pmin = reinterpret_cast<uint32_t*>(w + o_pmin);
-            uint32_t* pwmin = reinterpret_cast<uint32_t*>(w + o_pwmin);
-            uint32_t* ptau = reinterpret_cast<uint32_t*>(w + o_ptau);
-            uint32_t* pkeys = reinterpret_cast<uint32_t*>(w + o_pkeys);
-            ucfp::launch_cosine_mins_f16(rows, s->norms, n, dim, w + o_qimg, qn, np, pp, pmin, pwmin, pflag, st);
-            ucfp::launch_prune_tau(pmin, pwmin, pp, np, k, w + o_ptws, ptau, w + o_plist, pflag + 1, w + o_prange, pflag, st, eps);
-            const uint32_t per = ucfp::cosine_list_queries(dim);
-            const uint32_t nslices = (np + per - 1) / per, slice = (np + nslices - 1) / nslices;
-            for (uint32_t qb = 0; qb < np; qb += slice) {
-                const uint32_t ns = np - qb < slice ? np - qb : slice;
-                ucfp::launch_cosine_keys_list(rows, s->norms, n, dim, q + (size_t)qb * dim, qn + qb, ns, pp, w + o_plist, pflag + 1,
-                                              pkeys, pflag, st, qb);
-            }
-            ucfp::launch_prune_final(pkeys, pp, w + o_plist, w + o_prange, ptau, s->ids, n, np, k, d_out_ids, okeys, d_out_cnt,
-                                     pflag, st);
-            if (np <= per) ucfp::launch_cosine_keys_dense_mfma(rows, s->norms, n, dim, q, qn, np, keymat, pflag, st);
-            else ucfp::launch_cosine_keys(rows, s->norms, n, dim, q, qn, np, keymat, st, pflag);   // (the GEMM: cosine_mins_f16_ok)
-            select_merge(n, np, d_out_ids, okeys, d_out_cnt, pflag);
-            continue;
+    // one pass of 5 .. 64 queries: approximate minima -> widened thresholds -> ~k listed chunks per query -> their EXACT keys (the
+    // f32 tile's list pass, in slices of the queries its LDS image holds) -> answer.  The dense pass and its selection follow,
+    // gated on the flag.
+    auto f16_pass = [&](size_t qoff, uint32_t np) -> int {
+        const float* qp = q + qoff * dim;
+        float* qnp = qn + qoff;
+        uint64_t* oi = d_out_ids + qoff * k;
+        uint32_t* ok = okeys + qoff * k;
+        uint32_t* oc = d_out_cnt + qoff;
+        const ucfp::CosinePrunePlan pp = ucfp::cosine_prune_plan(n, np, k, true);
+        const float eps = ucfp::cosine_mins_eps(dim);
+        uint32_t* pflag = reinterpret_cast<uint32_t*>(w + o_pflag);
+        uint32_t* pmin = reinterpret_cast<uint32_t*>(w + o_pmin);
+        uint32_t* pwmin = reinterpret_cast<uint32_t*>(w + o_pwmin);
+        uint32_t* ptau = reinterpret_cast<uint32_t*>(w + o_ptau);
+        uint32_t* pkeys = reinterpret_cast<uint32_t*>(w + o_pkeys);
+        ucfp::launch_cosine_norms_image(qp, np, dim, qnp, w + o_qimg, pflag, st);   // (zeroes the flag and the list counter)
+        if (getenv("UCFP_COSINE_PRUNE_FALLBACK")) HIP_TRY(hipMemsetAsync(pflag, 1, 1, st));   // tests: the gated dense pass answers
+        ucfp::launch_cosine_mins_f16(rows, s->norms, n, dim, w + o_qimg, qnp, np, pp, pmin, pwmin, pflag, st);
+        ucfp::launch_prune_tau(pmin, pwmin, pp, np, k, w + o_ptws, ptau, w + o_plist, pflag + 1, w + o_prange, pflag, st, eps);
+        const uint32_t per = ucfp::cosine_list_queries(dim);
+        ucfp::launch_cosine_keys_list(rows, s->norms, n, dim, qp, qnp, np, pp, w + o_plist, pflag + 1, pkeys, pflag, st);
+        ucfp::launch_prune_final(pkeys, pp, w + o_plist, w + o_prange, ptau, s->ids, n, np, k, oi, ok, oc, pflag, st);
+        if (np <= per) ucfp::launch_cosine_keys_dense_mfma(rows, s->norms, n, dim, qp, qnp, np, keymat, pflag, st);
+        else ucfp::launch_cosine_keys(rows, s->norms, n, dim, qp, qnp, np, keymat, st, pflag);   // (the GEMM: cosine_mins_f16_ok)
+        select_merge(n, np, oi, ok, oc, pflag);
+        return 0;
+    };
+    if (prune_f16) {      // (the image kernel writes each pass's norms)
+        const size_t npass = (nq + 63) / 64, per_pass = (nq + npass - 1) / npass;
+        for (size_t q0 = 0; q0 < nq; q0 += per_pass) {
+            const int rc2 = f16_pass(q0, (uint32_t)(nq - q0 < per_pass ? nq - q0 : per_pass));
+            if (rc2) return rc2;
         }
+        if (d_out_scores) ucfp::launch_cosine_scores_from_keys(okeys, nq * k, d_out_scores, st);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    ucfp::launch_cosine_norms(q, nq, dim, qn, st);
+    for (size_t q0 = 0; q0 < nq; q0 += chunk) {
         const size_t qc = nq - q0 < chunk ? nq - q0 : chunk;
         // Batch passes over a large shard do not write the np x n key matrix: the exact answer over the first
         // kSample rows gives every query a threshold (its k-th best key there), the pass over the other rows keeps

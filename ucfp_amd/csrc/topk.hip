@@ -539,7 +539,15 @@ __global__ __launch_bounds__(256) void prune_bound_kernel(const uint32_t* __rest
     __shared__ __attribute__((aligned(16))) uint32_t s_tmin[256];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     uint32_t m = 0xffffffffu;
-    for (uint32_t w = tid; w < waves; w += 256) m = min(m, wmin[(size_t)q * waves + w]);
+    // (eight loads in flight per thread: one after the other the 32 of a 8192-wave launch were most of this kernel's 12 us)
+    const uint32_t* __restrict__ wq = wmin + (size_t)q * waves;
+    for (uint32_t w0 = tid; w0 < waves; w0 += 8 * 256) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = w0 + u * 256 < waves ? wq[w0 + u * 256] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 8; u++) m = min(m, v[u]);
+    }
     s_tmin[tid] = m;
     if (tid == 0) bound[q] = 0xffffffffu, ccnt[q] = 0;
     __syncthreads();

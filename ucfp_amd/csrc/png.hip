@@ -1034,51 +1034,52 @@ struct HuffLds {
 // parse_sub for the token kernel: EMIT = false counts (bytes, matches, token words), EMIT = true writes the tokens.
 template <bool EMIT, class LT>
 __device__ __forceinline__ Parse2 parse_tok(LT& L, uint32_t start, uint32_t limit, uint32_t out_pos, uint16_t* __restrict__ tok) {
+    // A divergent loop, lanes leaving as they finish, and plain divergent branches for the rare and the per-kind work: written
+    // with wave-uniform `if (__ballot(...))` guards around predicated bodies the step was ~45 vector + ~35 scalar instructions,
+    // a third of them materialising and re-testing predicates; four waves per SIMD are bound by issue, not by the LDS round trips.
     uint32_t pos = start, nb = 0, nm = 0, nt = 0, flags = 0;
-    bool act = pos < limit;
-    while (__ballot(act)) {
-        const uint32_t p = act ? pos : start;
-        const uint32_t w = p >> 5, sh = p & 31;
+    while (pos < limit) {
+        const uint32_t w = pos >> 5, sh = pos & 31;
         const uint32_t w0 = L.stage[w], w1 = L.stage[w + 1], w2 = L.stage[w + 2];
         const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, sh), x2 = __builtin_amdgcn_alignbit(w2, w1, sh);
         uint32_t e = L.lit[x & ((1u << kRoot) - 1)];
-        if (__ballot(act && (e >> 24) == kSlow)) {
-            if ((e >> 24) == kSlow) e = slow_code32(x, L.ll_count, L.ll_sorted, false);
-        }
+        if ((e >> 24) == kSlow) e = slow_code32(x, L.ll_count, L.ll_sorted, false);
         const uint32_t cl = (e >> 20) & 15u, kind = e >> 24, ex = (e >> 16) & 15u;
         const uint32_t s1 = cl + ex;
-        const bool is_len = kind == kLen;
-        const uint32_t len = (e & 0xffffu) + ((x >> cl) & ((1u << ex) - 1u));
-        uint32_t adv = s1, dist = 0;
-        bool bad = cl == 0;
-        if (__ballot(act && is_len)) {
+        if (cl == 0) {
+            flags |= 2u;
+            break;
+        }
+        if (kind == kLen) {
+            const uint32_t len = (e & 0xffffu) + ((x >> cl) & ((1u << ex) - 1u));
             const uint32_t y = __builtin_amdgcn_alignbit(x2, x, s1);
             uint32_t d = L.dst[y & ((1u << kDRoot) - 1)];
-            if (__ballot(act && is_len && (d >> 24) == kSlow)) {
-                if (is_len && (d >> 24) == kSlow) d = slow_code32(y, L.d_count, L.d_sorted, true);
-            }
+            if ((d >> 24) == kSlow) d = slow_code32(y, L.d_count, L.d_sorted, true);
             const uint32_t dl = (d >> 20) & 15u, dex = (d >> 16) & 15u;
-            dist = (d & 0xffffu) + ((y >> dl) & ((1u << dex) - 1u));
-            adv = is_len ? s1 + dl + dex : adv;
-            bad = bad || (is_len && dl == 0);
-        }
-        const bool lit = kind == kLit, eob = kind == kEob;
-        const bool go = act && !bad;
-        if (EMIT) {
-            if (go && lit) tok[nt] = (uint16_t)(e & 0xffu);
-            if (go && is_len) {
+            if (dl == 0) {
+                flags |= 2u;
+                break;
+            }
+            const uint32_t dist = (d & 0xffffu) + ((y >> dl) & ((1u << dex) - 1u));
+            if (EMIT) {
                 if (dist > out_pos + nb) flags |= 2u;          // reaches back before the first byte of the image
                 tok[nt] = (uint16_t)(0x8000u | (len - 3u));
                 tok[nt + 1] = (uint16_t)(dist - 1u);
             }
+            pos += s1 + dl + dex;
+            nb += len;
+            nm += 1u;
+            nt += 2u;
+        } else if (kind == kLit) {
+            if (EMIT) tok[nt] = (uint16_t)(e & 0xffu);
+            pos += s1;
+            nb += 1u;
+            nt += 1u;
+        } else {           // end of block (any other kind: not a code)
+            flags |= kind == kEob ? 1u : 2u;
+            pos += kind == kEob ? s1 : 0u;
+            break;
         }
-        flags |= (act && bad) ? 2u : 0u;
-        flags |= (go && eob) ? 1u : 0u;
-        pos += go ? adv : 0u;
-        nb += (go && lit) ? 1u : (go && is_len) ? len : 0u;
-        nm += (go && is_len) ? 1u : 0u;
-        nt += (go && lit) ? 1u : (go && is_len) ? 2u : 0u;
-        act = go && !eob && pos < limit;
     }
     return Parse2{start, pos, nb | nm << 17 | flags << 30, nt};
 }

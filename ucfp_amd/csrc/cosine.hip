@@ -1,4 +1,4 @@
-// cosine.hip -- exact brute-force cosine top-k over f32 embeddings for gfx950.
+// cosine.hip -- exact brute-force cosine top-k over f32 embeddings for gfx950 (every reported score is an f32 dot product).
 //
 // Replaces EmbeddedBackend::knn phase 2 (src/index/embedded/mod.rs:324-340): for every row v of
 // the tenant, score = dot(q, v) / (|q| |v|), rows with |v| = 0 skipped, a query with |q| = 0
@@ -16,6 +16,11 @@
 //     cosine_keys_gemm<NG,FILT,RT> batches: 256 queries per corpus read, K slices staged by LDS-DMA; FILT keeps
 //                                 only rows that beat a per-query threshold (candidate lists, no key matrix)
 //     cosine_keys                 VALU kernel for every other shape: 8 lanes share a row, queries from LDS
+//   round 4: batches of 2 .. 64 queries per pass over >= 2^17 rows of dim % 64 == 0 do not compute exact keys for every row:
+//     cosine_norms_image + cosine_mins_f16<G>   the smallest APPROXIMATE key of every 16-row chunk through the f16 matrix
+//                                 pipe (rows loaded coalesced, transposed through LDS), within cosine_mins_eps of the exact one
+//     topk.hip prune_* (eps)      thresholds widened by that bound -> ~k listed chunks per query
+//     cosine_keys_mfma<G,.,list>  the exact f32 keys of the listed chunks -> prune_final picks the answer
 //   the score is mapped to an order-preserving u32 key (ascending key = descending score), keys[q][row]
 //   select_topk_u32       (topk.hip) per (slice, query): wave-shared candidate list + threshold
 //   topk_select_lists_u32 (topk.hip) best k of the sample's answer + a candidate list (thresholded pass)

@@ -880,6 +880,31 @@ def test_cosine_f16_minima(gpu_ctx, n, dim, nq, k, cluster):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim", [640, 896, 576, 832])
+def test_cosine_small_shard_dims_between_kernel_instances(gpu_ctx, dim):
+    """5-16 queries over a shard below 2^17 rows take the 4x4x1 row-stream kernel, whose instances walk 2 / 4 / 6 / 8 / 12 / 16
+    chunks of 64 floats: a dim whose chunk count lies between two instances (577-640, 833-896) runs an instance wider than its
+    rows, and the query image has to be as wide (round 4: it was not -- the surplus chunks' operands of the last queries came
+    from behind the image, NaN patterns there made NaN scores and the rows were dropped.  Whether it bites depends on what an
+    earlier kernel left in LDS: `python tools/soak_index.py --seed 33` reproduced it within 25 s (profiles/r04/soak_index_seed33.txt);
+    this test pins the shapes."""
+    from ucfp_amd import index
+    rng = np.random.default_rng(dim)
+    n, nq, k = 40_000, 16, 50
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    ids = rng.permutation(n).astype(np.uint64)
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    for _ in range(3):          # (what lay behind the image depended on the previous launch)
+        g_ids, g_sc, _, g_c = ix.search(0, queries, k)
+        _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k)
+        g_ids, g_sc, _, g_c = ix.search(0, queries[:9], 10)
+        _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries[:9], 10)
+    ix.close()
+
+
+@pytest.mark.gpu
 def test_cosine_f16_minima_out_of_range_norms_fall_back(gpu_ctx):
     """A row or a query whose f32 norm is not a finite number in [1e-30, 1e30] (components around 1e20 and above: the sum of
     squares overflows) cannot be scaled into f16 with a bounded error: the f16 pass raises the fallback flag and the dense pass

@@ -93,15 +93,19 @@ def main():
             rows = torch.randn((n, dim), dtype=torch.float32, device=dev, generator=g)
             ids = torch.randperm(n, device=dev, generator=g).to(torch.int64)
             q = torch.randn((nq, dim), dtype=torch.float32, device=dev, generator=g)
+            planted = []
             if rng.random() < 0.5:      # clusters of near-matches around some queries (scores 1 - O(noise^2)): inside the f16 minima's margin
                 for j in rng.integers(0, nq, int(rng.integers(1, 5))):
                     m = int(rng.choice([5, 30, 200]))
                     pos = torch.from_numpy(rng.integers(0, n, m)).to(dev)
                     noise = float(rng.choice([1e-3, 1e-2, 5e-2]))
                     rows[pos] = q[int(j)][None, :] + noise * torch.randn((m, dim), dtype=torch.float32, device=dev, generator=g)
+                    planted.append(("cluster", int(j), m, noise))
             if rng.random() < 0.3:      # rows of very different magnitudes: the scores do not change
                 pos = torch.from_numpy(rng.integers(0, n, 64)).to(dev)
-                rows[pos] *= float(rng.choice([1e-9, 1e-4, 1e6, 1e11]))
+                scale = float(rng.choice([1e-9, 1e-4, 1e6, 1e11]))
+                rows[pos] *= scale
+                planted.append(("scale", scale))
             ix = index.DeviceIndex(index.COSINE_F32, dim, index.APPEND_ONLY, ctx)
             ix.append_dev(0, ids.data_ptr(), rows.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
             o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -113,7 +117,12 @@ def main():
             sc = (q.double() @ rows.double().T) / (q.double().norm(dim=1)[:, None] * rows.double().norm(dim=1)[None, :])
             kk = min(k, n)
             ref_sc, ref_ix = torch.topk(sc, min(kk + 1, n), dim=1)
-            assert (o_sc[:, :kk].double() - ref_sc[:, :kk]).abs().max() <= 1e-5, ("cosine score", n, dim, nq, k)
+            diff = (o_sc[:, :kk].double() - ref_sc[:, :kk]).abs()
+            if float(diff.max()) > 1e-5:       # what was planted, which query and rank, what came back
+                qi = int(diff.max(dim=1).values.argmax())
+                print("cosine score mismatch:", (n, dim, nq, k), "planted", planted, "query", qi, "counts", o_c.tolist(),
+                      "\n gpu", o_sc[qi, :kk].tolist(), "\n ref", ref_sc[qi, :kk].tolist(), flush=True)
+            assert float(diff.max()) <= 1e-5, ("cosine score", n, dim, nq, k)
             gap = (ref_sc[:, :-1] - ref_sc[:, 1:]) > 2e-5 if ref_sc.shape[1] > 1 else None
             ref_ids = ids[ref_ix[:, :kk]]
             same = o_ids[:, :kk] == ref_ids

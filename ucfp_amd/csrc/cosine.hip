@@ -1114,7 +1114,11 @@ bool blocks_path(const float* rows, uint32_t dim, const float* queries, uint32_t
 void launch_blocks(const float* rows, const float* norms, size_t n, uint32_t dim, const float* queries, const float* qnorm,
                    uint32_t nq_pass, uint32_t* keys, const uint32_t* run_flag, hipStream_t stream) {
     const uint32_t nch = ((dim + 63) / 64 + 1) & ~1u;      // whole chunks, an even number of them
-    const uint32_t qstride = nch * 64 + 16;                // >= dim, and 16 mod 64 floats: conflict-free A reads
+    // the kernel instance walks tn >= nch chunks (rows beyond dim load as zeros): the query image must be that wide too, or the
+    // last queries' operands of the surplus chunks come from whatever lies behind the image -- a NaN pattern there (the key
+    // stage's 0xffffffff) times a zero row is a NaN score, and the row is dropped (dims 577-640 and 833-896; found by the soak)
+    const uint32_t tn = nch <= 2 ? 2 : nch <= 4 ? 4 : nch <= 6 ? 6 : nch <= 8 ? 8 : nch <= 12 ? 12 : 16;
+    const uint32_t qstride = tn * 64 + 16;                 // >= dim, and 16 mod 64 floats: conflict-free A reads
     const size_t lds = (size_t)16 * qstride * sizeof(float) + (size_t)kBW * 16 * 32 * sizeof(uint32_t);
     const size_t supers = (n + 31) / 32;
     unsigned grid = (unsigned)((supers + kBW - 1) / kBW);

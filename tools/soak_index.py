@@ -82,9 +82,9 @@ def main():
                     assert torch.equal(oi[j:j + 64, :kk], ref & 0xFFFFFFFF), ("hamming id", n, nq, k)
             ix.close()
         else:
-            n = int(rng.choice([900, 5000, 40_000, 270_000, 600_000]))
-            dim = int(rng.choice([32, 64, 100, 128, 192, 256, 384, 512, 640, 768, 1024]))
-            nq = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 17, 33, 40, 48, 49, 130, 300]))
+            n = int(rng.choice([900, 5000, 40_000, 131_072, 140_001, 270_000, 600_000]))
+            dim = int(rng.choice([32, 64, 96, 100, 128, 160, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 832, 896, 960, 1024, 1152, 1536, 2048]))
+            nq = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 33, 40, 48, 49, 64, 65, 100, 130, 300]))
             k = int(rng.choice([1, 10, 20, 50, 64]))
             if n * dim > 250_000_000:
                 n = 250_000_000 // dim

@@ -1805,7 +1805,8 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t* __restr
             // what the lane above produced in the previous step (lane 0: lane 63's stored row)
             uint32_t up[BPP];
 #pragma unroll
-            for (int ch = 0; ch < BPP; ch++) up[ch] = __shfl_up(prev_out[ch], 1, 64);
+            for (int ch = 0; ch < BPP; ch++)      // wave_shr:1 on the vector pipe (__shfl_up is a ds_bpermute: an LDS round trip, and the compiler waits for each)
+                up[ch] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)prev_out[ch], 0x138, 0xf, 0xf, false);
             const int tt = (int)t - lane;
             const bool live = tt >= 0;
             const uint32_t xi = (uint32_t)tt & 63u;

@@ -1367,8 +1367,13 @@ HammingPlan hamming_plan(size_t n, uint32_t nq, uint32_t k) {
         static const char* gl = getenv("UCFP_HAMMING_GROWTH_LARGE");   // (tuning)
         if (gl && nq > 256) growth = (size_t)atoi(gl);
         // (with the bound pass the first stage starts over at row 0, so there is one even when bound_n == n)
+        // (a last stage over a remainder below a quarter of the stage before it is not worth its launches -- scan, rescan and
+        // threshold kernels, 35-60 us at 4096 queries -- nor its under-filled grid: 1.25 M codes x 4096 queries ran 2^20 + 0.2 M
+        // in 103 + 33 us of scans; the stage before takes the remainder along)
+        static const char* nomerge = getenv("UCFP_HAMMING_NO_STAGE_MERGE");   // (measurement)
         do {
             e = e * growth < n ? e * growth : n;
+            if (!nomerge && n - e < e / 4) e = n;
             p.stage_end[p.nstages++] = e;
         } while (e < n && p.nstages < 12);
         p.stage_end[p.nstages - 1] = n;

@@ -76,3 +76,40 @@ def test_f16_minima_error_bound_adversarial_search():
         err = abs(float(approx_scores(q.astype(np.float32), v[None, :])[0]) - float(exact_scores(q, v[None, :])[0]))
         worst = max(worst, err)
     assert worst <= eps(dim), worst
+
+
+# ---- the thresholds' widening (ucfp_amd/csrc/topk.hip relax_key), restated -------------------------------------------------
+def score_to_key(s):
+    u = np.asarray(s, np.float32).view(np.uint32)
+    u = np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000))
+    return ~u
+
+
+def key_to_score(k):
+    u = ~np.asarray(k, np.uint32)
+    u = np.where(u & np.uint32(0x80000000), u & np.uint32(0x7FFFFFFF), ~u)
+    return u.view(np.float32)
+
+
+def relax_key(key, d):
+    key = np.asarray(key, np.uint32)
+    r = score_to_key(key_to_score(key) - np.float32(d))
+    r = np.where(r < key, key, r)
+    return np.where(key == np.uint32(0xFFFFFFFF), key, r)
+
+
+def test_keys_are_the_inverted_order_image_of_the_score_and_relaxing_only_widens():
+    rng = np.random.default_rng(9)
+    s = np.concatenate([rng.uniform(-1, 1, 4000), [0.0, 1.0, -1.0, 1e-30, -1e-30, 0.177, 0.9999999]]).astype(np.float32)
+    k = score_to_key(s)                 # (-0.0 sorts one key behind +0.0: the order image of the bits, harmless)
+    assert np.array_equal(key_to_score(k).view(np.uint32), s.view(np.uint32))                       # a bijection on the bits
+    o = np.argsort(s, kind="stable")
+    assert np.all(np.diff(k[o].astype(np.int64)) <= 0)                                              # larger score, smaller key
+    for d in (0.0, 1.1e-3, 2.2e-3):
+        r = relax_key(k, d)
+        assert np.all(r >= k)                                                                       # never tighter
+        # everything within d of the threshold's score passes the widened threshold: key(s') <= relax(key(s), d) for s' >= s - d
+        sp = (s.astype(np.float64) - d * rng.uniform(0, 1, s.size)).astype(np.float32)
+        sp = np.maximum(sp, (s - np.float32(d)).astype(np.float32))
+        assert np.all(score_to_key(sp) <= r)
+    assert relax_key(np.uint32(0xFFFFFFFF), 1e-3) == np.uint32(0xFFFFFFFF)                          # "no threshold" stays

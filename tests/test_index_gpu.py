@@ -244,25 +244,35 @@ def test_cosine_matches_oracle(gpu_ctx, oracle, n, dim, nq, k):
 
 
 def _check_cosine_against_f64(g_ids, g_sc, g_c, ids, rows, queries, k):
+    """float64 reference for a whole batch: one matrix product per 64 queries, then per query the rows at or above its k-th best
+    score ordered by (score desc, id asc)."""
     r64 = rows.astype(np.float64)
     rn = np.sqrt((r64 * r64).sum(1))
-    for q in range(queries.shape[0]):
-        q64 = queries[q].astype(np.float64)
-        sc = (r64 @ q64) / np.maximum(rn * np.sqrt((q64 * q64).sum()), 1e-300)
-        sc[rn == 0] = -np.inf
-        order = np.lexsort((ids, -sc))[:k]
-        o_sc, o_ids = sc[order], ids[order]
-        m = int(np.isfinite(o_sc).sum())
-        assert g_c[q] == m, (q, g_c[q], m)
-        assert np.abs(g_sc[q, :m] - o_sc[:m]).max() <= COS_TOL, (q, g_sc[q, :m], o_sc[:m])
-        gap_ok = np.ones(m, bool)
-        if m > 1:
-            close = np.abs(np.diff(o_sc[:m])) <= 2 * COS_TOL
-            gap_ok[:-1] &= ~close
-            gap_ok[1:] &= ~close
-        if m == k and m > 0:
-            gap_ok[-1] = False
-        assert np.array_equal(g_ids[q, :m][gap_ok], o_ids[:m][gap_ok]), q
+    n = r64.shape[0]
+    q64 = queries.astype(np.float64)
+    qn = np.sqrt((q64 * q64).sum(1))
+    for q0 in range(0, queries.shape[0], 64):
+        dots = r64 @ q64[q0:q0 + 64].T                                      # n x (<= 64)
+        for j in range(dots.shape[1]):
+            q = q0 + j
+            sc = dots[:, j] / np.maximum(rn * qn[q], 1e-300)
+            sc[rn == 0] = -np.inf
+            kk = min(k, n)
+            thr = np.partition(sc, n - kk)[n - kk]                          # the k-th best score: everything at or above it competes
+            cand = np.nonzero(sc >= thr)[0]
+            order = cand[np.lexsort((ids[cand], -sc[cand]))][:k]
+            o_sc, o_ids = sc[order], ids[order]
+            m = int(np.isfinite(o_sc).sum())
+            assert g_c[q] == m, (q, g_c[q], m)
+            assert np.abs(g_sc[q, :m] - o_sc[:m]).max() <= COS_TOL, (q, g_sc[q, :m], o_sc[:m])
+            gap_ok = np.ones(m, bool)
+            if m > 1:
+                close = np.abs(np.diff(o_sc[:m])) <= 2 * COS_TOL
+                gap_ok[:-1] &= ~close
+                gap_ok[1:] &= ~close
+            if m == k and m > 0:
+                gap_ok[-1] = False
+            assert np.array_equal(g_ids[q, :m][gap_ok], o_ids[:m][gap_ok]), q
 
 
 @pytest.mark.parametrize("nq,k", [(100, 10), (300, 1), (64, 50)])

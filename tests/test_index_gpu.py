@@ -890,6 +890,34 @@ def test_cosine_f16_minima(gpu_ctx, n, dim, nq, k, cluster):
 
 
 @pytest.mark.gpu
+def test_cosine_f16_minima_non_finite_rows(gpu_ctx):
+    """Rows with a NaN or an infinite component have no cosine score (the f32 arithmetic drops or zeroes them); the f16 pass
+    cannot bound its error on them, raises the fallback flag, and the answer is the f32 path's bit for bit."""
+    import os
+    from ucfp_amd import index
+    rng = np.random.default_rng(12)
+    n, dim, nq, k = 135_000, 128, 24, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    rows[17, 3] = np.nan
+    rows[90_000, :] = np.inf
+    rows[123_456, 5] = -np.inf
+    rows[50_000] = queries[2] * np.float32(4.0)              # a finite exact-direction match must still be found
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    ix = index.DeviceIndex(index.COSINE_F32, dim, ctx=gpu_ctx)
+    ix.upsert(0, ids, rows)
+    g = ix.search(0, queries, k)
+    os.environ["UCFP_COSINE_NO_F16"] = "1"
+    try:
+        d = ix.search(0, queries, k)
+    finally:
+        del os.environ["UCFP_COSINE_NO_F16"]
+    assert np.array_equal(g[3], d[3]) and np.array_equal(g[0], d[0]) and np.array_equal(g[1], d[1], equal_nan=True)
+    assert g[0][2, 0] == 50_000 * 2 + 1 and abs(g[1][2, 0] - 1.0) <= COS_TOL
+    ix.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dim", [640, 896, 576, 832])
 def test_cosine_small_shard_dims_between_kernel_instances(gpu_ctx, dim):
     """5-16 queries over a shard below 2^17 rows take the 4x4x1 row-stream kernel, whose instances walk 2 / 4 / 6 / 8 / 12 / 16
